@@ -1,0 +1,105 @@
+"""Shared helpers for the test-suite: golden fixture loading and synthetic tables."""
+
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict
+
+import numpy as np
+
+from oracle import suave_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name: str):
+    path = os.path.join(GOLDEN, name + ".npz")
+    z = np.load(path, allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def columns_from_json(text) -> list:
+    cols = []
+    for c in json.loads(str(text)):
+        cols.append(orc.Column(c["name"], c["type"], c.get("n_classes"), c.get("y_dim"), c.get("stats") or {}))
+    return cols
+
+
+def fixture_model(fx) -> tuple:
+    meta = json.loads(str(fx["meta"]))
+    cols = columns_from_json(fx["columns"])
+    om = orc.OracleModel(cols, n_components=meta["K"], latent_dim=meta["D"], hidden=tuple(meta["hidden"]),
+                         dropout=meta.get("dropout", 0.0), behaviour=meta.get("behaviour", "supervised"))
+    P = {k[len("param/"):]: v for k, v in fx.items() if k.startswith("param/")}
+    return om, P, meta
+
+
+def fixture_noise(fx, om, meta) -> Dict[str, object]:
+    noise: Dict[str, object] = {"exp": fx["noise/exp"], "eps": fx["noise/eps"]}
+    nh = len(om.hidden)
+    if meta.get("dropout", 0.0) > 0:
+        noise["enc_drop"] = [fx[f"noise/enc_drop{i}"] for i in range(nh)]
+        if meta["behaviour"] == "supervised":
+            noise["dec_drop"] = [fx[f"noise/dec_drop0_{i}"] for i in range(nh)]
+        else:
+            noise["dec_drop"] = [[fx[f"noise/dec_drop{j}_{i}"] for i in range(nh)] for j in range(om.K)]
+    return noise
+
+
+# ---------------------------------------------------------------------------
+# synthetic tables
+# ---------------------------------------------------------------------------
+def s64_columns(n_cols: int = 64, real_variant: str = "std"):
+    """Columns cycle [real,pos,count,cat,ordinal]; class counts cycle [2,3,4,5,8]."""
+
+    cyc = ["real", "pos", "count", "cat", "ordinal"]
+    classes = [2, 3, 4, 5, 8]
+    cols = []
+    n_disc = 0
+    for j in range(n_cols):
+        t = cyc[j % 5]
+        if t == "real":
+            st = {"mean": 0.0, "std": 1.0} if real_variant == "std" else {"mean": 50.0, "std": 12.0}
+            cols.append(orc.Column(f"f{j}", t, stats=st))
+        elif t == "pos":
+            cols.append(orc.Column(f"f{j}", t, stats={"mean_log": 1.2, "std_log": 0.45}))
+        elif t == "count":
+            cols.append(orc.Column(f"f{j}", t, stats={"offset": 1.0}))
+        else:
+            cols.append(orc.Column(f"f{j}", t, n_classes=classes[n_disc % 5]))
+            n_disc += 1
+    return cols
+
+
+def synth_packed(cols, B, mask_rate, seed):
+    rng = np.random.default_rng(seed)
+    n_num = sum(c.type in ("real", "pos", "count") for c in cols)
+    xnum = np.zeros((B, n_num), np.float32)
+    codes = np.zeros((B, len(cols) - n_num), np.int16)
+    mask = (rng.random((B, len(cols))) >= mask_rate).astype(np.uint8)
+    i_num = i_disc = 0
+    for j, c in enumerate(cols):
+        if c.type == "real":
+            xnum[:, i_num] = rng.standard_normal(B)
+        elif c.type == "pos":
+            raw = rng.lognormal(1.0, 0.5, B)
+            xnum[:, i_num] = (np.log1p(raw) - c.stats["mean_log"]) / c.stats["std_log"]
+        elif c.type == "count":
+            cnt = rng.poisson(3.0, B)
+            xnum[:, i_num] = np.log(cnt + c.stats["offset"] + (1.0 if c.stats["offset"] == 0 else 0.0))
+        if c.type in ("real", "pos", "count"):
+            xnum[mask[:, j] == 0, i_num] = 0.0
+            i_num += 1
+        else:
+            codes[:, i_disc] = rng.integers(0, c.n_classes, B)
+            codes[mask[:, j] == 0, i_disc] = -1
+            i_disc += 1
+    return xnum, codes, mask
+
+
+def rel_err(a, b, floor=1e-6):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    scale = max(float(np.max(np.abs(b))), floor)
+    return float(np.max(np.abs(a - b))) / scale
