@@ -1,0 +1,220 @@
+/*
+ * suave_hip.h -- C-ABI of libsuave_hip.so: the MI355X (gfx950) implementation of
+ * SUAVE's ELBO training step and generative decode.
+ *
+ * The reference (xuxu-wei/SUAVE @ 2025-10-03) is pure Python/PyTorch and has no
+ * FFI; its boundary for this path is the object protocol between
+ * suave/model.py and suave/modules/{encoder,decoder,distributions,losses,prior}.py
+ * + suave/sampling.py.  Each entry point below names the
+ * reference code it replaces (file:line under the reference root).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in _host;
+ *  - the caller owns every buffer; the library allocates no device memory after
+ *    suave_plan_create (query sizes with suave_workspace_bytes);
+ *  - all launches go to the caller-supplied hipStream_t (passed as void*);
+ *    calls are asynchronous with respect to the host;
+ *  - return value: 0 on success, non-zero error code otherwise; the message of
+ *    the last error on the calling thread is returned by suave_last_error();
+ *    no C++ exception crosses the ABI;
+ *  - one plan per device; a plan is immutable after creation and may be shared
+ *    by calls that use distinct workspaces.
+ *
+ * Data layout in HBM
+ *  - packed table: xnum  float32 [n_rows, ld_num]   real/pos/count cells, schema order
+ *                  codes int16   [n_rows, ld_disc]  cat code / ordinal level, -1 = all-zero encoding
+ *                  mask  uint8   [n_rows, ld_mask]  1 = observed, schema order
+ *    (the reference's dense one-hot / thermometer tensors, model.py:2784-2922,
+ *    are never materialised in HBM except as the encoder input tile);
+ *  - parameters: one flat float32 buffer, layout given by suave_layer_t /
+ *    suave_col_t offsets; weight matrices are [n_out, ld] row-major with ld a
+ *    multiple of 4 floats, pad entries zero;
+ *  - gradients, Adam moments: flat buffers with the parameter layout.
+ */
+#ifndef SUAVE_HIP_H
+#define SUAVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUAVE_TYPE_REAL 0
+#define SUAVE_TYPE_POS 1
+#define SUAVE_TYPE_COUNT 2
+#define SUAVE_TYPE_CAT 3
+#define SUAVE_TYPE_ORDINAL 4
+
+#define SUAVE_MAX_HIDDEN 8
+#define SUAVE_MAX_COMPONENTS 32
+
+/* One column of the schema, in schema order (suave/types.py:9-33; head
+ * modules suave/modules/decoder.py:56-265). */
+typedef struct suave_col_t {
+  int32_t type;      /* SUAVE_TYPE_* */
+  int32_t n_classes; /* cat / ordinal, else 0 */
+  int32_t y_off;     /* first column of this feature's slice of y_full (decoder.py:306-314) */
+  int32_t y_dim;     /* width of that slice (types.py:267-287) */
+  int32_t x_index;   /* column in xnum (numeric types) or in codes (cat / ordinal) */
+  int32_t enc_off;   /* first column of the feature's values in the encoder input (model.py:2813-2905) */
+  int32_t enc_mask;  /* column of the feature's mask in the encoder input */
+  int32_t w_off;     /* flat-parameter offset: mean_layer / rate_layer / logits_layer / partition_layer weight */
+  int32_t w2_off;    /* flat-parameter offset: var_layer (real,pos) / mean_layer (ordinal); -1 otherwise */
+  float scale;       /* std (real) / std_log (pos); 1 otherwise */
+  float shift;       /* mean (real) / mean_log (pos) / offset (count); 0 otherwise */
+} suave_col_t;
+
+/* One dense layer: weight [n_out, ld] row-major at w_off, bias [n_out] at b_off. */
+typedef struct suave_layer_t {
+  int32_t w_off, b_off, n_out, n_in, ld;
+} suave_layer_t;
+
+/* Model description.  Layers: encoder hidden layers, encoder head (rows
+ * [0,K) = component_logits, [K,K+K*D) = mu_layer, then logvar_layer;
+ * encoder.py:56-58), decoder hidden layers, y_projection (decoder.py:300). */
+typedef struct suave_model_t {
+  int32_t n_cols, n_num, n_disc;
+  int32_t n_components; /* K */
+  int32_t latent_dim;   /* D */
+  int32_t n_hidden;     /* number of hidden layers in encoder and decoder */
+  int32_t enc_in;       /* I: encoder input width */
+  int32_t total_y;      /* Y */
+  int32_t behaviour;    /* 0 supervised (trainable prior tensors), 1 unsupervised (PriorMean) */
+  int32_t n_params;     /* length of the flat parameter buffer */
+  float dropout;        /* p of nn.Dropout after every hidden ReLU */
+  suave_layer_t enc[SUAVE_MAX_HIDDEN];
+  suave_layer_t enc_head;
+  suave_layer_t dec[SUAVE_MAX_HIDDEN];
+  suave_layer_t y_proj;
+  int32_t head_off, head_len; /* contiguous range of all likelihood-head weights */
+  /* prior: supervised -> logits[K], mu[K,D], logvar[K,D] (model.py:543-551);
+   * unsupervised -> pm_w = PriorMean.linear.weight [D,K], pm_b = bias [D]
+   * (prior.py:20-39), prior logits / logvar fixed at zero (model.py:538-542). */
+  int32_t prior_logits_off, prior_mu_off, prior_logvar_off;
+  int32_t pm_w_off, pm_b_off;
+} suave_model_t;
+
+/* A batch of rows of the packed table.  row_index == NULL selects rows
+ * [row_begin, row_begin + n_rows); otherwise row_index[i] is the table row of
+ * batch row i (the per-epoch permutation slice, model.py:1465-1491). */
+typedef struct suave_batch_t {
+  const float* xnum;
+  const int16_t* codes;
+  const uint8_t* mask;
+  const int32_t* row_index;
+  int64_t row_begin;
+  int32_t n_rows;
+  int32_t ld_num, ld_disc, ld_mask;
+} suave_batch_t;
+
+/* Noise of one ELBO step (SURVEY.md section 8a "noise inventory").  A NULL
+ * pointer makes the kernels draw that noise themselves from the counter-based
+ * generator keyed by (seed, step, table row); non-NULL pointers inject
+ * explicit tensors (parity runs). */
+typedef struct suave_noise_t {
+  const float* exp_noise;  /* [B,K]   Exp(1) draws behind the Gumbel noise (F.gumbel_softmax) */
+  const float* eps;        /* [B,D] supervised / [B,K,D] unsupervised: N(0,1) of model.py:2929 */
+  const uint8_t* enc_keep[SUAVE_MAX_HIDDEN]; /* [B,H_i] dropout keep masks, encoder.py:52 */
+  const uint8_t* dec_keep[SUAVE_MAX_HIDDEN]; /* [B(*K),H_i] dropout keep masks, decoder.py:292 */
+  uint64_t seed;
+  uint64_t step;
+} suave_noise_t;
+
+/* Per-row outputs of the ELBO step: the return contract of
+ * SUAVE._forward_elbo_batch (model.py:1656-1667).  Any pointer may be NULL. */
+typedef struct suave_elbo_out_t {
+  float* reconstruction; /* [B] */
+  float* categorical_kl; /* [B] */
+  float* gaussian_kl;    /* [B] */
+  float* latent;         /* [B,D] */
+  int32_t* component;    /* [B] selected component (supervised) */
+  float* enc_out;        /* [B, K + 2*K*D]: component_logits | component_mu | component_logvar (clamped) */
+  double* sums;          /* [4]: sum recon, sum cat_kl, sum gauss_kl, n_rows -- accumulated (+=) */
+} suave_elbo_out_t;
+
+typedef struct suave_plan suave_plan; /* opaque */
+
+const char* suave_last_error(void);
+
+/* Compile a schema into a device-resident plan (column table, chunking,
+ * launch geometry).  Replaces the Python-side construction of EncoderMLP /
+ * Decoder / heads (encoder.py:33-58, decoder.py:271-331). */
+int suave_plan_create(const suave_model_t* model, const suave_col_t* cols, suave_plan** out);
+int suave_plan_destroy(suave_plan* plan);
+
+/* Bytes of scratch the step functions need for batches of up to max_rows rows
+ * (max_rows counts virtual rows B*K for the unsupervised branch). */
+int suave_workspace_bytes(const suave_plan* plan, int64_t max_rows, size_t* bytes);
+
+/* ELBO forward only (validation / eval mode): SUAVE._forward_elbo_batch under
+ * torch.no_grad() as driven by _compute_elbo_on_dataset (model.py:2497-2559).
+ * training != 0 applies dropout. */
+int suave_elbo_forward(const suave_plan* plan, const float* params, const suave_batch_t* batch,
+                       const suave_noise_t* noise, float beta_scale, float tau, int training,
+                       void* workspace, size_t workspace_bytes, void* stream,
+                       const suave_elbo_out_t* out);
+
+/* ELBO forward + backward: SUAVE._forward_elbo_batch followed by
+ * loss.backward() (model.py:1496-1505).  loss = -mean_b(recon - beta*(KLs)) over
+ * global_rows rows (== batch rows on one GPU; the global batch under data
+ * parallelism, so that summing rank gradients gives the single-batch gradient).
+ * grads [n_params] is overwritten with d loss / d params. */
+int suave_elbo_backward(const suave_plan* plan, const float* params, const suave_batch_t* batch,
+                        const suave_noise_t* noise, float beta_scale, float tau,
+                        int64_t global_rows, void* workspace, size_t workspace_bytes, void* stream,
+                        const suave_elbo_out_t* out, float* grads);
+
+/* torch.optim.Adam step (defaults betas=(0.9,0.999), eps=1e-8, no weight decay;
+ * model.py:1443) on the flat buffers.  group_begin[g]..group_begin[g+1] is the
+ * parameter range of learning-rate group g (model.py:1894-1909); lr_host has
+ * n_groups entries.  step_t is the 1-based step count. */
+int suave_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                    const int32_t* group_begin_host, const float* lr_host, int32_t n_groups,
+                    int64_t step_t, float beta1, float beta2, float eps, void* stream);
+
+/* Encoder pass + mixture moment matching: SUAVE.encode /
+ * _collect_posterior_statistics (encoder.py:60-72, model.py:2944-2964).
+ * enc_out [B, K+2KD] (logits | mu | clamped logvar); post_mean, post_logvar
+ * [B,D]; probs [B,K].  inv_temperature scales the logits (1 = none). */
+int suave_encode(const suave_plan* plan, const float* params, const suave_batch_t* batch,
+                 float inv_temperature, void* workspace, size_t workspace_bytes, void* stream,
+                 float* enc_out, float* post_mean, float* post_logvar, float* probs);
+
+/* Prior latent draw: sampling.sample_prepared_mixture_latents (sampling.py:38-56).
+ * cdf [K] cumulative softmax(prior_logits); u [n] uniform and eps [n,D] normal
+ * draws, or NULL to generate from (seed, row_offset + i). */
+int suave_prior_latents(const suave_plan* plan, const float* params, const float* cdf,
+                        const float* u, const float* eps, uint64_t seed, int64_t row_offset, int64_t n,
+                        void* stream, float* z, int32_t* component);
+
+/* Conditional latent draw: SUAVE._draw_conditional_latents (model.py:3042-3114)
+ * without the per-row Python loop.  class_offsets [n_classes+1] / class_rows
+ * index the cached training rows per class; labels [n]; train_probs [N,K],
+ * train_mu / train_logvar [N,K,D]. */
+int suave_conditional_latents(const suave_plan* plan, const int64_t* class_offsets,
+                              const int64_t* class_rows, const int32_t* labels, const float* train_probs,
+                              const float* train_mu, const float* train_logvar, const float* u_row,
+                              const float* e_comp, const float* eps, uint64_t seed, int64_t row_offset,
+                              int64_t n, void* stream, float* z, int32_t* component);
+
+/* Decoder pass + per-column sample draw: Decoder.forward as used by
+ * SUAVE.sample / SUAVE.impute (decoder.py:333-384, head samplers
+ * distributions.py:67-80,112-117,130-134,167-174) followed by the value
+ * conversion of sampling.decoder_outputs_to_frame (sampling.py:138-179).
+ * z [n,D]; s [n,K] dense assignments (may be soft, model.py:3635-3644) or NULL
+ * with component [n].  Output, columnar in the packed-table layout:
+ * out_num float32 [n, ld_num] (real, pos, count as float), out_codes int16
+ * [n, ld_disc].  noise_normal [n, n_cols], noise_uniform [n, n_cols],
+ * noise_exp [n, total classes] inject draws (any may be NULL). */
+int suave_decode_sample(const suave_plan* plan, const float* params, const float* z, const float* s,
+                        const int32_t* component, int64_t n, const float* noise_normal,
+                        const float* noise_uniform, const float* noise_exp, uint64_t seed,
+                        int64_t row_offset, void* workspace, size_t workspace_bytes, void* stream,
+                        float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUAVE_HIP_H */

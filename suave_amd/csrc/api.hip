@@ -1,0 +1,676 @@
+// C-ABI entry points: plan construction, workspace carving and the launch
+// sequences of the ELBO step / encode paths.  See include/suave_hip.h.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "kernels.h"
+
+namespace suave {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+__global__ void k_onehot(const int32_t* kidx, int n_rows, int K, int ld, float* out) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)n_rows * K; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / K), j = (int)(e % K);
+    out[(size_t)r * ld + j] = kidx[r] == j ? 1.f : 0.f;
+  }
+}
+
+int launch_onehot(const int32_t* kidx, int n_rows, int K, int ld, float* out, hipStream_t s) {
+  const int64_t n = (int64_t)n_rows * K;
+  hipLaunchKernelGGL(k_onehot, dim3((int)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, kidx, n_rows, K, ld, out);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// workspace carving: all scratch of one step, sized by the number of rows
+// ---------------------------------------------------------------------------
+struct Workspace {
+  float *x, *encout, *ysoft, *z, *eps, *y, *dz, *dencout;
+  float* he[SUAVE_MAX_HIDDEN];
+  float* hd[SUAVE_MAX_HIDDEN];
+  float* dhe[SUAVE_MAX_HIDDEN];
+  float* dhd[SUAVE_MAX_HIDDEN];
+  int32_t* kidx;
+  float *recon_part, *ds_part, *catkl, *gausskl, *gkl_logit, *gkl_mu, *gkl_lv, *prior_terms, *recon;
+  float* onehot;
+  float* slab;
+  double* sums_slab;
+  size_t slab_floats;
+  size_t total_bytes;
+};
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~size_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+// split count of a weight-gradient GEMM over `rows` batch rows
+int tn_splits(const suave_plan* p, int n_out, int n_in1, int64_t rows) {
+  const bool narrow = n_in1 <= 64;
+  const int tiles = narrow ? ((n_out + 255) / 256) * ((n_in1 + 63) / 64) : ((n_out + 127) / 128) * ((n_in1 + 127) / 128);
+  int64_t s = (2 * (int64_t)p->n_cu + tiles - 1) / tiles;
+  s = std::min<int64_t>(s, std::max<int64_t>(1, rows / 256));
+  return (int)std::max<int64_t>(1, std::min<int64_t>(s, 512));
+}
+
+int loss_grid(const suave_plan* p, int64_t rows) {
+  const int64_t tiles = (rows + 63) / 64;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(tiles, 2 * (int64_t)p->n_cu));
+}
+
+struct LayerRef {
+  const suave_layer_t* l;
+};
+
+std::vector<const suave_layer_t*> all_layers(const suave_plan* p) {
+  std::vector<const suave_layer_t*> v;
+  for (int i = 0; i < p->model.n_hidden; ++i) v.push_back(&p->model.enc[i]);
+  v.push_back(&p->model.enc_head);
+  for (int i = 0; i < p->model.n_hidden; ++i) v.push_back(&p->model.dec[i]);
+  v.push_back(&p->model.y_proj);
+  return v;
+}
+
+void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
+  const suave_model_t& m = p->model;
+  Carver c{static_cast<char*>(base)};
+  const size_t R = (size_t)std::max<int64_t>(rows, 1);
+  w->x = c.take<float>(R * p->ldI);
+  w->encout = c.take<float>(R * p->ldE);
+  w->ysoft = c.take<float>(R * p->ldK);
+  w->z = c.take<float>(R * p->ldD);
+  w->eps = c.take<float>(R * p->ldD * (m.behaviour == 1 ? 1 : 1));
+  w->y = c.take<float>(R * p->ldY);
+  w->dz = c.take<float>(R * p->ldD);
+  w->dencout = c.take<float>(R * p->ldE);
+  for (int i = 0; i < m.n_hidden; ++i) {
+    w->he[i] = c.take<float>(R * p->ldH[i]);
+    w->hd[i] = c.take<float>(R * p->ldH[i]);
+    w->dhe[i] = c.take<float>(R * p->ldH[i]);
+    w->dhd[i] = c.take<float>(R * p->ldH[i]);
+  }
+  w->kidx = c.take<int32_t>(R);
+  const size_t nch = p->chunks_host.size();
+  w->recon_part = c.take<float>(nch * R);
+  w->ds_part = c.take<float>(nch * R * p->ldK);
+  w->catkl = c.take<float>(R);
+  w->gausskl = c.take<float>(R);
+  w->recon = c.take<float>(R);
+  w->gkl_logit = c.take<float>(R * p->ldK);
+  w->gkl_mu = c.take<float>(R * p->ldD);
+  w->gkl_lv = c.take<float>(R * p->ldD);
+  const int ldT = round_up(2 * m.latent_dim + m.n_components, 4);
+  w->prior_terms = c.take<float>(R * ldT);
+  w->onehot = c.take<float>(R * p->ldK);
+  // slabs: every weight-gradient GEMM + the head slab + the prior slab
+  size_t slab = 0;
+  for (const suave_layer_t* l : all_layers(p)) {
+    const int ldc = round_up(l->n_in + 1, 4);
+    slab += (size_t)tn_splits(p, l->n_out, l->n_in + 1, rows) * l->n_out * ldc;
+  }
+  const int lg = loss_grid(p, rows);
+  slab += (size_t)lg * m.head_len;
+  {
+    const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components + 1;
+    slab += (size_t)tn_splits(p, Mt, Nt, rows) * Mt * round_up(Nt, 4);
+  }
+  w->slab_floats = slab;
+  w->slab = c.take<float>(slab);
+  w->sums_slab = c.take<double>((size_t)lg * nch * 4);
+  w->total_bytes = (c.off + 255) & ~size_t(255);
+}
+
+int check_batch(const suave_plan* p, const suave_batch_t* b) {
+  SUAVE_REQUIRE(b != nullptr, "batch is null");
+  SUAVE_REQUIRE(b->n_rows >= 0, "batch: negative row count");
+  SUAVE_REQUIRE(b->mask != nullptr, "batch: mask is null");
+  SUAVE_REQUIRE(p->model.n_num == 0 || b->xnum != nullptr, "batch: xnum is null");
+  SUAVE_REQUIRE(p->model.n_disc == 0 || b->codes != nullptr, "batch: codes is null");
+  SUAVE_REQUIRE(b->ld_num >= p->model.n_num && b->ld_disc >= p->model.n_disc && b->ld_mask >= p->model.n_cols,
+                "batch: leading dimensions smaller than the schema");
+  return 0;
+}
+
+GemmArgs gemm_base() {
+  GemmArgs g;
+  std::memset(&g, 0, sizeof(g));
+  g.ones_col = -1;
+  g.splits = 1;
+  return g;
+}
+
+// forward layer: C = epi(A * W^T + b)
+int fwd_layer(const suave_plan* p, const float* params, const suave_layer_t& l, const float* A, int lda, float* C,
+              int ldc, int rows, bool relu_drop, float drop_p, const uint8_t* keep, const suave_batch_t* b,
+              const suave_noise_t* nz, uint32_t stream_id, int vdiv, hipStream_t s) {
+  GemmArgs g = gemm_base();
+  g.A = A; g.B = params + l.w_off; g.C = C; g.bias = params + l.b_off;
+  g.M = rows; g.N = l.n_out; g.K = l.n_in;
+  g.lda = lda; g.ldb = l.ld; g.ldc = ldc;
+  g.epi = relu_drop ? kEpiReluDrop : kEpiBias;
+  g.drop_p = relu_drop ? drop_p : 0.f;
+  g.keep = keep;
+  g.row_ids = (vdiv == 1) ? b->row_index : nullptr;
+  g.row_begin = b->row_begin * vdiv;
+  g.seed = nz ? nz->seed : 0;
+  g.step = nz ? nz->step : 0;
+  g.stream_id = stream_id;
+  return launch_gemm(g, p->n_cu, s);
+}
+
+// data gradient: dA = (dC * W) [* relu/dropout mask of H]
+int bwd_data(const suave_plan* p, const float* params, const suave_layer_t& l, const float* dC, int lddc, float* dA,
+             int ldda, int rows, const float* H, float drop_p, hipStream_t s) {
+  GemmArgs g = gemm_base();
+  g.A = dC; g.B = params + l.w_off; g.C = dA;
+  g.M = rows; g.N = l.n_in; g.K = l.n_out;
+  g.lda = lddc; g.ldb = l.ld; g.ldc = ldda;
+  g.b_kmajor = 1;
+  g.epi = H ? kEpiMaskBwd : kEpiBias;
+  g.H = H;
+  g.drop_p = drop_p;
+  return launch_gemm(g, p->n_cu, s);
+}
+
+// weight gradient into a slab + its reduction segments (weight, bias)
+int bwd_weight(const suave_plan* p, const suave_layer_t& l, const float* dC, int lddc, const float* A, int lda,
+               int rows, float* slab_base, size_t* slab_off, ReduceArgs* red, int* max_elems, hipStream_t s) {
+  const int ldc = round_up(l.n_in + 1, 4);
+  const int splits = tn_splits(p, l.n_out, l.n_in + 1, rows);
+  GemmArgs g = gemm_base();
+  g.A = dC; g.B = A; g.C = slab_base + *slab_off;
+  g.M = l.n_out; g.N = l.n_in + 1; g.K = rows;
+  g.lda = lddc; g.ldb = lda; g.ldc = ldc;
+  g.a_kmajor = 1; g.b_kmajor = 1;
+  g.epi = kEpiSlab;
+  g.splits = splits;
+  g.slab_stride = (int64_t)l.n_out * ldc;
+  g.ones_col = l.n_in;
+  int rc = launch_gemm(g, p->n_cu, s);
+  if (rc) return rc;
+  SUAVE_REQUIRE(red->n_segs + 2 <= kMaxReduceSegs, "too many reduction segments");
+  ReduceSeg w{};
+  w.src_off = (int64_t)*slab_off; w.slab_stride = g.slab_stride; w.n_slabs = splits;
+  w.rows = l.n_out; w.cols = l.n_in; w.src_ld = ldc;
+  w.dst_off = l.w_off; w.dst_si = l.ld; w.dst_sj = 1;
+  red->segs[red->n_segs++] = w;
+  ReduceSeg bseg = w;
+  bseg.src_off += l.n_in; bseg.cols = 1; bseg.dst_off = l.b_off; bseg.dst_si = 1; bseg.dst_sj = 1;
+  red->segs[red->n_segs++] = bseg;
+  *max_elems = std::max(*max_elems, l.n_out * l.n_in);
+  *slab_off += (size_t)splits * l.n_out * ldc;
+  return 0;
+}
+
+__global__ void k_sum_chunks(const float* part, int n_chunks, int n_rows, float* out) {
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < n_rows; r += gridDim.x * 256) {
+    float t = 0.f;
+    for (int c = 0; c < n_chunks; ++c) t += part[(size_t)c * n_rows + r];
+    out[r] = t;
+  }
+}
+
+int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* batch, const suave_noise_t* noise,
+              float beta_scale, float tau, int training, int64_t global_rows, void* workspace,
+              size_t workspace_bytes, hipStream_t s, const suave_elbo_out_t* out, float* grads) {
+  SUAVE_REQUIRE(p != nullptr && params != nullptr, "plan/params is null");
+  if (int rc = check_batch(p, batch)) return rc;
+  const suave_model_t& m = p->model;
+  SUAVE_REQUIRE(m.behaviour == 0, "unsupervised ELBO branch goes through suave_elbo_*_unsup");
+  const bool grad = grads != nullptr;
+  const int B = batch->n_rows;
+  if (B == 0) return 0;
+  SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(params) & 15) == 0, "params must be 16-byte aligned");
+  SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
+  Workspace w;
+  carve(p, B, workspace, &w);
+  SUAVE_REQUIRE(workspace_bytes >= w.total_bytes, "workspace too small (see suave_workspace_bytes)");
+  SUAVE_REQUIRE(global_rows >= 1, "global_rows must be positive");
+  const float tau_c = std::max(tau, 1e-6f);  // model.py:1587
+  const float drop_p = training ? m.dropout : 0.f;
+  const int nh = m.n_hidden;
+  suave_noise_t nz_default;
+  std::memset(&nz_default, 0, sizeof(nz_default));
+  const suave_noise_t* nz = noise ? noise : &nz_default;
+
+  // ---- encoder ----
+  if (int rc = launch_expand(p, p->enc_src_dev, *batch, w.x, s)) return rc;
+  const float* act = w.x;
+  int ld_act = p->ldI;
+  for (int i = 0; i < nh; ++i) {
+    if (int rc = fwd_layer(p, params, m.enc[i], act, ld_act, w.he[i], p->ldH[i], B, true, drop_p, nz->enc_keep[i], batch,
+                           nz, kStreamEncDrop + i, 1, s))
+      return rc;
+    act = w.he[i];
+    ld_act = p->ldH[i];
+  }
+  if (int rc = fwd_layer(p, params, m.enc_head, act, ld_act, w.encout, p->ldE, B, false, 0.f, nullptr, batch, nz, 0, 1, s))
+    return rc;
+  // ---- assignment + reparameterisation ----
+  {
+    LatentFwdArgs a{};
+    a.encout = w.encout; a.ldE = p->ldE; a.K = m.n_components; a.D = m.latent_dim; a.ldK = p->ldK; a.ldD = p->ldD;
+    a.n_rows = B; a.row_index = batch->row_index; a.row_begin = batch->row_begin;
+    a.exp_noise = nz->exp_noise; a.eps_in = nz->eps; a.seed = nz->seed; a.step = nz->step; a.tau = tau_c;
+    a.ysoft = w.ysoft; a.kidx = w.kidx; a.z = w.z; a.eps_buf = w.eps;
+    a.latent_out = out ? out->latent : nullptr;
+    a.comp_out = out ? out->component : nullptr;
+    if (int rc = launch_latent_fwd(a, s)) return rc;
+  }
+  // ---- decoder trunk ----
+  act = w.z;
+  ld_act = p->ldD;
+  for (int i = 0; i < nh; ++i) {
+    if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], B, true, drop_p, nz->dec_keep[i], batch,
+                           nz, kStreamDecDrop + i, 1, s))
+      return rc;
+    act = w.hd[i];
+    ld_act = p->ldH[i];
+  }
+  if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, batch, nz, 0, 1, s))
+    return rc;
+  // ---- fused likelihood + KL (+ gradients) ----
+  const int n_chunks = (int)p->chunks_host.size();
+  const int lgrid = loss_grid(p, B);
+  const int ldT = round_up(2 * m.latent_dim + m.n_components, 4);
+  size_t slab_off = 0;
+  float* head_slab = w.slab;
+  slab_off += (size_t)lgrid * m.head_len;
+  {
+    LossArgs a{};
+    a.cols = p->cols_dev; a.chunks = p->chunks_dev; a.params = params; a.y = w.y; a.batch = *batch;
+    a.n_rows = B; a.vdiv = 1; a.kidx = w.kidx; a.row_weight = nullptr;
+    a.c_up = -1.0f / (float)global_rows;
+    a.bk = beta_scale / (float)global_rows;
+    a.K = m.n_components; a.D = m.latent_dim; a.ldY = p->ldY; a.ldy = p->max_chunk_y | 1; a.ldK = p->ldK;
+    a.ldD = p->ldD; a.ldE = p->ldE; a.ldT = ldT; a.max_classes = p->max_classes;
+    a.recon_part = w.recon_part; a.ds_part = w.ds_part; a.do_kl = 1; a.encout = w.encout;
+    a.prior_logits_off = m.prior_logits_off; a.prior_mu_off = m.prior_mu_off; a.prior_logvar_off = m.prior_logvar_off;
+    a.catkl = w.catkl; a.gausskl = w.gausskl; a.gkl_logit = w.gkl_logit; a.gkl_mu = w.gkl_mu; a.gkl_lv = w.gkl_lv;
+    a.prior_terms = w.prior_terms; a.head_slab = grad ? head_slab : nullptr; a.sums_slab = w.sums_slab;
+    a.head_off = m.head_off; a.head_len = m.head_len; a.hw_max = p->hw_max;
+    if (int rc = launch_loss(a, grad, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
+  }
+  const float* recon_final = w.recon_part;
+  if (n_chunks > 1) {
+    hipLaunchKernelGGL(k_sum_chunks, dim3(std::min((B + 255) / 256, 1024)), dim3(256), 0, s, w.recon_part, n_chunks, B,
+                       w.recon);
+    recon_final = w.recon;
+  }
+
+  ReduceArgs red{};
+  red.n_segs = 0;
+  red.slab = w.slab;
+  red.dst = grads;
+  red.sums_slab = w.sums_slab;
+  red.n_sum_slabs = lgrid * n_chunks;
+  red.sums_out = out ? out->sums : nullptr;
+  red.n_rows = (double)B;
+  int max_elems = 256;
+
+  if (grad) {
+    // ---- decoder backward ----
+    const float* hlast = nh ? w.hd[nh - 1] : w.z;
+    const int ldh = nh ? p->ldH[nh - 1] : p->ldD;
+    if (int rc = bwd_weight(p, m.y_proj, w.y, p->ldY, hlast, ldh, B, w.slab, &slab_off, &red, &max_elems, s)) return rc;
+    const float* dcur = w.y;
+    int lddcur = p->ldY;
+    const suave_layer_t* lcur = &m.y_proj;
+    for (int i = nh - 1; i >= 0; --i) {
+      if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dhd[i], p->ldH[i], B, w.hd[i], drop_p, s)) return rc;
+      const float* ain = i > 0 ? w.hd[i - 1] : w.z;
+      const int ldain = i > 0 ? p->ldH[i - 1] : p->ldD;
+      if (int rc = bwd_weight(p, m.dec[i], w.dhd[i], p->ldH[i], ain, ldain, B, w.slab, &slab_off, &red, &max_elems, s))
+        return rc;
+      dcur = w.dhd[i];
+      lddcur = p->ldH[i];
+      lcur = &m.dec[i];
+    }
+    if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dz, p->ldD, B, nullptr, 0.f, s)) return rc;
+    // ---- latent backward ----
+    {
+      LatentBwdArgs a{};
+      a.encout = w.encout; a.ldE = p->ldE; a.K = m.n_components; a.D = m.latent_dim; a.ldK = p->ldK; a.ldD = p->ldD;
+      a.n_rows = B; a.n_chunks = n_chunks; a.ysoft = w.ysoft; a.kidx = w.kidx; a.eps_buf = w.eps; a.dz = w.dz;
+      a.ds_part = w.ds_part; a.gkl_logit = w.gkl_logit; a.gkl_mu = w.gkl_mu; a.gkl_lv = w.gkl_lv; a.tau = tau_c;
+      a.dencout = w.dencout;
+      if (int rc = launch_latent_bwd(a, s)) return rc;
+    }
+    // ---- encoder backward ----
+    const float* helast = nh ? w.he[nh - 1] : w.x;
+    const int ldhe = nh ? p->ldH[nh - 1] : p->ldI;
+    if (int rc = bwd_weight(p, m.enc_head, w.dencout, p->ldE, helast, ldhe, B, w.slab, &slab_off, &red, &max_elems, s))
+      return rc;
+    dcur = w.dencout;
+    lddcur = p->ldE;
+    lcur = &m.enc_head;
+    for (int i = nh - 1; i >= 0; --i) {
+      if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dhe[i], p->ldH[i], B, w.he[i], drop_p, s)) return rc;
+      const float* ain = i > 0 ? w.he[i - 1] : w.x;
+      const int ldain = i > 0 ? p->ldH[i - 1] : p->ldI;
+      if (int rc = bwd_weight(p, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, B, w.slab, &slab_off, &red, &max_elems, s))
+        return rc;
+      dcur = w.dhe[i];
+      lddcur = p->ldH[i];
+      lcur = &m.enc[i];
+    }
+    // ---- prior gradients: (prior_terms^T * [onehot(k) | 1]) via the split GEMM ----
+    {
+      const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components + 1;
+      const int ldc = round_up(Nt, 4);
+      const int splits = tn_splits(p, Mt, Nt, B);
+      float* onehot = w.onehot;  // [B, ldK] one-hot of the selected component
+      const int ld1 = p->ldK;
+      if (int rc = launch_onehot(w.kidx, B, m.n_components, ld1, onehot, s)) return rc;
+      GemmArgs g = gemm_base();
+      g.A = w.prior_terms; g.B = onehot; g.C = w.slab + slab_off;
+      g.M = Mt; g.N = Nt; g.K = B;
+      g.lda = ldT; g.ldb = ld1; g.ldc = ldc;
+      g.a_kmajor = 1; g.b_kmajor = 1; g.epi = kEpiSlab; g.splits = splits;
+      g.slab_stride = (int64_t)Mt * ldc; g.ones_col = m.n_components;
+      if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
+      SUAVE_REQUIRE(red.n_segs + 4 <= kMaxReduceSegs, "too many reduction segments");
+      const int D = m.latent_dim, K = m.n_components;
+      ReduceSeg sm{};  // prior.mu[k][d] = out[d][k]
+      sm.src_off = (int64_t)slab_off; sm.slab_stride = g.slab_stride; sm.n_slabs = splits;
+      sm.rows = D; sm.cols = K; sm.src_ld = ldc; sm.dst_off = m.prior_mu_off; sm.dst_si = 1; sm.dst_sj = D;
+      red.segs[red.n_segs++] = sm;
+      ReduceSeg sv = sm;  // prior.logvar[k][d] = out[D + d][k]
+      sv.src_off += (int64_t)D * ldc; sv.dst_off = m.prior_logvar_off;
+      red.segs[red.n_segs++] = sv;
+      ReduceSeg sl = sm;  // prior.logits[j] = out[2D + j][K]  (ones column)
+      sl.src_off += (int64_t)2 * D * ldc + K; sl.rows = K; sl.cols = 1; sl.dst_off = m.prior_logits_off;
+      sl.dst_si = 1; sl.dst_sj = 1;
+      red.segs[red.n_segs++] = sl;
+      slab_off += (size_t)splits * Mt * ldc;
+    }
+    // ---- likelihood-head weights ----
+    {
+      ReduceSeg sh{};
+      sh.src_off = 0; sh.slab_stride = m.head_len; sh.n_slabs = lgrid; sh.rows = 1; sh.cols = m.head_len;
+      sh.src_ld = m.head_len; sh.dst_off = m.head_off; sh.dst_si = 0; sh.dst_sj = 1;
+      red.segs[red.n_segs++] = sh;
+      max_elems = std::max(max_elems, m.head_len);
+    }
+    SUAVE_REQUIRE(slab_off <= w.slab_floats, "internal: slab overflow");
+  }
+  if (grad || red.sums_out) {
+    if (int rc = launch_reduce(red, max_elems, s)) return rc;
+  }
+  // ---- per-row outputs ----
+  if (out) {
+    if (out->reconstruction)
+      SUAVE_CHECK_HIP(hipMemcpyAsync(out->reconstruction, recon_final, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+    if (out->categorical_kl)
+      SUAVE_CHECK_HIP(hipMemcpyAsync(out->categorical_kl, w.catkl, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+    if (out->gaussian_kl)
+      SUAVE_CHECK_HIP(hipMemcpyAsync(out->gaussian_kl, w.gausskl, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+    if (out->enc_out)
+      if (int rc = launch_posterior_stats(w.encout, p->ldE, m.n_components, m.latent_dim, B, 1.0f, out->enc_out, nullptr,
+                                          nullptr, nullptr, s))
+        return rc;
+  }
+  return 0;
+}
+
+}  // namespace
+
+}  // namespace suave
+
+using namespace suave;
+
+extern "C" const char* suave_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* cols, suave_plan** out) {
+  SUAVE_REQUIRE(model && cols && out, "plan_create: null argument");
+  const suave_model_t& m = *model;
+  SUAVE_REQUIRE(m.n_cols > 0 && m.n_cols < 16384, "plan_create: 1..16383 columns");
+  SUAVE_REQUIRE(m.n_components >= 1 && m.n_components <= SUAVE_MAX_COMPONENTS, "plan_create: 1..32 mixture components");
+  SUAVE_REQUIRE(m.latent_dim >= 1, "plan_create: latent_dim must be positive");
+  SUAVE_REQUIRE(m.n_hidden >= 0 && m.n_hidden <= SUAVE_MAX_HIDDEN, "plan_create: at most 8 hidden layers");
+  SUAVE_REQUIRE(m.dropout >= 0.f && m.dropout < 1.f, "plan_create: dropout must lie in [0,1)");
+  suave_plan* p = new suave_plan();
+  p->model = m;
+  p->cols_host.assign(cols, cols + m.n_cols);
+  const int K = m.n_components, D = m.latent_dim;
+  p->ldI = round_up(m.enc_in, 4);
+  p->enc_out_width = K + 2 * K * D;
+  p->ldE = round_up(p->enc_out_width, 4);
+  p->ldK = round_up(K, 4);
+  p->ldD = round_up(D, 4);
+  p->ldY = round_up(m.total_y, 4);
+  for (int i = 0; i < m.n_hidden; ++i) p->ldH[i] = round_up(m.enc[i].n_out, 4);
+  p->kmax = K <= 8 ? 8 : (K <= 16 ? 16 : 32);
+  auto fail = [&](const char* msg) {
+    set_error(msg);
+    delete p;
+    return 1;
+  };
+  // layer table consistency: every ld is the padded input width, offsets 16-byte aligned
+  {
+    int prev = p->ldI, prev_n = m.enc_in;
+    for (int i = 0; i < m.n_hidden; ++i) {
+      if (m.enc[i].ld != prev || m.enc[i].n_in != prev_n || m.enc[i].w_off % 4) return fail("plan_create: encoder layer table inconsistent");
+      if (m.dec[i].n_out != m.enc[i].n_out) return fail("plan_create: encoder/decoder hidden sizes differ");
+      prev = p->ldH[i];
+      prev_n = m.enc[i].n_out;
+    }
+    if (m.enc_head.ld != prev || m.enc_head.n_in != prev_n || m.enc_head.n_out != p->enc_out_width || m.enc_head.w_off % 4)
+      return fail("plan_create: encoder head table inconsistent");
+    prev = p->ldD;
+    prev_n = D;
+    for (int i = 0; i < m.n_hidden; ++i) {
+      if (m.dec[i].ld != prev || m.dec[i].n_in != prev_n || m.dec[i].w_off % 4) return fail("plan_create: decoder layer table inconsistent");
+      prev = p->ldH[i];
+      prev_n = m.dec[i].n_out;
+    }
+    if (m.y_proj.ld != prev || m.y_proj.n_in != prev_n || m.y_proj.n_out != m.total_y || m.y_proj.w_off % 4)
+      return fail("plan_create: y_projection table inconsistent");
+  }
+  // column table: y slices contiguous in schema order, head weights contiguous in schema order
+  int y = 0, hw = m.head_off, total_classes = 0, max_classes = 1;
+  for (int c = 0; c < m.n_cols; ++c) {
+    const suave_col_t& col = cols[c];
+    if (col.type < 0 || col.type > SUAVE_TYPE_ORDINAL) return fail("plan_create: bad column type");
+    if (col.y_off != y || col.y_dim < 1) return fail("plan_create: y slices must be contiguous in schema order");
+    y += col.y_dim;
+    if (col.w_off != hw) return fail("plan_create: head weights must be contiguous in schema order");
+    const bool disc = col.type >= SUAVE_TYPE_CAT;
+    if (disc && (col.n_classes < 2 || col.n_classes > 32767)) return fail("plan_create: cat/ordinal need 2..32767 classes");
+    if (col.x_index < 0 || col.x_index >= (disc ? m.n_disc : m.n_num)) return fail("plan_create: x_index out of range");
+    int len1 = 0, len2 = 0;
+    switch (col.type) {
+      case SUAVE_TYPE_REAL: case SUAVE_TYPE_POS: len1 = col.y_dim + K; len2 = K; break;
+      case SUAVE_TYPE_COUNT: len1 = col.y_dim + K; break;
+      case SUAVE_TYPE_CAT: len1 = (col.n_classes - 1) * (col.y_dim + K); break;
+      case SUAVE_TYPE_ORDINAL: len1 = (col.n_classes - 1) * K; len2 = col.y_dim + K; break;
+    }
+    if (len2 ? col.w2_off != hw + len1 : col.w2_off != -1) return fail("plan_create: second head tensor misplaced");
+    hw += len1 + len2;
+    if (disc) { total_classes += col.n_classes; if (col.type == SUAVE_TYPE_CAT) max_classes = std::max(max_classes, col.n_classes); }
+  }
+  if (y != m.total_y) return fail("plan_create: total_y mismatch");
+  if (hw != m.head_off + m.head_len) return fail("plan_create: head_len mismatch");
+  p->total_classes = total_classes;
+  p->max_classes = max_classes;
+  // chunking of the schema for the loss kernel (LDS budget)
+  {
+    const int kChunkY = 384;
+    ColChunk cur{0, 0, 0, 0};
+    int hw_max = 0, hw_start = m.head_off, max_y = 0;
+    for (int c = 0; c < m.n_cols; ++c) {
+      if (cur.col_end > cur.col_begin && cur.y_len + cols[c].y_dim > kChunkY) {
+        p->chunks_host.push_back(cur);
+        hw_max = std::max(hw_max, cols[c].w_off - hw_start);
+        hw_start = cols[c].w_off;
+        max_y = std::max(max_y, cur.y_len);
+        cur = ColChunk{c, c, cols[c].y_off, 0};
+      }
+      cur.col_end = c + 1;
+      cur.y_len += cols[c].y_dim;
+    }
+    p->chunks_host.push_back(cur);
+    hw_max = std::max(hw_max, m.head_off + m.head_len - hw_start);
+    max_y = std::max(max_y, cur.y_len);
+    p->max_chunk_y = max_y;
+    p->hw_max = hw_max;
+    p->loss_lds_bytes = loss_lds_bytes(max_y | 1, K, hw_max, max_classes);
+    if (p->loss_lds_bytes > 150 * 1024)
+      return fail("plan_create: schema needs more than 150 KB of LDS in the likelihood kernel (very wide categorical "
+                  "columns need the GEMM head path, which this build does not have yet)");
+  }
+  // device tables
+  hipDeviceProp_t prop;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("plan_create: no HIP device");
+  p->device = dev;
+  p->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  std::vector<int32_t> enc_src(p->ldI, -1);
+  for (int c = 0; c < m.n_cols; ++c) {
+    const suave_col_t& col = cols[c];
+    const int width = col.type >= SUAVE_TYPE_CAT ? col.n_classes : 1;
+    if (col.enc_off < 0 || col.enc_off + width > m.enc_in || col.enc_mask < 0 || col.enc_mask >= m.enc_in)
+      return fail("plan_create: encoder input offsets out of range");
+    for (int k = 0; k < width; ++k) enc_src[col.enc_off + k] = (c << 16) | k;
+    enc_src[col.enc_mask] = (1 << 30) | (c << 16);
+  }
+  auto dfail = [&](const char* msg) {
+    set_error(msg);
+    suave_plan_destroy(p);
+    return 2;
+  };
+  if (hipMalloc(&p->cols_dev, sizeof(suave_col_t) * m.n_cols) != hipSuccess) return dfail("plan_create: hipMalloc failed");
+  if (hipMalloc(&p->chunks_dev, sizeof(ColChunk) * p->chunks_host.size()) != hipSuccess) return dfail("plan_create: hipMalloc failed");
+  if (hipMalloc(&p->enc_src_dev, sizeof(int32_t) * p->ldI) != hipSuccess) return dfail("plan_create: hipMalloc failed");
+  if (hipMalloc(&p->cls_off_dev, sizeof(int32_t) * m.n_cols) != hipSuccess) return dfail("plan_create: hipMalloc failed");
+  {
+    std::vector<int32_t> cls_off(m.n_cols, 0);
+    int acc = 0;
+    for (int c = 0; c < m.n_cols; ++c) {
+      cls_off[c] = acc;
+      if (cols[c].type >= SUAVE_TYPE_CAT) acc += cols[c].n_classes;
+    }
+    if (hipMemcpy(p->cls_off_dev, cls_off.data(), sizeof(int32_t) * m.n_cols, hipMemcpyHostToDevice) != hipSuccess)
+      return dfail("plan_create: hipMemcpy failed");
+  }
+  if (hipMemcpy(p->cols_dev, cols, sizeof(suave_col_t) * m.n_cols, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->chunks_dev, p->chunks_host.data(), sizeof(ColChunk) * p->chunks_host.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->enc_src_dev, enc_src.data(), sizeof(int32_t) * p->ldI, hipMemcpyHostToDevice) != hipSuccess)
+    return dfail("plan_create: hipMemcpy failed");
+  if (p->loss_lds_bytes > 48 * 1024)
+    if (loss_set_lds_limit(p->loss_lds_bytes)) { suave_plan_destroy(p); return 2; }
+  *out = p;
+  return 0;
+}
+
+extern "C" int suave_plan_destroy(suave_plan* p) {
+  if (!p) return 0;
+  if (p->cols_dev) (void)hipFree(p->cols_dev);
+  if (p->chunks_dev) (void)hipFree(p->chunks_dev);
+  if (p->enc_src_dev) (void)hipFree(p->enc_src_dev);
+  if (p->cls_off_dev) (void)hipFree(p->cls_off_dev);
+  delete p;
+  return 0;
+}
+
+extern "C" int suave_workspace_bytes(const suave_plan* plan, int64_t max_rows, size_t* bytes) {
+  SUAVE_REQUIRE(plan && bytes, "workspace_bytes: null argument");
+  SUAVE_REQUIRE(max_rows >= 0 && max_rows < (int64_t(1) << 31), "workspace_bytes: row count out of range");
+  Workspace w;
+  carve(plan, max_rows, nullptr, &w);
+  *bytes = w.total_bytes;
+  return 0;
+}
+
+extern "C" int suave_elbo_forward(const suave_plan* plan, const float* params, const suave_batch_t* batch,
+                                  const suave_noise_t* noise, float beta_scale, float tau, int training,
+                                  void* workspace, size_t workspace_bytes, void* stream,
+                                  const suave_elbo_out_t* out) {
+  return elbo_impl(plan, params, batch, noise, beta_scale, tau, training, batch ? std::max(batch->n_rows, 1) : 1,
+                   workspace, workspace_bytes, static_cast<hipStream_t>(stream), out, nullptr);
+}
+
+extern "C" int suave_elbo_backward(const suave_plan* plan, const float* params, const suave_batch_t* batch,
+                                   const suave_noise_t* noise, float beta_scale, float tau, int64_t global_rows,
+                                   void* workspace, size_t workspace_bytes, void* stream,
+                                   const suave_elbo_out_t* out, float* grads) {
+  SUAVE_REQUIRE(grads != nullptr, "elbo_backward: grads is null");
+  return elbo_impl(plan, params, batch, noise, beta_scale, tau, 1, global_rows, workspace, workspace_bytes,
+                   static_cast<hipStream_t>(stream), out, grads);
+}
+
+extern "C" int suave_encode(const suave_plan* p, const float* params, const suave_batch_t* batch,
+                            float inv_temperature, void* workspace, size_t workspace_bytes, void* stream,
+                            float* enc_out, float* post_mean, float* post_logvar, float* probs) {
+  SUAVE_REQUIRE(p != nullptr && params != nullptr, "plan/params is null");
+  if (int rc = check_batch(p, batch)) return rc;
+  const suave_model_t& m = p->model;
+  const int B = batch->n_rows;
+  if (B == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Workspace w;
+  carve(p, B, workspace, &w);
+  SUAVE_REQUIRE(workspace_bytes >= w.total_bytes, "workspace too small (see suave_workspace_bytes)");
+  if (int rc = launch_expand(p, p->enc_src_dev, *batch, w.x, s)) return rc;
+  const float* act = w.x;
+  int ld_act = p->ldI;
+  for (int i = 0; i < m.n_hidden; ++i) {
+    if (int rc = fwd_layer(p, params, m.enc[i], act, ld_act, w.he[i], p->ldH[i], B, true, 0.f, nullptr, batch, nullptr, 0, 1, s))
+      return rc;
+    act = w.he[i];
+    ld_act = p->ldH[i];
+  }
+  if (int rc = fwd_layer(p, params, m.enc_head, act, ld_act, w.encout, p->ldE, B, false, 0.f, nullptr, batch, nullptr, 0, 1, s))
+    return rc;
+  return launch_posterior_stats(w.encout, p->ldE, m.n_components, m.latent_dim, B, inv_temperature, enc_out, post_mean,
+                                post_logvar, probs, s);
+}
+
+extern "C" int suave_decode_sample(const suave_plan* p, const float* params, const float* z, const float* s_dense,
+                                   const int32_t* component, int64_t n, const float* noise_normal,
+                                   const float* noise_uniform, const float* noise_exp, uint64_t seed,
+                                   int64_t row_offset, void* workspace, size_t workspace_bytes, void* stream,
+                                   float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc) {
+  SUAVE_REQUIRE(p && params && z, "decode_sample: null argument");
+  SUAVE_REQUIRE(s_dense != nullptr || component != nullptr, "decode_sample: need dense assignments or component indices");
+  const suave_model_t& m = p->model;
+  SUAVE_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "decode_sample: row count out of range");
+  SUAVE_REQUIRE((m.n_num == 0 || (out_num && ld_num >= m.n_num)) && (m.n_disc == 0 || (out_codes && ld_disc >= m.n_disc)),
+                "decode_sample: output buffers missing or too narrow");
+  if (n == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace w;
+  carve(p, n, workspace, &w);
+  SUAVE_REQUIRE(workspace_bytes >= w.total_bytes, "workspace too small (see suave_workspace_bytes)");
+  const int B = (int)n;
+  SUAVE_CHECK_HIP(hipMemcpy2DAsync(w.z, sizeof(float) * p->ldD, z, sizeof(float) * m.latent_dim,
+                                   sizeof(float) * m.latent_dim, B, hipMemcpyDeviceToDevice, st));
+  suave_batch_t dummy;
+  std::memset(&dummy, 0, sizeof(dummy));
+  const float* act = w.z;
+  int ld_act = p->ldD;
+  for (int i = 0; i < m.n_hidden; ++i) {  // eval mode: no dropout (model.py:3613-3617, 4397-4419)
+    if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], B, true, 0.f, nullptr, &dummy, nullptr, 0, 1, st))
+      return rc;
+    act = w.hd[i];
+    ld_act = p->ldH[i];
+  }
+  if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, &dummy, nullptr, 0, 1, st))
+    return rc;
+  return launch_sample_heads(p, p->cls_off_dev, params, w.y, s_dense, component, n, noise_normal, noise_uniform,
+                             noise_exp, seed, row_offset, out_num, ld_num, out_codes, ld_disc, st);
+}

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Build libsuave_hip.so for gfx950 in-tree (the .so travels to the GPU box; it is git-ignored).
+set -e
+cd "$(dirname "$0")"
+OUT=../libsuave_hip.so
+OBJ=../../build/obj
+mkdir -p "$OBJ"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+pids=()
+for f in gemm loss latent optim sample api; do
+  [ -f $f.hip ] || continue
+  if [ ! -f $OBJ/$f.o ] || [ $f.hip -nt $OBJ/$f.o ] || [ common.h -nt $OBJ/$f.o ] || [ kernels.h -nt $OBJ/$f.o ] || [ detmath.h -nt $OBJ/$f.o ] || [ ../../include/suave_hip.h -nt $OBJ/$f.o ]; then
+    hipcc $FLAGS -c $f.hip -o $OBJ/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+objs=""
+for f in gemm loss latent optim sample api; do [ -f $OBJ/$f.o ] && objs="$objs $OBJ/$f.o"; done
+hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $OUT
+echo "built $(realpath $OUT)"

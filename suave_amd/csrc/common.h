@@ -1,0 +1,161 @@
+// Internal declarations shared by the translation units of libsuave_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/suave_hip.h"
+
+namespace suave {
+
+void set_error(const std::string& msg);
+
+#define SUAVE_CHECK_HIP(expr)                                                              \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      ::suave::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));               \
+      return 2;                                                                            \
+    }                                                                                      \
+  } while (0)
+
+#define SUAVE_REQUIRE(cond, msg)                                                           \
+  do {                                                                                     \
+    if (!(cond)) {                                                                         \
+      ::suave::set_error(std::string(msg) + " [" #cond "]");                               \
+      return 1;                                                                            \
+    }                                                                                      \
+  } while (0)
+
+constexpr float kEps = 1e-6f;            // suave/modules/distributions.py:18
+constexpr float kLog2Pi = 1.8378770664f; // distributions.py:19
+constexpr float kLogvarMin = -15.0f;     // suave/modules/encoder.py:31
+constexpr float kLogvarMax = 15.0f;
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// A chunk of consecutive schema columns handled by one loss-kernel block column.
+struct ColChunk {
+  int32_t col_begin, col_end;
+  int32_t y_begin, y_len;
+};
+
+}  // namespace suave
+
+// Opaque plan (C-ABI name).
+struct suave_plan {
+  suave_model_t model;
+  std::vector<suave_col_t> cols_host;
+  std::vector<suave::ColChunk> chunks_host;
+  suave_col_t* cols_dev = nullptr;
+  suave::ColChunk* chunks_dev = nullptr;
+  int device = 0;
+  int n_cu = 256;
+  int32_t* enc_src_dev = nullptr;
+  int32_t* cls_off_dev = nullptr;
+  // padded leading dimensions (floats)
+  int ldI, ldE, ldK, ldD, ldY;
+  int ldH[SUAVE_MAX_HIDDEN];
+  int enc_out_width;  // K + 2*K*D
+  int total_classes;  // sum of n_classes over cat/ordinal columns
+  int max_chunk_y;    // widest y chunk
+  int max_classes;
+  int kmax;           // template bucket for K (8, 16 or 32)
+  int hw_max;         // widest per-chunk range of likelihood-head weights
+  int loss_blocks;    // grid.x of the loss kernel
+  size_t loss_lds_bytes;
+};
+
+namespace suave {
+
+// ----- counter-based RNG (Philox-4x32-10) -----------------------------------
+struct Philox {
+  uint32_t key0, key1;
+  __device__ __forceinline__ Philox(uint64_t seed)
+      : key0(static_cast<uint32_t>(seed)), key1(static_cast<uint32_t>(seed >> 32)) {}
+  __device__ __forceinline__ uint4 operator()(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) const {
+    uint32_t k0 = key0, k1 = key1;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+      uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+      uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+      c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+  }
+};
+
+// uniform in (0,1): 24 random bits, never 0 or 1
+__device__ __forceinline__ float u01(uint32_t r) { return (static_cast<float>(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// two N(0,1) from two 32-bit words (Box-Muller)
+__device__ __forceinline__ float2 normal2(uint32_t r0, uint32_t r1) {
+  float u = u01(r0), v = u01(r1);
+  float rad = sqrtf(-2.0f * __logf(u));
+  float s, c;
+  __sincosf(6.28318530718f * v, &s, &c);
+  return make_float2(rad * c, rad * s);
+}
+
+// RNG stream ids (counter word c2)
+enum : uint32_t {
+  kStreamGumbel = 1,
+  kStreamEps = 2,
+  kStreamEncDrop = 16,  // + layer
+  kStreamDecDrop = 32,  // + layer
+  kStreamSampleNormal = 64,
+  kStreamSampleUniform = 65,
+  kStreamSampleExp = 66,
+  kStreamPriorU = 67,
+  kStreamPriorEps = 68,
+  kStreamCondU = 69,
+  kStreamCondExp = 70,
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float softplus_grad_f(float x) { return x > 20.0f ? 1.0f : sigmoid_f(x); }
+
+// ----- GEMM launcher (gemm.hip) ----------------------------------------------
+enum GemmEpi : int {
+  kEpiBias = 0,       // C = acc + bias
+  kEpiReluDrop = 1,   // C = dropout(relu(acc + bias))
+  kEpiMaskBwd = 2,    // C = acc * (H > 0 ? inv_keep : 0)     (dropout+relu backward)
+  kEpiSlab = 3,       // split-K partial slab, no bias
+};
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;      // kEpiBias / kEpiReluDrop (may be null)
+  const float* H;         // kEpiMaskBwd: forward activation, same shape/ld as C
+  const uint8_t* keep;    // kEpiReluDrop: injected keep mask [M, N] (ld = N) or null
+  const int32_t* row_ids; // table row id per output row (RNG key) or null -> row_begin + i
+  int64_t row_begin;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int a_kmajor, b_kmajor; // element (i,k) at A[k*lda+i] if a_kmajor else A[i*lda+k]; same for B(k,j)
+  int epi;
+  int splits;             // kEpiSlab: K is split into `splits` ranges, slab s at C + s*slab_stride
+  int64_t slab_stride;
+  int ones_col;           // kEpiSlab: virtual B column index holding 1.0 (bias gradient) or -1
+  float drop_p;
+  uint64_t seed, step;
+  uint32_t stream_id;
+};
+
+int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream);
+
+}  // namespace suave

@@ -1,0 +1,104 @@
+// Kernel argument structs and host launchers shared between translation units.
+#pragma once
+#include "common.h"
+
+namespace suave {
+
+struct LossArgs {
+  const suave_col_t* cols;
+  const ColChunk* chunks;
+  const float* params;
+  float* y;            // [n_rows, ldY]; overwritten with dY when GRAD
+  suave_batch_t batch; // packed table (data rows)
+  int n_rows;          // rows of y (virtual rows when vdiv > 1)
+  int vdiv;            // virtual rows per data row (K in the unsupervised branch, else 1)
+  const int32_t* kidx; // [n_rows] component of each row, or null -> row % vdiv
+  const float* row_weight;  // [n_rows] multiplies the upstream gradient, or null
+  float c_up;          // d loss / d recon_row
+  float bk;            // d loss / d KL_row
+  int K, D, ldY, ldy, ldK, ldD, ldE, ldT;
+  int max_classes;
+  float* recon_part;   // [n_chunks, n_rows]
+  float* ds_part;      // [n_chunks, n_rows, ldK]
+  int do_kl;
+  const float* encout;
+  int prior_logits_off, prior_mu_off, prior_logvar_off;
+  float* catkl;
+  float* gausskl;
+  float* gkl_logit;    // [n_rows, ldK]
+  float* gkl_mu;       // [n_rows, ldD]
+  float* gkl_lv;       // [n_rows, ldD]
+  float* prior_terms;  // [n_rows, ldT]: d/d prior_mu_k | d/d prior_logvar_k | d/d prior_logits
+  float* head_slab;    // [gridDim.x, head_len]
+  double* sums_slab;   // [gridDim.x * gridDim.y, 4]
+  int head_off, head_len, hw_max;
+};
+
+struct LatentFwdArgs {
+  const float* encout;  // [B, ldE] logits | mu | raw logvar
+  int ldE, K, D, ldK, ldD;
+  int n_rows;
+  const int32_t* row_index;
+  int64_t row_begin;
+  const float* exp_noise;  // [B,K] or null
+  const float* eps_in;     // [B,D] or null
+  uint64_t seed, step;
+  float tau;
+  float* ysoft;   // [B, ldK]
+  int32_t* kidx;  // [B]
+  float* z;       // [B, ldD]
+  float* eps_buf; // [B, ldD] (eps actually used; read back by the backward)
+  float* latent_out;    // [B, D] or null
+  int32_t* comp_out;    // [B] or null
+};
+
+struct LatentBwdArgs {
+  const float* encout;
+  int ldE, K, D, ldK, ldD, n_rows, n_chunks;
+  const float* ysoft;
+  const int32_t* kidx;
+  const float* eps_buf;
+  const float* dz;         // [B, ldD]
+  const float* ds_part;    // [n_chunks, B, ldK]
+  const float* gkl_logit;  // [B, ldK]  d loss/d logits from the categorical KL
+  const float* gkl_mu;     // [B, ldD]
+  const float* gkl_lv;     // [B, ldD]
+  float tau;
+  float* dencout;          // [B, ldE]
+};
+
+// dst[dst_off + i*dst_si + j*dst_sj] = sum_s src[src_off + s*slab_stride + i*src_ld + j]
+struct ReduceSeg {
+  int64_t src_off, slab_stride;
+  int32_t n_slabs, rows, cols, src_ld;
+  int32_t dst_off, dst_si, dst_sj;
+  int32_t pad;
+};
+
+constexpr int kMaxReduceSegs = 48;
+struct ReduceArgs {
+  ReduceSeg segs[kMaxReduceSegs];
+  int n_segs;
+  const float* slab;
+  float* dst;
+  const double* sums_slab;  // [n_sum_slabs, 4] or null
+  int n_sum_slabs;
+  double* sums_out;         // [4], accumulated (+=); entry 3 += n_rows
+  double n_rows;
+};
+
+size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes);
+int loss_set_lds_limit(size_t lds_bytes);
+int launch_loss(const LossArgs& a, bool grad, int kmax, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s);
+int launch_expand(const suave_plan* p, const int32_t* enc_src_dev, const suave_batch_t& b, float* x, hipStream_t s);
+int launch_latent_fwd(const LatentFwdArgs& a, hipStream_t s);
+int launch_latent_bwd(const LatentBwdArgs& a, hipStream_t s);
+int launch_posterior_stats(const float* encout, int ldE, int K, int D, int n_rows, float inv_temp, float* enc_out_user,
+                           float* post_mean, float* post_logvar, float* probs, hipStream_t s);
+int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const float* params, const float* y,
+                        const float* s, const int32_t* comp, int64_t n, const float* nn, const float* nu,
+                        const float* ne, uint64_t seed, int64_t row_offset, float* out_num, int ld_num,
+                        int16_t* out_codes, int ld_disc, hipStream_t st);
+int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s);
+
+}  // namespace suave

@@ -1,0 +1,407 @@
+// Generative decode: latent draws (prior / conditional) and the fused per-column
+// sample kernel.
+//
+// Replaces sampling.sample_prepared_mixture_latents (suave/sampling.py:38-56),
+// SUAVE._draw_conditional_latents (suave/model.py:3042-3114, a Python per-row
+// loop with two host syncs per row), the head samplers
+// (suave/modules/distributions.py:67-80,112-117,130-134,167-174 as called from
+// suave/modules/decoder.py:90-91,139,172,214-216,258) and the value conversion of
+// sampling.decoder_outputs_to_frame (sampling.py:138-179).  The log-likelihood
+// the reference computes on placeholder batches and throws away
+// (sampling.py:79-100) is not computed at all.
+//
+// Every value that feeds a discrete decision (argmax / threshold) is computed
+// with the individually rounded binary32 operations of detmath.h, in the same
+// order as oracle/sampling_oracle.py, so sampled categories / levels / counts /
+// components are bit-identical to the oracle for identical inputs and noise.
+#include "kernels.h"
+#include "detmath.h"
+
+namespace suave {
+
+namespace {
+
+__device__ __forceinline__ float philox_u(const Philox& rng, uint32_t a, uint32_t b, uint32_t stream, uint32_t d) {
+  return u01(rng(a, b, stream, d).x);
+}
+
+// (rate, uniform, normal) -> Poisson count; mirrors sampling_oracle.poisson_from_noise
+__device__ float poisson_from_noise(float rate, float u, float n) {
+  const bool small = rate < 64.0f;
+  const float r = small ? rate : 1.0f;
+  float p = detm::exp(-r);
+  float cdf = p;
+  float k = 0.f;
+  bool go = small && (u > cdf);
+  for (int i = 1; i <= 512 && go; ++i) {
+    const float fi = (float)i;
+    p = detm::dvd(detm::mul(p, r), fi);
+    cdf = detm::add(cdf, p);
+    k = fi;
+    go = (u > cdf) && ((p > 1e-30f) || (fi <= r));
+  }
+  float big = floorf(detm::add(detm::add(rate, detm::mul(__fsqrt_rn(rate), n)), 0.5f));
+  big = fmaxf(big, 0.f);
+  return small ? k : big;
+}
+
+struct SampleArgs {
+  const suave_col_t* cols;
+  const int32_t* cls_off;  // [n_cols] offset of the column's classes in noise_exp
+  const float* params;
+  const float* y;          // [n, ldY]
+  const float* s;          // [n, K] dense assignments or null
+  const int32_t* comp;     // [n] component index (used when s == null)
+  int64_t n;
+  int n_cols, n_num, n_disc, K, ldY, Y, total_classes;
+  const float* noise_normal;   // [n, n_cols] or null
+  const float* noise_uniform;  // [n, n_cols] or null
+  const float* noise_exp;      // [n, total_classes] or null
+  uint64_t seed;
+  int64_t row_offset;
+  float* out_num;
+  int ld_num;
+  int16_t* out_codes;
+  int ld_disc;
+  int ldy, ldon, ldoc;  // LDS row strides
+};
+
+__global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ytile = lds;                                      // [64][ldy]
+  float* onum = ytile + 64 * a.ldy;                        // [64][ldon]
+  int* ocode = reinterpret_cast<int*>(onum + 64 * a.ldon); // [64][ldoc]
+  float* s_s = reinterpret_cast<float*>(ocode + 64 * a.ldoc);  // [64][K] (dense s only)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = a.K;
+  const Philox rng(a.seed);
+  const int64_t n_tiles = (a.n + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t r0 = tile * 64;
+    const int nrows = (int)min((int64_t)64, a.n - r0);
+    __syncthreads();
+    const int nq = a.ldY / 4;
+    for (int idx = tid; idx < nrows * nq; idx += 256) {
+      const int lr = idx / nq, q = idx % nq;
+      const float4 v = *reinterpret_cast<const float4*>(a.y + (size_t)(r0 + lr) * a.ldY + q * 4);
+      float* dst = ytile + lr * a.ldy + q * 4;
+      if (q * 4 + 0 < a.Y) dst[0] = v.x;
+      if (q * 4 + 1 < a.Y) dst[1] = v.y;
+      if (q * 4 + 2 < a.Y) dst[2] = v.z;
+      if (q * 4 + 3 < a.Y) dst[3] = v.w;
+    }
+    if (a.s)
+      for (int idx = tid; idx < nrows * K; idx += 256) s_s[idx] = a.s[(size_t)r0 * K + idx];
+    __syncthreads();
+    const bool valid = lane < nrows;
+    const int64_t r = r0 + (valid ? lane : 0);
+    const uint32_t rid = (uint32_t)(a.row_offset + r), rid_hi = (uint32_t)((uint64_t)(a.row_offset + r) >> 32);
+    const int kc = a.s ? 0 : a.comp[r];
+    const float* yrow = ytile + lane * a.ldy;
+    const float* srow = s_s + lane * K;
+
+    // sequential, individually rounded dot of [y ; s] with [w_y ; w_s]
+    auto dot = [&](const float* w, const float* yb, int yd) {
+      float acc = 0.f;
+      for (int i = 0; i < yd; ++i) acc = detm::add(acc, detm::mul(w[i], yb[i]));
+      if (a.s) {
+        for (int j = 0; j < K; ++j) acc = detm::add(acc, detm::mul(w[yd + j], srow[j]));
+      } else {
+        acc = detm::add(acc, w[yd + kc]);
+      }
+      return acc;
+    };
+
+    for (int c = wave; c < a.n_cols; c += 4) {
+      const suave_col_t col = a.cols[c];
+      const float* yb = yrow + col.y_off;
+      const int yd = col.y_dim;
+      const float* w = a.params + col.w_off;
+      if (col.type <= SUAVE_TYPE_COUNT) {
+        float nrm, uni = 0.f;
+        if (a.noise_normal) nrm = a.noise_normal[(size_t)r * a.n_cols + c];
+        else { const uint4 q = rng(rid, (uint32_t)c, kStreamSampleNormal, rid_hi); nrm = normal2(q.x, q.y).x; }
+        float val;
+        if (col.type == SUAVE_TYPE_COUNT) {
+          if (a.noise_uniform) uni = a.noise_uniform[(size_t)r * a.n_cols + c];
+          else uni = philox_u(rng, rid, (uint32_t)c, kStreamSampleUniform, rid_hi);
+          const float rho = dot(w, yb, yd);
+          const float rate = detm::add(detm::softplus(rho), kEps);
+          val = poisson_from_noise(rate, uni, nrm);
+        } else {
+          const float am = dot(w, yb, yd);
+          const float bv = dot(a.params + col.w2_off, yb, 0);
+          const float v = detm::add(detm::softplus(bv), kEps);
+          if (col.type == SUAVE_TYPE_REAL) {  // decoder.py:90-91
+            const float sd = __fsqrt_rn(fmaxf(v, kEps));
+            val = detm::add(detm::mul(detm::add(am, detm::mul(nrm, sd)), col.scale), col.shift);
+          } else {  // decoder.py:139
+            const float mean = detm::add(detm::mul(am, col.scale), col.shift);
+            const float vs = detm::mul(v, detm::mul(col.scale, col.scale));
+            const float sd = __fsqrt_rn(fmaxf(vs, kEps));
+            val = detm::sub(detm::exp(detm::add(mean, detm::mul(nrm, sd))), 1.0f);
+          }
+        }
+        onum[lane * a.ldon + col.x_index] = val;
+      } else {
+        const int C = col.n_classes;
+        const int coff = a.cls_off[c];
+        auto draw_e = [&](int cl) {
+          if (a.noise_exp) return a.noise_exp[(size_t)r * a.total_classes + coff + cl];
+          const uint4 q = rng(rid, (uint32_t)(coff + cl), kStreamSampleExp, rid_hi);
+          return -__logf(u01(q.x));
+        };
+        int best_i = 0;
+        if (col.type == SUAVE_TYPE_CAT) {  // Gumbel-max == exponential race on softmax(logits)
+          const int ldw = yd + K;
+          float best = detm::sub(0.f, detm::log(draw_e(0)));
+          for (int cl = 1; cl < C; ++cl) {
+            const float L = dot(w + (cl - 1) * ldw, yb, yd);
+            const float sc = detm::sub(L, detm::log(draw_e(cl)));
+            if (sc > best) { best = sc; best_i = cl; }
+          }
+        } else {  // ordinal: race on the clipped cumulative-link probabilities
+          const float mo = dot(a.params + col.w2_off, yb, yd);
+          float thr = 0.f, prev = 0.f, best = -1.0f;
+          for (int cl = 0; cl < C; ++cl) {
+            float p;
+            if (cl < C - 1) {
+              const float part = dot(w + cl * K - 0, yb, 0);
+              thr = detm::add(thr, detm::add(detm::softplus(part), kEps));
+              const float sg = detm::sigmoid(detm::sub(thr, mo));
+              p = detm::sub(sg, prev);
+              prev = sg;
+            } else {
+              p = detm::sub(1.0f, prev);
+            }
+            p = fminf(fmaxf(p, kEps), 1.0f);
+            const float sc = detm::dvd(p, draw_e(cl));
+            if (sc > best) { best = sc; best_i = cl; }
+          }
+        }
+        ocode[lane * a.ldoc + col.x_index] = best_i;
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nrows * a.n_num; idx += 256) {
+      const int lr = idx / a.n_num, j = idx % a.n_num;
+      a.out_num[(size_t)(r0 + lr) * a.ld_num + j] = onum[lr * a.ldon + j];
+    }
+    for (int idx = tid; idx < nrows * a.n_disc; idx += 256) {
+      const int lr = idx / a.n_disc, j = idx % a.n_disc;
+      a.out_codes[(size_t)(r0 + lr) * a.ld_disc + j] = (int16_t)ocode[lr * a.ldoc + j];
+    }
+  }
+}
+
+struct PriorArgs {
+  const float* params;
+  int prior_mu_off, prior_logvar_off, pm_w_off, pm_b_off;
+  const float* cdf;
+  const float* u;
+  const float* eps;
+  uint64_t seed;
+  int64_t row_offset, n;
+  int K, D;
+  float* z;
+  int32_t* comp;
+};
+
+__global__ __launch_bounds__(256) void k_prior_latents(PriorArgs a) {
+  __shared__ int k_s[64];
+  const int tid = threadIdx.x;
+  const Philox rng(a.seed);
+  const int64_t n_tiles = (a.n + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t r0 = tile * 64;
+    const int nrows = (int)min((int64_t)64, a.n - r0);
+    __syncthreads();
+    if (tid < nrows) {
+      const int64_t r = r0 + tid;
+      const uint64_t gid = (uint64_t)(a.row_offset + r);
+      const float u = a.u ? a.u[r] : philox_u(rng, (uint32_t)gid, 0, kStreamPriorU, (uint32_t)(gid >> 32));
+      int k = 0;
+      for (int j = 0; j < a.K - 1; ++j) k += (u >= a.cdf[j]) ? 1 : 0;
+      k_s[tid] = k;
+      a.comp[r] = k;
+    }
+    __syncthreads();
+    const int dq = (a.D + 3) / 4;
+    for (int idx = tid; idx < nrows * dq; idx += 256) {
+      const int lr = idx / dq, q = idx % dq;
+      const int64_t r = r0 + lr;
+      const int k = k_s[lr];
+      const uint64_t gid = (uint64_t)(a.row_offset + r);
+      float ev[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!a.eps) {
+        const uint4 w = rng((uint32_t)gid, (uint32_t)q, kStreamPriorEps, (uint32_t)(gid >> 32));
+        const float2 n0 = normal2(w.x, w.y), n1 = normal2(w.z, w.w);
+        ev[0] = n0.x; ev[1] = n0.y; ev[2] = n1.x; ev[3] = n1.y;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int d = q * 4 + e;
+        if (d >= a.D) break;
+        float mu, lv;
+        if (a.prior_mu_off >= 0) {
+          mu = a.params[a.prior_mu_off + k * a.D + d];
+          lv = a.params[a.prior_logvar_off + k * a.D + d];
+        } else {  // PriorMean: mu[k,d] = W[d,k] + b[d]; logvar == 0 (prior.py:31-39, model.py:538-542)
+          mu = a.params[a.pm_w_off + d * a.K + k] + a.params[a.pm_b_off + d];
+          lv = 0.f;
+        }
+        const float eps = a.eps ? a.eps[(size_t)r * a.D + d] : ev[e];
+        a.z[(size_t)r * a.D + d] = mu + eps * __expf(0.5f * lv);
+      }
+    }
+  }
+}
+
+struct CondArgs {
+  const int64_t* class_offsets;
+  const int64_t* class_rows;
+  const int32_t* labels;
+  const float* train_probs;
+  const float* train_mu;
+  const float* train_logvar;
+  const float* u_row;
+  const float* e_comp;
+  const float* eps;
+  uint64_t seed;
+  int64_t row_offset, n;
+  int K, D;
+  float* z;
+  int32_t* comp;
+};
+
+__global__ __launch_bounds__(256) void k_cond_latents(CondArgs a) {
+  __shared__ int k_s[64];
+  __shared__ long long row_s[64];
+  const int tid = threadIdx.x;
+  const Philox rng(a.seed);
+  const int64_t n_tiles = (a.n + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t r0 = tile * 64;
+    const int nrows = (int)min((int64_t)64, a.n - r0);
+    __syncthreads();
+    if (tid < nrows) {
+      const int64_t r = r0 + tid;
+      const uint64_t gid = (uint64_t)(a.row_offset + r);
+      const int lab = a.labels[r];
+      const int64_t start = a.class_offsets[lab];
+      const int64_t count = a.class_offsets[lab + 1] - start;
+      const float u = a.u_row ? a.u_row[r] : philox_u(rng, (uint32_t)gid, 0, kStreamCondU, (uint32_t)(gid >> 32));
+      int64_t pick = (int64_t)detm::mul(u, (float)count);  // torch.randint analogue, model.py:3088
+      pick = min(pick, count - 1);
+      const int64_t row = a.class_rows[start + pick];
+      const float* pr = a.train_probs + (size_t)row * a.K;
+      float best = -1.0f;
+      int kb = 0;
+      for (int j = 0; j < a.K; ++j) {  // Categorical(probs).sample(): argmax(p / e), model.py:3092-3094
+        float e;
+        if (a.e_comp) e = a.e_comp[(size_t)r * a.K + j];
+        else e = -__logf(philox_u(rng, (uint32_t)gid, (uint32_t)j, kStreamCondExp, (uint32_t)(gid >> 32)));
+        const float sc = detm::dvd(pr[j], e);
+        if (sc > best) { best = sc; kb = j; }
+      }
+      k_s[tid] = kb;
+      row_s[tid] = row;
+      a.comp[r] = kb;
+    }
+    __syncthreads();
+    const int dq = (a.D + 3) / 4;
+    for (int idx = tid; idx < nrows * dq; idx += 256) {
+      const int lr = idx / dq, q = idx % dq;
+      const int64_t r = r0 + lr;
+      const int k = k_s[lr];
+      const int64_t row = row_s[lr];
+      const uint64_t gid = (uint64_t)(a.row_offset + r);
+      float ev[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!a.eps) {
+        const uint4 w = rng((uint32_t)gid, (uint32_t)q, kStreamPriorEps, (uint32_t)(gid >> 32));
+        const float2 n0 = normal2(w.x, w.y), n1 = normal2(w.z, w.w);
+        ev[0] = n0.x; ev[1] = n0.y; ev[2] = n1.x; ev[3] = n1.y;
+      }
+      const float* mu = a.train_mu + ((size_t)row * a.K + k) * a.D;
+      const float* lv = a.train_logvar + ((size_t)row * a.K + k) * a.D;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int d = q * 4 + e;
+        if (d >= a.D) break;
+        const float eps = a.eps ? a.eps[(size_t)r * a.D + d] : ev[e];
+        a.z[(size_t)r * a.D + d] = mu[d] + eps * __expf(0.5f * lv[d]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const float* params, const float* y,
+                        const float* s, const int32_t* comp, int64_t n, const float* nn, const float* nu,
+                        const float* ne, uint64_t seed, int64_t row_offset, float* out_num, int ld_num,
+                        int16_t* out_codes, int ld_disc, hipStream_t st) {
+  if (n <= 0) return 0;
+  const suave_model_t& m = p->model;
+  SampleArgs a{};
+  a.cols = p->cols_dev; a.cls_off = cls_off_dev; a.params = params; a.y = y; a.s = s; a.comp = comp; a.n = n;
+  a.n_cols = m.n_cols; a.n_num = m.n_num; a.n_disc = m.n_disc; a.K = m.n_components; a.ldY = p->ldY; a.Y = m.total_y;
+  a.total_classes = p->total_classes;
+  a.noise_normal = nn; a.noise_uniform = nu; a.noise_exp = ne; a.seed = seed; a.row_offset = row_offset;
+  a.out_num = out_num; a.ld_num = ld_num; a.out_codes = out_codes; a.ld_disc = ld_disc;
+  a.ldy = p->ldY | 1; a.ldon = std::max(m.n_num, 1) | 1; a.ldoc = std::max(m.n_disc, 1) | 1;
+  const size_t lds = sizeof(float) * ((size_t)64 * a.ldy + 64 * a.ldon + 64 * a.ldoc + 64 * m.n_components);
+  SUAVE_REQUIRE(lds <= 150 * 1024, "decode_sample: schema too wide for the single-chunk sample kernel");
+  static thread_local size_t lds_set = 0;
+  if (lds > 48 * 1024 && lds > lds_set) {
+    SUAVE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sample_heads),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set = lds;
+  }
+  const int64_t tiles = (n + 63) / 64;
+  const int grid = (int)std::min<int64_t>(tiles, 2 * (int64_t)p->n_cu);
+  hipLaunchKernelGGL(k_sample_heads, dim3(grid), dim3(256), lds, st, a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace suave
+
+using namespace suave;
+
+extern "C" int suave_prior_latents(const suave_plan* p, const float* params, const float* cdf, const float* u,
+                                   const float* eps, uint64_t seed, int64_t row_offset, int64_t n, void* stream,
+                                   float* z, int32_t* component) {
+  SUAVE_REQUIRE(p && params && cdf && z && component, "prior_latents: null argument");
+  if (n <= 0) return 0;
+  PriorArgs a{};
+  a.params = params;
+  a.prior_mu_off = p->model.prior_mu_off; a.prior_logvar_off = p->model.prior_logvar_off;
+  a.pm_w_off = p->model.pm_w_off; a.pm_b_off = p->model.pm_b_off;
+  a.cdf = cdf; a.u = u; a.eps = eps; a.seed = seed; a.row_offset = row_offset; a.n = n;
+  a.K = p->model.n_components; a.D = p->model.latent_dim; a.z = z; a.comp = component;
+  const int grid = (int)std::min<int64_t>((n + 63) / 64, 4096);
+  hipLaunchKernelGGL(k_prior_latents, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int suave_conditional_latents(const suave_plan* p, const int64_t* class_offsets, const int64_t* class_rows,
+                                         const int32_t* labels, const float* train_probs, const float* train_mu,
+                                         const float* train_logvar, const float* u_row, const float* e_comp,
+                                         const float* eps, uint64_t seed, int64_t row_offset, int64_t n, void* stream,
+                                         float* z, int32_t* component) {
+  SUAVE_REQUIRE(p && class_offsets && class_rows && labels && train_probs && train_mu && train_logvar && z && component,
+                "conditional_latents: null argument");
+  if (n <= 0) return 0;
+  CondArgs a{};
+  a.class_offsets = class_offsets; a.class_rows = class_rows; a.labels = labels; a.train_probs = train_probs;
+  a.train_mu = train_mu; a.train_logvar = train_logvar; a.u_row = u_row; a.e_comp = e_comp; a.eps = eps;
+  a.seed = seed; a.row_offset = row_offset; a.n = n; a.K = p->model.n_components; a.D = p->model.latent_dim;
+  a.z = z; a.comp = component;
+  const int grid = (int)std::min<int64_t>((n + 63) / 64, 4096);
+  hipLaunchKernelGGL(k_cond_latents, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,242 @@
+"""Device engine: owns the plan, the flat parameter / gradient / Adam buffers and
+the packed table in HBM, and drives the C-ABI entry points on a HIP stream.
+
+PyTorch is used for device memory, streams and ``torch.distributed`` only; no
+torch operator runs on the compute path.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .plan import BatchT, ElboOutT, MAX_HIDDEN, ModelLayout, NoiseT
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class PackedTable:
+    """The mixed-type table resident in HBM in packed form (include/suave_hip.h)."""
+
+    def __init__(self, xnum, codes, mask, device):
+        self.xnum = torch.as_tensor(np.ascontiguousarray(xnum, np.float32)).to(device)
+        self.codes = torch.as_tensor(np.ascontiguousarray(codes, np.int16)).to(device)
+        self.mask = torch.as_tensor(np.ascontiguousarray(mask, np.uint8)).to(device)
+        self.n_rows = int(self.mask.shape[0])
+        if self.xnum.shape[0] != self.n_rows or self.codes.shape[0] != self.n_rows:
+            raise ValueError("xnum / codes / mask must have the same number of rows")
+        self.ld_num = int(self.xnum.shape[1]) if self.xnum.dim() == 2 else 0
+        self.ld_disc = int(self.codes.shape[1]) if self.codes.dim() == 2 else 0
+        self.ld_mask = int(self.mask.shape[1])
+
+    def batch(self, row_begin: int, n_rows: int, row_index: Optional[torch.Tensor] = None) -> BatchT:
+        b = BatchT()
+        b.xnum = self.xnum.data_ptr() if self.xnum.numel() else None
+        b.codes = self.codes.data_ptr() if self.codes.numel() else None
+        b.mask = self.mask.data_ptr()
+        b.row_index = _ptr(row_index)
+        b.row_begin = int(row_begin)
+        b.n_rows = int(n_rows)
+        b.ld_num, b.ld_disc, b.ld_mask = self.ld_num, self.ld_disc, self.ld_mask
+        if row_index is None and row_begin + n_rows > self.n_rows:
+            raise ValueError("batch exceeds the table")
+        return b
+
+
+class Engine:
+    def __init__(self, layout: ModelLayout, device: str | torch.device = "cuda:0"):
+        self.layout = layout
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.SuaveHipError("the SUAVE HIP engine needs a GPU device (there is no CPU fallback)")
+        self.lib = _lib.load()
+        torch.cuda.set_device(self.device)
+        self._plan = C.c_void_p()
+        cols = layout.cols_array()
+        _lib.check(self.lib.suave_plan_create(C.byref(layout.model), cols, C.byref(self._plan)), "suave_plan_create")
+        n = layout.n_params
+        self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.adam_t = 0
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_rows = 0
+        self.sums = torch.zeros(4, dtype=torch.float64, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_plan", None) and self._plan.value:
+                self.lib.suave_plan_destroy(self._plan)
+                self._plan = C.c_void_p()
+        except Exception:
+            pass
+
+    # -- parameters ------------------------------------------------------------
+    def load_state(self, tensors: Mapping[str, np.ndarray]) -> None:
+        self.params.copy_(torch.from_numpy(self.layout.pack(tensors)))
+
+    def state(self) -> Dict[str, np.ndarray]:
+        return self.layout.unpack(self.params.cpu().numpy())
+
+    def grad_state(self) -> Dict[str, np.ndarray]:
+        return self.layout.unpack(self.grads.cpu().numpy())
+
+    def reset_optimizer(self) -> None:
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.adam_t = 0
+
+    # -- workspace -------------------------------------------------------------
+    def workspace(self, rows: int) -> torch.Tensor:
+        if self._ws is None or rows > self._ws_rows:
+            nbytes = C.c_size_t()
+            _lib.check(self.lib.suave_workspace_bytes(self._plan, int(rows), C.byref(nbytes)), "suave_workspace_bytes")
+            self._ws = torch.empty(int(nbytes.value) + 256, dtype=torch.uint8, device=self.device)
+            self._ws_rows = rows
+        return self._ws
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    @staticmethod
+    def _noise(noise: Optional[Mapping[str, object]], seed: int, step: int, keep_alive: list) -> NoiseT:
+        nz = NoiseT()
+        nz.seed, nz.step = int(seed), int(step)
+        if noise:
+            for key in ("exp_noise", "eps"):
+                t = noise.get(key)
+                if t is not None:
+                    keep_alive.append(t)
+                    setattr(nz, key, t.data_ptr())
+            for key in ("enc_keep", "dec_keep"):
+                lst = noise.get(key)
+                if lst is not None:
+                    arr = getattr(nz, key)
+                    for i, t in enumerate(lst):
+                        keep_alive.append(t)
+                        arr[i] = t.data_ptr()
+        return nz
+
+    # -- ELBO step -------------------------------------------------------------
+    def elbo(self, table: PackedTable, row_begin: int, n_rows: int, *, row_index: Optional[torch.Tensor] = None,
+             beta_scale: float, tau: float = 1.0, grad: bool = True, training: bool = True,
+             global_rows: Optional[int] = None, noise: Optional[Mapping[str, object]] = None, seed: int = 0,
+             step: int = 0, want: Sequence[str] = (), accumulate_sums: bool = False) -> Dict[str, torch.Tensor]:
+        """One ELBO forward (+ backward into ``self.grads``).  ``want`` selects
+        per-row outputs among reconstruction, categorical_kl, gaussian_kl,
+        latent, component, enc_out."""
+
+        B = int(n_rows)
+        ws = self.workspace(B)
+        keep: list = []
+        nz = self._noise(noise, seed, step, keep)
+        batch = table.batch(row_begin, B, row_index)
+        out = ElboOutT()
+        res: Dict[str, torch.Tensor] = {}
+        K, D = self.layout.n_components, self.layout.latent_dim
+        shapes = {"reconstruction": ((B,), torch.float32), "categorical_kl": ((B,), torch.float32),
+                  "gaussian_kl": ((B,), torch.float32), "latent": ((B, D), torch.float32),
+                  "component": ((B,), torch.int32), "enc_out": ((B, K + 2 * K * D), torch.float32)}
+        for name in want:
+            shape, dt = shapes[name]
+            res[name] = torch.empty(shape, dtype=dt, device=self.device)
+            setattr(out, name, res[name].data_ptr())
+        if accumulate_sums:
+            out.sums = self.sums.data_ptr()
+        base = (ws.data_ptr() + 255) // 256 * 256
+        nbytes = ws.numel() - (base - ws.data_ptr())
+        if grad:
+            rc = self.lib.suave_elbo_backward(self._plan, self.params.data_ptr(), C.byref(batch), C.byref(nz),
+                                              float(beta_scale), float(tau), int(global_rows or B), base, nbytes,
+                                              self._stream(), C.byref(out), self.grads.data_ptr())
+            _lib.check(rc, "suave_elbo_backward")
+        else:
+            rc = self.lib.suave_elbo_forward(self._plan, self.params.data_ptr(), C.byref(batch), C.byref(nz),
+                                             float(beta_scale), float(tau), int(bool(training)), base, nbytes,
+                                             self._stream(), C.byref(out))
+            _lib.check(rc, "suave_elbo_forward")
+        return res
+
+    def adam_step(self, lr: float | Mapping[str, float], *, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+        """torch.optim.Adam step; ``lr`` may map group name (encoder/decoder/prior) -> lr (0 = frozen)."""
+
+        self.adam_t += 1
+        names = ["encoder", "decoder", "prior"]
+        begins = [self.layout.group_ranges[n][0] for n in names] + [self.layout.group_ranges["prior"][1]]
+        lrs = [float(lr[n]) if isinstance(lr, Mapping) else float(lr) for n in names]
+        gb = (C.c_int32 * 4)(*begins)
+        lra = (C.c_float * 3)(*lrs)
+        rc = self.lib.suave_adam_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                      self.exp_avg_sq.data_ptr(), gb, lra, 3, self.adam_t, float(betas[0]),
+                                      float(betas[1]), float(eps), self._stream())
+        _lib.check(rc, "suave_adam_step")
+
+    # -- encode ----------------------------------------------------------------
+    def encode(self, table: PackedTable, row_begin: int, n_rows: int, *, temperature: Optional[float] = None,
+               row_index: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        B = int(n_rows)
+        K, D = self.layout.n_components, self.layout.latent_dim
+        ws = self.workspace(B)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        nbytes = ws.numel() - (base - ws.data_ptr())
+        batch = table.batch(row_begin, B, row_index)
+        enc = torch.empty((B, K + 2 * K * D), dtype=torch.float32, device=self.device)
+        pm = torch.empty((B, D), dtype=torch.float32, device=self.device)
+        plv = torch.empty((B, D), dtype=torch.float32, device=self.device)
+        pr = torch.empty((B, K), dtype=torch.float32, device=self.device)
+        inv_t = 1.0 if temperature is None else 1.0 / max(float(temperature), 1e-6)
+        rc = self.lib.suave_encode(self._plan, self.params.data_ptr(), C.byref(batch), inv_t, base, nbytes,
+                                   self._stream(), enc.data_ptr(), pm.data_ptr(), plv.data_ptr(), pr.data_ptr())
+        _lib.check(rc, "suave_encode")
+        return {"enc_out": enc, "mean": pm, "logvar": plv, "probs": pr}
+
+    # -- generation ------------------------------------------------------------
+    def prior_latents(self, n: int, cdf: torch.Tensor, *, u=None, eps=None, seed: int = 0, row_offset: int = 0):
+        D = self.layout.latent_dim
+        z = torch.empty((n, D), dtype=torch.float32, device=self.device)
+        comp = torch.empty((n,), dtype=torch.int32, device=self.device)
+        rc = self.lib.suave_prior_latents(self._plan, self.params.data_ptr(), cdf.data_ptr(), _ptr(u), _ptr(eps),
+                                          int(seed), int(row_offset), int(n), self._stream(), z.data_ptr(),
+                                          comp.data_ptr())
+        _lib.check(rc, "suave_prior_latents")
+        return z, comp
+
+    def conditional_latents(self, labels: torch.Tensor, class_offsets: torch.Tensor, class_rows: torch.Tensor,
+                            train_probs: torch.Tensor, train_mu: torch.Tensor, train_logvar: torch.Tensor, *,
+                            u_row=None, e_comp=None, eps=None, seed: int = 0, row_offset: int = 0):
+        n = int(labels.numel())
+        D = self.layout.latent_dim
+        z = torch.empty((n, D), dtype=torch.float32, device=self.device)
+        comp = torch.empty((n,), dtype=torch.int32, device=self.device)
+        rc = self.lib.suave_conditional_latents(self._plan, class_offsets.data_ptr(), class_rows.data_ptr(),
+                                                labels.data_ptr(), train_probs.data_ptr(), train_mu.data_ptr(),
+                                                train_logvar.data_ptr(), _ptr(u_row), _ptr(e_comp), _ptr(eps),
+                                                int(seed), int(row_offset), n, self._stream(), z.data_ptr(),
+                                                comp.data_ptr())
+        _lib.check(rc, "suave_conditional_latents")
+        return z, comp
+
+    def decode_sample(self, z: torch.Tensor, *, component: Optional[torch.Tensor] = None,
+                      assignments: Optional[torch.Tensor] = None, noise_normal=None, noise_uniform=None,
+                      noise_exp=None, seed: int = 0, row_offset: int = 0):
+        n = int(z.shape[0])
+        L = self.layout
+        ws = self.workspace(n)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        nbytes = ws.numel() - (base - ws.data_ptr())
+        out_num = torch.empty((n, max(L.n_num, 1)), dtype=torch.float32, device=self.device)
+        out_codes = torch.empty((n, max(L.n_disc, 1)), dtype=torch.int16, device=self.device)
+        rc = self.lib.suave_decode_sample(self._plan, self.params.data_ptr(), z.data_ptr(), _ptr(assignments),
+                                          _ptr(component), n, _ptr(noise_normal), _ptr(noise_uniform),
+                                          _ptr(noise_exp), int(seed), int(row_offset), base, nbytes, self._stream(),
+                                          out_num.data_ptr(), int(out_num.shape[1]), out_codes.data_ptr(),
+                                          int(out_codes.shape[1]))
+        _lib.check(rc, "suave_decode_sample")
+        return out_num[:, : L.n_num], out_codes[:, : L.n_disc]

@@ -1,0 +1,80 @@
+"""ctypes binding of ``libsuave_hip.so`` (C-ABI declared in ``include/suave_hip.h``).
+
+The product path has no CPU fallback: if the HIP library is missing or an
+entry point is absent this module raises, loudly.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .plan import BatchT, ColT, ElboOutT, ModelT, NoiseT
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsuave_hip.so")
+_lib = None
+
+EXPORTS = (
+    "suave_last_error",
+    "suave_plan_create",
+    "suave_plan_destroy",
+    "suave_workspace_bytes",
+    "suave_elbo_forward",
+    "suave_elbo_backward",
+    "suave_adam_step",
+    "suave_encode",
+    "suave_prior_latents",
+    "suave_conditional_latents",
+    "suave_decode_sample",
+)
+
+
+class SuaveHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library (once) and declare the entry-point signatures."""
+
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise SuaveHipError(
+            f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or suave_amd/csrc/build.sh). There is no CPU fallback."
+        )
+    lib = C.CDLL(_LIB_PATH)
+    missing = [name for name in EXPORTS if not hasattr(lib, name)]
+    if missing:
+        raise SuaveHipError(f"libsuave_hip.so lacks entry points: {missing}")
+    vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
+    lib.suave_last_error.restype = C.c_char_p
+    lib.suave_last_error.argtypes = []
+    lib.suave_plan_create.argtypes = [C.POINTER(ModelT), C.POINTER(ColT), C.POINTER(vp)]
+    lib.suave_plan_destroy.argtypes = [vp]
+    lib.suave_workspace_bytes.argtypes = [vp, i64, C.POINTER(sz)]
+    lib.suave_elbo_forward.argtypes = [vp, vp, C.POINTER(BatchT), C.POINTER(NoiseT), f32, f32, C.c_int, vp, sz, vp,
+                                       C.POINTER(ElboOutT)]
+    lib.suave_elbo_backward.argtypes = [vp, vp, C.POINTER(BatchT), C.POINTER(NoiseT), f32, f32, i64, vp, sz, vp,
+                                        C.POINTER(ElboOutT), vp]
+    lib.suave_adam_step.argtypes = [vp, vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, i64, f32, f32, f32, vp]
+    lib.suave_encode.argtypes = [vp, vp, C.POINTER(BatchT), f32, vp, sz, vp, vp, vp, vp, vp]
+    lib.suave_prior_latents.argtypes = [vp, vp, vp, vp, vp, u64, i64, i64, vp, vp, vp]
+    lib.suave_conditional_latents.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, i64, i64, vp, vp, vp]
+    lib.suave_decode_sample.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, u64, i64, vp, sz, vp, vp, i32, vp, i32]
+    for name in EXPORTS:
+        if name != "suave_last_error":
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().suave_last_error()
+        raise SuaveHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,310 @@
+"""Schema plan: flat parameter layout, column table and ctypes mirrors of
+``include/suave_hip.h``.
+
+The flat float32 parameter buffer is a bijection of the reference's
+``state_dict`` tensors: ``encoder.backbone.<i>.weight`` ...
+``decoder.heads.<col>.mean_layer.weight`` plus the prior tensors.  Weight
+matrices are stored ``[n_out, ld]`` row-major with ``ld`` = input width rounded
+up to 4 floats (pad entries stay zero: their gradient is identically zero and
+Adam leaves them untouched); the encoder's three output linears
+(``component_logits``, ``mu_layer``, ``logvar_layer``, encoder.py:56-58) are
+stacked into one ``[K + 2KD, H]`` matrix so the head is a single GEMM.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .types import DISCRETE_TYPES, NUMERIC_TYPES, Schema
+
+MAX_HIDDEN = 8
+MAX_COMPONENTS = 32
+TYPE_CODE = {"real": 0, "pos": 1, "count": 2, "cat": 3, "ordinal": 4}
+TYPE_ORDER = ("real", "pos", "count", "cat", "ordinal")  # encoder-input order, model.py:2813-2900
+
+
+class ColT(C.Structure):
+    _fields_ = [("type", C.c_int32), ("n_classes", C.c_int32), ("y_off", C.c_int32), ("y_dim", C.c_int32),
+                ("x_index", C.c_int32), ("enc_off", C.c_int32), ("enc_mask", C.c_int32), ("w_off", C.c_int32),
+                ("w2_off", C.c_int32), ("scale", C.c_float), ("shift", C.c_float)]
+
+
+class LayerT(C.Structure):
+    _fields_ = [("w_off", C.c_int32), ("b_off", C.c_int32), ("n_out", C.c_int32), ("n_in", C.c_int32),
+                ("ld", C.c_int32)]
+
+
+class ModelT(C.Structure):
+    _fields_ = [("n_cols", C.c_int32), ("n_num", C.c_int32), ("n_disc", C.c_int32), ("n_components", C.c_int32),
+                ("latent_dim", C.c_int32), ("n_hidden", C.c_int32), ("enc_in", C.c_int32), ("total_y", C.c_int32),
+                ("behaviour", C.c_int32), ("n_params", C.c_int32), ("dropout", C.c_float),
+                ("enc", LayerT * MAX_HIDDEN), ("enc_head", LayerT), ("dec", LayerT * MAX_HIDDEN), ("y_proj", LayerT),
+                ("head_off", C.c_int32), ("head_len", C.c_int32), ("prior_logits_off", C.c_int32),
+                ("prior_mu_off", C.c_int32), ("prior_logvar_off", C.c_int32), ("pm_w_off", C.c_int32),
+                ("pm_b_off", C.c_int32)]
+
+
+class BatchT(C.Structure):
+    _fields_ = [("xnum", C.c_void_p), ("codes", C.c_void_p), ("mask", C.c_void_p), ("row_index", C.c_void_p),
+                ("row_begin", C.c_int64), ("n_rows", C.c_int32), ("ld_num", C.c_int32), ("ld_disc", C.c_int32),
+                ("ld_mask", C.c_int32)]
+
+
+class NoiseT(C.Structure):
+    _fields_ = [("exp_noise", C.c_void_p), ("eps", C.c_void_p), ("enc_keep", C.c_void_p * MAX_HIDDEN),
+                ("dec_keep", C.c_void_p * MAX_HIDDEN), ("seed", C.c_uint64), ("step", C.c_uint64)]
+
+
+class ElboOutT(C.Structure):
+    _fields_ = [("reconstruction", C.c_void_p), ("categorical_kl", C.c_void_p), ("gaussian_kl", C.c_void_p),
+                ("latent", C.c_void_p), ("component", C.c_void_p), ("enc_out", C.c_void_p), ("sums", C.c_void_p)]
+
+
+def _r4(x: int) -> int:
+    return (x + 3) // 4 * 4
+
+
+@dataclass
+class TensorSlot:
+    """Where one ``state_dict`` tensor lives in the flat buffer."""
+
+    name: str
+    offset: int
+    shape: Tuple[int, ...]
+    ld: int  # row stride in the flat buffer (== shape[-1] for unpadded tensors)
+    row0: int = 0  # first row inside a stacked matrix
+
+
+@dataclass
+class ModelLayout:
+    schema: Schema
+    n_components: int
+    latent_dim: int
+    hidden: Tuple[int, ...]
+    dropout: float
+    behaviour: str
+    norm_stats: Mapping[str, Mapping[str, object]]
+    slots: Dict[str, TensorSlot] = field(default_factory=dict)
+    cols: List[ColT] = field(default_factory=list)
+    model: Optional[ModelT] = None
+
+    # derived
+    enc_in: int = 0
+    total_y: int = 0
+    n_num: int = 0
+    n_disc: int = 0
+    n_params: int = 0
+    numeric_columns: Tuple[str, ...] = ()
+    discrete_columns: Tuple[str, ...] = ()
+    total_classes: int = 0
+    class_offsets: Dict[str, int] = field(default_factory=dict)
+    group_ranges: Dict[str, Tuple[int, int]] = field(default_factory=dict)
+
+    def __post_init__(self) -> None:
+        self._build()
+
+    # ------------------------------------------------------------------
+    def _build(self) -> None:
+        schema, K, D = self.schema, int(self.n_components), int(self.latent_dim)
+        if not (1 <= K <= MAX_COMPONENTS):
+            raise ValueError(f"n_components must lie in 1..{MAX_COMPONENTS}")
+        if len(self.hidden) > MAX_HIDDEN:
+            raise ValueError(f"at most {MAX_HIDDEN} hidden layers are supported")
+        names = list(schema.feature_names)
+        ydims = schema.y_dimensions()
+        self.numeric_columns = tuple(n for n in names if schema[n].type in NUMERIC_TYPES)
+        self.discrete_columns = tuple(n for n in names if schema[n].type in DISCRETE_TYPES)
+        self.n_num, self.n_disc = len(self.numeric_columns), len(self.discrete_columns)
+        # encoder-input layout: values by type, then masks by type (model.py:2813-2905)
+        by_type = [n for t in TYPE_ORDER for n in names if schema[n].type == t]
+        enc_off: Dict[str, int] = {}
+        pos = 0
+        for n in by_type:
+            enc_off[n] = pos
+            pos += 1 if schema[n].type in NUMERIC_TYPES else int(schema[n].n_classes)
+        enc_mask = {n: pos + i for i, n in enumerate(by_type)}
+        self.enc_in = pos + len(by_type)
+        self.total_y = int(sum(ydims.values()))
+        step = 3 if self.dropout > 0 else 2  # index step of nn.Sequential(Linear, ReLU[, Dropout])
+
+        off = 0
+        m = ModelT()
+
+        def add_layer(layer: LayerT, prefix_w: str, prefix_b: str, n_out: int, n_in: int) -> None:
+            nonlocal off
+            ld = _r4(n_in)
+            layer.w_off, layer.n_out, layer.n_in, layer.ld = off, n_out, n_in, ld
+            self.slots[prefix_w] = TensorSlot(prefix_w, off, (n_out, n_in), ld)
+            off += _r4(n_out * ld)
+            layer.b_off = off
+            self.slots[prefix_b] = TensorSlot(prefix_b, off, (n_out,), n_out)
+            off += _r4(n_out)
+
+        g0 = off
+        prev = self.enc_in
+        for i, h in enumerate(self.hidden):
+            add_layer(m.enc[i], f"encoder.backbone.{i * step}.weight", f"encoder.backbone.{i * step}.bias", h, prev)
+            prev = h
+        # stacked encoder head
+        E = K + 2 * K * D
+        ld = _r4(prev)
+        m.enc_head.w_off, m.enc_head.n_out, m.enc_head.n_in, m.enc_head.ld = off, E, prev, ld
+        for nm, r0, rows in (("component_logits", 0, K), ("mu_layer", K, K * D), ("logvar_layer", K + K * D, K * D)):
+            self.slots[f"encoder.{nm}.weight"] = TensorSlot(f"encoder.{nm}.weight", off + r0 * ld, (rows, prev), ld, r0)
+        off += _r4(E * ld)
+        m.enc_head.b_off = off
+        for nm, r0, rows in (("component_logits", 0, K), ("mu_layer", K, K * D), ("logvar_layer", K + K * D, K * D)):
+            self.slots[f"encoder.{nm}.bias"] = TensorSlot(f"encoder.{nm}.bias", off + r0, (rows,), rows, r0)
+        off += _r4(E)
+        self.group_ranges["encoder"] = (g0, off)
+        g0 = off
+        prev = D
+        for i, h in enumerate(self.hidden):
+            add_layer(m.dec[i], f"decoder.backbone.{i * step}.weight", f"decoder.backbone.{i * step}.bias", h, prev)
+            prev = h
+        add_layer(m.y_proj, "decoder.y_projection.weight", "decoder.y_projection.bias", self.total_y, prev)
+        # likelihood heads, contiguous, schema order (all bias-free, decoder.py:61-62,105-106,153,190-192,233-236)
+        m.head_off = off
+        y_off = 0
+        i_num = i_disc = 0
+        cls_off = 0
+        for n in names:
+            spec = schema[n]
+            yd = int(ydims[n])
+            col = ColT()
+            col.type = TYPE_CODE[spec.type]
+            col.n_classes = int(spec.n_classes or 0)
+            col.y_off, col.y_dim = y_off, yd
+            col.enc_off, col.enc_mask = enc_off[n], enc_mask[n]
+            col.w_off, col.w2_off = off, -1
+            col.scale, col.shift = 1.0, 0.0
+            stats = self.norm_stats.get(n, {}) if self.norm_stats else {}
+            p = f"decoder.heads.{n}."
+            if spec.type in ("real", "pos"):
+                if spec.type == "real":
+                    col.scale, col.shift = float(stats.get("std", 1.0)), float(stats.get("mean", 0.0))
+                else:
+                    col.scale, col.shift = float(stats.get("std_log", 1.0)), float(stats.get("mean_log", 0.0))
+                self.slots[p + "mean_layer.weight"] = TensorSlot(p + "mean_layer.weight", off, (1, yd + K), yd + K)
+                off += yd + K
+                col.w2_off = off
+                self.slots[p + "var_layer.weight"] = TensorSlot(p + "var_layer.weight", off, (1, K), K)
+                off += K
+            elif spec.type == "count":
+                col.shift = float(stats.get("offset", 0.0))
+                self.slots[p + "rate_layer.weight"] = TensorSlot(p + "rate_layer.weight", off, (1, yd + K), yd + K)
+                off += yd + K
+            elif spec.type == "cat":
+                Cn = int(spec.n_classes)
+                self.slots[p + "logits_layer.weight"] = TensorSlot(p + "logits_layer.weight", off, (Cn - 1, yd + K), yd + K)
+                off += (Cn - 1) * (yd + K)
+            else:
+                Cn = int(spec.n_classes)
+                self.slots[p + "partition_layer.weight"] = TensorSlot(p + "partition_layer.weight", off, (Cn - 1, K), K)
+                off += (Cn - 1) * K
+                col.w2_off = off
+                self.slots[p + "mean_layer.weight"] = TensorSlot(p + "mean_layer.weight", off, (1, yd + K), yd + K)
+                off += yd + K
+            if spec.type in NUMERIC_TYPES:
+                col.x_index = i_num
+                i_num += 1
+            else:
+                col.x_index = i_disc
+                i_disc += 1
+                self.class_offsets[n] = cls_off
+                cls_off += int(spec.n_classes)
+            y_off += yd
+            self.cols.append(col)
+        self.total_classes = cls_off
+        m.head_len = off - m.head_off
+        off = _r4(off)
+        self.group_ranges["decoder"] = (g0, off)
+        g0 = off
+        m.prior_logits_off = m.prior_mu_off = m.prior_logvar_off = m.pm_w_off = m.pm_b_off = -1
+        if self.behaviour == "supervised":  # model.py:543-551
+            m.prior_logits_off = off
+            self.slots["prior.logits"] = TensorSlot("prior.logits", off, (K,), K)
+            off += _r4(K)
+            m.prior_mu_off = off
+            self.slots["prior.mu"] = TensorSlot("prior.mu", off, (K, D), D)
+            off += _r4(K * D)
+            m.prior_logvar_off = off
+            self.slots["prior.logvar"] = TensorSlot("prior.logvar", off, (K, D), D)
+            off += _r4(K * D)
+        else:  # prior.py:20-39
+            m.pm_w_off = off
+            self.slots["prior_mean.linear.weight"] = TensorSlot("prior_mean.linear.weight", off, (D, K), K)
+            off += _r4(D * K)
+            m.pm_b_off = off
+            self.slots["prior_mean.linear.bias"] = TensorSlot("prior_mean.linear.bias", off, (D,), D)
+            off += _r4(D)
+        self.group_ranges["prior"] = (g0, off)
+        self.n_params = off
+        m.n_cols, m.n_num, m.n_disc = len(names), self.n_num, self.n_disc
+        m.n_components, m.latent_dim, m.n_hidden = K, D, len(self.hidden)
+        m.enc_in, m.total_y = self.enc_in, self.total_y
+        m.behaviour = 0 if self.behaviour == "supervised" else 1
+        m.n_params = off
+        m.dropout = float(self.dropout)
+        self.model = m
+
+    # ------------------------------------------------------------------
+    def cols_array(self):
+        arr = (ColT * len(self.cols))()
+        for i, c in enumerate(self.cols):
+            arr[i] = c
+        return arr
+
+    def pack(self, tensors: Mapping[str, np.ndarray]) -> np.ndarray:
+        """state_dict-style tensors -> flat float32 buffer."""
+
+        flat = np.zeros(self.n_params, np.float32)
+        missing = [k for k in self.slots if k not in tensors]
+        if missing:
+            raise KeyError(f"missing parameter tensors: {missing[:4]}...")
+        for name, slot in self.slots.items():
+            t = np.asarray(tensors[name], np.float32).reshape(slot.shape)
+            if len(slot.shape) == 1:
+                flat[slot.offset : slot.offset + slot.shape[0]] = t
+            else:
+                rows, cols = slot.shape
+                view = np.lib.stride_tricks.as_strided(
+                    flat[slot.offset :], shape=(rows, cols), strides=(slot.ld * 4, 4), writeable=True)
+                view[...] = t
+        return flat
+
+    def unpack(self, flat: np.ndarray) -> Dict[str, np.ndarray]:
+        """flat buffer (parameters or gradients) -> state_dict-style tensors."""
+
+        flat = np.ascontiguousarray(flat, np.float32)
+        out: Dict[str, np.ndarray] = {}
+        for name, slot in self.slots.items():
+            if len(slot.shape) == 1:
+                out[name] = flat[slot.offset : slot.offset + slot.shape[0]].copy()
+            else:
+                rows, cols = slot.shape
+                view = np.lib.stride_tricks.as_strided(flat[slot.offset :], shape=(rows, cols), strides=(slot.ld * 4, 4))
+                out[name] = view.copy()
+        return out
+
+    def init_params(self, seed: int = 0) -> Dict[str, np.ndarray]:
+        """torch.nn.Linear default init (uniform +-1/sqrt(fan_in) for weight and bias);
+        prior tensors start at zero (model.py:533-551, prior.py:21-22)."""
+
+        rng = np.random.default_rng(seed)
+        out: Dict[str, np.ndarray] = {}
+        for name, slot in self.slots.items():
+            if name.startswith("prior"):
+                out[name] = np.zeros(slot.shape, np.float32)
+                continue
+            if name.endswith(".weight"):
+                fan_in = slot.shape[-1]
+            else:
+                fan_in = self.slots[name[: -len("bias")] + "weight"].shape[-1]
+            bound = 1.0 / np.sqrt(max(fan_in, 1))
+            out[name] = rng.uniform(-bound, bound, size=slot.shape).astype(np.float32)
+        return out

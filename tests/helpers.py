@@ -56,7 +56,7 @@ def s64_columns(n_cols: int = 64, real_variant: str = "std"):
     cyc = ["real", "pos", "count", "cat", "ordinal"]
     classes = [2, 3, 4, 5, 8]
     cols = []
-    n_disc = 0
+    n_seen = {"cat": 0, "ordinal": 0}  # each discrete type cycles through the class counts on its own
     for j in range(n_cols):
         t = cyc[j % 5]
         if t == "real":
@@ -67,8 +67,8 @@ def s64_columns(n_cols: int = 64, real_variant: str = "std"):
         elif t == "count":
             cols.append(orc.Column(f"f{j}", t, stats={"offset": 1.0}))
         else:
-            cols.append(orc.Column(f"f{j}", t, n_classes=classes[n_disc % 5]))
-            n_disc += 1
+            cols.append(orc.Column(f"f{j}", t, n_classes=classes[n_seen[t] % 5]))
+            n_seen[t] += 1
     return cols
 
 
@@ -103,3 +103,38 @@ def rel_err(a, b, floor=1e-6):
     b = np.asarray(b, np.float64)
     scale = max(float(np.max(np.abs(b))), floor)
     return float(np.max(np.abs(a - b))) / scale
+
+
+# ---------------------------------------------------------------------------
+# product-side helpers (GPU tests)
+# ---------------------------------------------------------------------------
+def layout_from_columns(cols, *, K, D, hidden, dropout=0.0, behaviour="supervised"):
+    from suave_amd.plan import ModelLayout
+    from suave_amd.types import Schema
+
+    spec = {}
+    stats = {}
+    for c in cols:
+        entry = {"type": c.type}
+        if c.n_classes:
+            entry["n_classes"] = c.n_classes
+        if c.y_dim:
+            entry["y_dim"] = c.y_dim
+        spec[c.name] = entry
+        stats[c.name] = dict(c.stats or {})
+    return ModelLayout(Schema(spec), K, D, tuple(hidden), float(dropout), behaviour, stats)
+
+
+def torch_noise(noise, device):
+    import torch
+
+    out = {}
+    if "exp" in noise:
+        out["exp_noise"] = torch.from_numpy(np.ascontiguousarray(noise["exp"], np.float32)).to(device)
+    if "eps" in noise:
+        out["eps"] = torch.from_numpy(np.ascontiguousarray(noise["eps"], np.float32)).to(device)
+    if noise.get("enc_drop") is not None:
+        out["enc_keep"] = [torch.from_numpy(np.ascontiguousarray(m, np.uint8)).to(device) for m in noise["enc_drop"]]
+    if noise.get("dec_drop") is not None:
+        out["dec_keep"] = [torch.from_numpy(np.ascontiguousarray(m, np.uint8)).to(device) for m in noise["dec_drop"]]
+    return out

@@ -1,0 +1,144 @@
+"""GPU parity of the HIP ELBO step (through the C-ABI) against the reference's
+golden vectors and against the CPU oracle.
+
+Tolerance: 1e-4 relative on per-row ELBO terms, KL and gradients
+(BASELINE.json north_star); component assignments bit-exact.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import suave_oracle as orc
+from tests.helpers import (fixture_model, fixture_noise, layout_from_columns, load_golden, rel_err, s64_columns,
+                           synth_packed, torch_noise)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+SUP = ["elbo_sup_mixed7_k3", "elbo_sup_mixed7_k1", "elbo_sup_mixed12_drop", "elbo_sup_ydim"]
+
+
+def _engine(om, P, device="cuda:0"):
+    from suave_amd.engine import Engine
+
+    layout = layout_from_columns(om.columns, K=om.K, D=om.D, hidden=om.hidden, dropout=om.dropout,
+                                 behaviour=om.behaviour)
+    eng = Engine(layout, device)
+    eng.load_state(P)
+    return eng
+
+
+def _grad_check(got, ref_grads, tol=TOL):
+    gmax = max(float(np.abs(v).max()) for v in ref_grads.values() if v.size)
+    for k, ref in ref_grads.items():
+        g = np.asarray(got[k]).reshape(ref.shape)
+        scale = max(float(np.abs(ref).max()), 1e-3 * gmax, 1e-9)
+        err = float(np.abs(g - ref).max())
+        assert err <= tol * scale + 1e-7, (k, err, scale)
+
+
+@pytest.mark.parametrize("name", SUP)
+def test_golden_supervised_step(name):
+    import torch
+    from suave_amd.engine import PackedTable
+
+    fx = load_golden(name)
+    om, P, meta = fixture_model(fx)
+    eng = _engine(om, P)
+    table = PackedTable(fx["xnum"], fx["codes"], fx["mask"], eng.device)
+    noise = torch_noise(fixture_noise(fx, om, meta), eng.device)
+    B = meta["B"]
+    res = eng.elbo(table, 0, B, beta_scale=meta["beta_scale"], tau=meta["tau"], grad=True, noise=noise,
+                   want=("reconstruction", "categorical_kl", "gaussian_kl", "latent", "component", "enc_out"),
+                   accumulate_sums=True)
+    torch.cuda.synchronize()
+    K, D = om.K, om.D
+    enc = res["enc_out"].cpu().numpy()
+    assert rel_err(enc[:, :K], fx["out/component_logits"]) < TOL
+    assert rel_err(enc[:, K:K + K * D], fx["out/component_mu"].reshape(B, -1)) < TOL
+    assert rel_err(enc[:, K + K * D:], fx["out/component_logvar"].reshape(B, -1)) < TOL
+    assert rel_err(res["reconstruction"].cpu().numpy(), fx["out/reconstruction"]) < TOL
+    assert rel_err(res["categorical_kl"].cpu().numpy(), fx["out/categorical_kl"]) < TOL
+    assert rel_err(res["gaussian_kl"].cpu().numpy(), fx["out/gaussian_kl"]) < TOL
+    assert rel_err(res["latent"].cpu().numpy(), fx["out/latent"]) < TOL
+    sums = eng.sums.cpu().numpy()
+    assert abs(sums[0] - float(fx["out/reconstruction"].sum())) < TOL * abs(float(fx["out/reconstruction"].sum())) + 1e-4
+    assert sums[3] == B
+    loss = -(sums[0] - meta["beta_scale"] * (sums[1] + sums[2])) / B
+    assert abs(loss - float(fx["out/loss"])) < TOL * abs(float(fx["out/loss"]))
+    ref_grads = {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")}
+    _grad_check(eng.grad_state(), ref_grads)
+    # one Adam step (torch.optim.Adam defaults)
+    eng.adam_step(meta["lr"])
+    torch.cuda.synchronize()
+    new = eng.state()
+    for k in ref_grads:
+        upd_ref = fx["adam1/" + k] - fx["param/" + k]
+        upd = new[k] - fx["param/" + k]
+        nz = np.abs(fx["grad/" + k]) > 1e-6
+        assert np.allclose(upd[nz], upd_ref[nz], atol=2e-3 * meta["lr"], rtol=0), k
+
+
+@pytest.mark.parametrize("B,dropout", [(256, 0.0), (4096, 0.1), (1000, 0.1)])
+def test_s64_step_matches_oracle(B, dropout):
+    """BASELINE config #2 schema (64 mixed columns, K=10, D=32, hidden (256,128)) against the CPU oracle."""
+
+    import torch
+    from suave_amd.engine import PackedTable
+
+    cols = s64_columns(64, real_variant="std" if dropout == 0 else "scaled")
+    om = orc.OracleModel(cols, n_components=10, latent_dim=32, hidden=(256, 128), dropout=dropout)
+    P = om.init_params(seed=3)
+    rng = np.random.default_rng(5)
+    for k in P:  # O(1) head weights / prior so every term matters
+        if ".heads." in k:
+            P[k] = (0.3 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    xnum, codes, mask = synth_packed(cols, B, 0.1, seed=20201021)
+    x_enc, data, masks = orc.dense_from_packed(om, xnum, codes, mask)
+    noise = {"exp": rng.exponential(size=(B, 10)).astype(np.float32),
+             "eps": rng.standard_normal((B, 32)).astype(np.float32)}
+    if dropout > 0:
+        noise["enc_drop"] = [(rng.random((B, h)) >= dropout).astype(np.uint8) for h in (256, 128)]
+        noise["dec_drop"] = [(rng.random((B, h)) >= dropout).astype(np.uint8) for h in (256, 128)]
+    ref = orc.elbo_supervised(om, P, x_enc, data, masks, noise, beta_scale=1.5, tau=1.0, training=True)
+    eng = _engine(om, P)
+    table = PackedTable(xnum, codes, mask, eng.device)
+    res = eng.elbo(table, 0, B, beta_scale=1.5, tau=1.0, grad=True, noise=torch_noise(noise, eng.device),
+                   want=("reconstruction", "categorical_kl", "gaussian_kl", "latent", "component"))
+    torch.cuda.synchronize()
+    assert np.array_equal(res["component"].cpu().numpy().astype(np.int64), ref["component_indices"])
+    assert rel_err(res["reconstruction"].cpu().numpy(), ref["reconstruction"]) < TOL
+    assert rel_err(res["categorical_kl"].cpu().numpy(), ref["categorical_kl"]) < TOL
+    assert rel_err(res["gaussian_kl"].cpu().numpy(), ref["gaussian_kl"]) < TOL
+    assert rel_err(res["latent"].cpu().numpy(), ref["latent"]) < TOL
+    _grad_check(eng.grad_state(), ref["grads"])
+
+
+def test_row_index_gather_and_determinism():
+    """A permuted batch through row_index equals the contiguous batch of the permuted table, bit for bit,
+    and two identical launches give bit-identical gradients (no float atomics anywhere)."""
+
+    import torch
+    from suave_amd.engine import PackedTable
+
+    cols = s64_columns(20)
+    om = orc.OracleModel(cols, n_components=4, latent_dim=8, hidden=(32, 16), dropout=0.0)
+    P = om.init_params(seed=1)
+    B = 300
+    xnum, codes, mask = synth_packed(cols, 1000, 0.2, seed=9)
+    perm = np.random.default_rng(2).permutation(1000)[:B].astype(np.int32)
+    eng = _engine(om, P)
+    full = PackedTable(xnum, codes, mask, eng.device)
+    sub = PackedTable(xnum[perm], codes[perm], mask[perm], eng.device)
+    rng = np.random.default_rng(4)
+    noise = torch_noise({"exp": rng.exponential(size=(B, 4)).astype(np.float32),
+                         "eps": rng.standard_normal((B, 8)).astype(np.float32)}, eng.device)
+    idx = torch.from_numpy(perm).to(eng.device)
+    eng.elbo(full, 0, B, row_index=idx, beta_scale=1.0, grad=True, noise=noise)
+    g1 = eng.grads.clone()
+    eng.elbo(sub, 0, B, beta_scale=1.0, grad=True, noise=noise)
+    g2 = eng.grads.clone()
+    eng.elbo(sub, 0, B, beta_scale=1.0, grad=True, noise=noise)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, g2)
+    assert torch.equal(g2, eng.grads)
