@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ELBO train rows/sec (BASELINE.json), S64 schema.
+
+A "step" is one pass of the hot path over one batch: packed-batch gather ->
+encoder -> Gumbel assignment + reparameterisation -> decoder -> fused
+likelihood + KL -> full backward -> (N>1: RCCL all-reduce of the flat gradient)
+-> Adam.  Warm-up-phase objective of the reference (suave/model.py:1496-1506),
+dropout 0.1, fp32 arithmetic, noise drawn in-kernel from the counter-based
+generators, inputs resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+K_COMP, LATENT, HIDDEN = 10, 32, (256, 128)
+PROF_CLASSES = ["gemm", "likelihood_kl", "latent", "expand", "reduce", "adam", "sample", "other"]
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def s64_schema(n_cols=64):
+    """columns cycle [real,pos,count,cat,ordinal]; class counts cycle [2,3,4,5,8]."""
+
+    cyc = ["real", "pos", "count", "cat", "ordinal"]
+    classes = [2, 3, 4, 5, 8]
+    seen = {"cat": 0, "ordinal": 0}
+    spec, stats = {}, {}
+    for j in range(n_cols):
+        t = cyc[j % 5]
+        name = f"f{j}"
+        if t in ("cat", "ordinal"):
+            spec[name] = {"type": t, "n_classes": classes[seen[t] % 5]}
+            seen[t] += 1
+            stats[name] = {}
+        else:
+            spec[name] = {"type": t}
+            stats[name] = ({"mean": 50.0, "std": 12.0} if t == "real" else
+                           {"mean_log": 1.2, "std_log": 0.45} if t == "pos" else {"offset": 1.0})
+    return spec, stats
+
+
+def synth_table_device(layout, n_rows, device, seed):
+    """Synthetic S64 table generated directly in HBM (torch is plumbing here, not the measured path)."""
+
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    schema = layout.schema
+    names = list(schema.feature_names)
+    mask = (torch.rand((n_rows, len(names)), device=device, generator=g) >= 0.1)
+    xnum = torch.empty((n_rows, layout.n_num), device=device, dtype=torch.float32)
+    codes = torch.empty((n_rows, layout.n_disc), device=device, dtype=torch.int16)
+    i_num = i_disc = 0
+    for j, n in enumerate(names):
+        spec = schema[n]
+        if spec.type == "real":
+            col = torch.randn(n_rows, device=device, generator=g)
+        elif spec.type == "pos":
+            raw = torch.exp(1.0 + 0.5 * torch.randn(n_rows, device=device, generator=g))
+            col = (torch.log1p(raw) - 1.2) / 0.45
+        elif spec.type == "count":
+            cnt = torch.poisson(torch.full((n_rows,), 3.0, device=device), generator=g)
+            col = torch.log(cnt + 1.0)
+        if spec.type in ("real", "pos", "count"):
+            xnum[:, i_num] = torch.where(mask[:, j], col, torch.zeros_like(col))
+            i_num += 1
+        else:
+            c = torch.randint(0, spec.n_classes, (n_rows,), device=device, generator=g).to(torch.int16)
+            codes[:, i_disc] = torch.where(mask[:, j], c, torch.full_like(c, -1))
+            i_disc += 1
+    return xnum, codes, mask.to(torch.uint8)
+
+
+def gemm_flops_per_row(layout):
+    """Algorithmic FLOPs of the dense layers, forward + backward (2*MAC, x3): SURVEY.md §8d."""
+
+    I, Y, K, D = layout.enc_in, layout.total_y, layout.n_components, layout.latent_dim
+    mac = 0
+    prev = I
+    for h in layout.hidden:
+        mac += prev * h
+        prev = h
+    mac += prev * (K + 2 * K * D)
+    prev = D
+    for h in layout.hidden:
+        mac += prev * h
+        prev = h
+    mac += prev * Y
+    return 6 * mac
+
+
+def cpu_baseline(spec, stats, dropout, budget_s=15.0, batch=4096):
+    """The CPU oracle (numpy restatement of the reference path, oracle/) timed on this host's cores."""
+
+    from oracle import suave_oracle as orc
+
+    cols = [orc.Column(n, s["type"], s.get("n_classes"), None, stats[n]) for n, s in spec.items()]
+    om = orc.OracleModel(cols, n_components=K_COMP, latent_dim=LATENT, hidden=HIDDEN, dropout=dropout)
+    P = om.init_params(seed=0)
+    rng = np.random.default_rng(0)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests.helpers import synth_packed
+
+    xnum, codes, mask = synth_packed(cols, batch, 0.1, seed=20201021)
+    x_enc, data, masks = orc.dense_from_packed(om, xnum, codes, mask)
+    state = {}
+    times = []
+    t_end = time.perf_counter() + budget_s
+    step = 0
+    while True:
+        noise = {"exp": rng.exponential(size=(batch, K_COMP)).astype(np.float32),
+                 "eps": rng.standard_normal((batch, LATENT)).astype(np.float32),
+                 "enc_drop": [(rng.random((batch, h)) >= dropout) for h in HIDDEN],
+                 "dec_drop": [(rng.random((batch, h)) >= dropout) for h in HIDDEN]}
+        t0 = time.perf_counter()
+        out = orc.elbo_supervised(om, P, x_enc, data, masks, noise, beta_scale=1.0, tau=1.0, training=True)
+        step += 1
+        orc.adam_step(P, out["grads"], state, lr=1e-3, step=step)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() > t_end and len(times) >= 4:
+            break
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
+    except Exception:
+        cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    med = float(np.median(times[1:]))
+    return {"value": batch / med, "unit": "rows/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times) - 1} ELBO steps (fwd+bwd+Adam) of the numpy oracle on {batch} S64 rows, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=65536, help="rows per GPU per step")
+    ap.add_argument("--rows", type=int, default=0, help="table rows per GPU (default 1M at N=1, 2M at N>1)")
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    from suave_amd import lib as slib
+    from suave_amd.engine import Engine, PackedTable
+    from suave_amd.plan import ModelLayout
+    from suave_amd.types import Schema
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    spec, stats = s64_schema()
+    layout = ModelLayout(Schema(spec), K_COMP, LATENT, HIDDEN, args.dropout, "supervised", stats)
+    eng = Engine(layout, device)
+    eng.load_state(layout.init_params(seed=0))  # identical replicas on every rank
+    rows = args.rows or (1_000_000 if world == 1 else 2_000_000)
+    B = min(args.batch, rows)
+    xnum, codes, mask = synth_table_device(layout, rows, device, seed=20201021 + rank)
+    table = PackedTable.__new__(PackedTable)
+    table.xnum, table.codes, table.mask = xnum, codes, mask
+    table.n_rows, table.ld_num, table.ld_disc, table.ld_mask = rows, xnum.shape[1], codes.shape[1], mask.shape[1]
+
+    n_batches = max(1, rows // B)
+    warmup_steps = max(1, 10 * n_batches)  # kl_warmup_epochs = 10 (model.py:59, :1448)
+    state = {"perm": None, "step": 0}
+    lr = 1e-3
+
+    def one_step():
+        i = state["step"] % n_batches
+        if i == 0:  # per-epoch permutation of this rank's shard (model.py:1465)
+            state["perm"] = torch.randperm(rows, device=device, dtype=torch.int32)
+        state["step"] += 1
+        idx = state["perm"][i * B:(i + 1) * B]
+        beta = 1.5 * min(state["step"], warmup_steps) / warmup_steps  # losses.kl_warmup
+        eng.elbo(table, 0, B, row_index=idx, beta_scale=beta, tau=1.0, grad=True, global_rows=B * world,
+                 seed=1234, step=state["step"], accumulate_sums=True)
+        if dist is not None:
+            dist.all_reduce(eng.grads)  # RCCL sum of the flat gradient (each rank already scaled by 1/global_rows)
+        eng.adam_step(lr)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    prof = not args.no_profile
+    if prof:
+        slib.load().suave_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ms = (C.c_double * 8)()
+    cnt = (C.c_int64 * 8)()
+    if prof:
+        slib.load().suave_profile_enable(0)
+        slib.check(slib.load().suave_profile_read(ms, cnt, 8), "suave_profile_read")
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sums = eng.sums.cpu().numpy()
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        value = world * B * steps / elapsed
+        line = {
+            "metric": "ELBO train rows/sec", "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("S64: 1M rows x 64 mixed cols (13 real/13 pos/13 count/13 cat/12 ordinal, 10%% masked), "
+                                    "latent 32, K=10, hidden (256,128), dropout %.2f, fwd+bwd+Adam" % args.dropout)
+                       if world == 1 else
+                       ("S64 data-parallel: %dM rows x 64 cols row-sharded over %d GPUs, RCCL all-reduce of the flat "
+                        "gradient per step" % (rows * world // 1_000_000, world)),
+                       "rows_per_gpu": rows, "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}"},
+            "mean_elbo_terms": {"reconstruction": sums[0] / max(sums[3], 1), "categorical_kl": sums[1] / max(sums[3], 1),
+                                "gaussian_kl": sums[2] / max(sums[3], 1)},
+        }
+        if prof and cnt[0] > 0:
+            gemm_flops = gemm_flops_per_row(layout) * B * steps
+            achieved = gemm_flops / (ms[0] * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (fp32 MFMA, all %d launches/step)" % (cnt[0] // steps),
+                                "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                                "avg_launch_us": 1e3 * ms[0] / cnt[0],
+                                "algorithmic_flops_per_launch": gemm_flops / cnt[0]}
+            line["kernel_ms_per_step"] = {PROF_CLASSES[i]: ms[i] / steps for i in range(8) if cnt[i] > 0}
+            loss_bytes = 3.0e3 * B  # ~3.0 KB/row fwd+bwd for the fused likelihood+KL kernel
+            if cnt[1] > 0:
+                line["roofline_likelihood_kl"] = {"bound": "hbm", "achieved": loss_bytes * steps / (ms[1] * 1e-3) / 1e9,
+                                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                  "frac": loss_bytes * steps / (ms[1] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                                  "traffic": None}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(spec, stats, args.dropout)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -214,6 +214,15 @@ int suave_decode_sample(const suave_plan* plan, const float* params, const float
                         int64_t row_offset, void* workspace, size_t workspace_bytes, void* stream,
                         float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc);
 
+/* Measurement aid (no counterpart in the reference): when enabled, every kernel
+ * launch of the library is bracketed by HIP events on its stream;
+ * suave_profile_read synchronises and returns the summed device time (ms) and
+ * launch count per kernel class since the last read.  Classes: 0 GEMM,
+ * 1 likelihood+KL, 2 latent, 3 expand, 4 reduce, 5 Adam, 6 sample, 7 other. */
+#define SUAVE_PROFILE_CLASSES 8
+int suave_profile_enable(int on);
+int suave_profile_read(double* ms_by_class, int64_t* launches_by_class, int32_t n_classes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,42 @@ namespace suave {
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 
+// ---------------------------------------------------------------------------
+// per-kernel-class timing (off by default; bench.py turns it on)
+// ---------------------------------------------------------------------------
+namespace {
+struct ProfState {
+  bool enabled = false;
+  std::vector<hipEvent_t> start[kProfCount], stop[kProfCount];
+  std::vector<hipEvent_t> pool;
+} g_prof;
+hipEvent_t prof_event() {
+  if (!g_prof.pool.empty()) {
+    hipEvent_t e = g_prof.pool.back();
+    g_prof.pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+
+ProfScope::ProfScope(int c, hipStream_t s) : cls(c), stream(s), on(g_prof.enabled) {
+  if (!on) return;
+  hipEvent_t e = prof_event();
+  if (!e) { on = false; return; }
+  (void)hipEventRecord(e, stream);
+  g_prof.start[cls].push_back(e);
+}
+ProfScope::~ProfScope() {
+  if (!on) return;
+  hipEvent_t e = prof_event();
+  if (!e) { g_prof.pool.push_back(g_prof.start[cls].back()); g_prof.start[cls].pop_back(); return; }
+  (void)hipEventRecord(e, stream);
+  g_prof.stop[cls].push_back(e);
+}
+
 __global__ void k_onehot(const int32_t* kidx, int n_rows, int K, int ld, float* out) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)n_rows * K; e += (int64_t)gridDim.x * 256) {
     const int r = (int)(e / K), j = (int)(e % K);
@@ -673,4 +709,30 @@ extern "C" int suave_decode_sample(const suave_plan* p, const float* params, con
     return rc;
   return launch_sample_heads(p, p->cls_off_dev, params, w.y, s_dense, component, n, noise_normal, noise_uniform,
                              noise_exp, seed, row_offset, out_num, ld_num, out_codes, ld_disc, st);
+}
+
+extern "C" int suave_profile_enable(int on) {
+  g_prof.enabled = on != 0;
+  return 0;
+}
+
+extern "C" int suave_profile_read(double* ms_by_class, int64_t* launches_by_class, int32_t n_classes) {
+  SUAVE_REQUIRE(ms_by_class && launches_by_class && n_classes >= kProfCount, "profile_read: need room for all classes");
+  for (int c = 0; c < kProfCount; ++c) {
+    double total = 0.0;
+    const size_t n = std::min(g_prof.start[c].size(), g_prof.stop[c].size());
+    for (size_t i = 0; i < n; ++i) {
+      SUAVE_CHECK_HIP(hipEventSynchronize(g_prof.stop[c][i]));
+      float ms = 0.f;
+      SUAVE_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.start[c][i], g_prof.stop[c][i]));
+      total += ms;
+    }
+    ms_by_class[c] = total;
+    launches_by_class[c] = (int64_t)n;
+    for (hipEvent_t e : g_prof.start[c]) g_prof.pool.push_back(e);
+    for (hipEvent_t e : g_prof.stop[c]) g_prof.pool.push_back(e);
+    g_prof.start[c].clear();
+    g_prof.stop[c].clear();
+  }
+  return 0;
 }

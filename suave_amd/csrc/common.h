@@ -158,4 +158,14 @@ struct GemmArgs {
 
 int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream);
 
+// ----- optional per-kernel-class timing with HIP events (suave_profile_*) -----
+enum ProfClass : int { kProfGemm = 0, kProfLoss, kProfLatent, kProfExpand, kProfReduce, kProfAdam, kProfSample, kProfOther, kProfCount };
+struct ProfScope {
+  int cls;
+  hipStream_t stream;
+  bool on;
+  ProfScope(int cls, hipStream_t stream);
+  ~ProfScope();
+};
+
 }  // namespace suave

@@ -285,6 +285,7 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   const int splits = a.epi == kEpiSlab ? a.splits : 1;
   GemmArgs args = a;
   args.splits = splits;
+  ProfScope prof_scope(kProfGemm, stream);
   const bool narrow = a.N <= 64;
   if (narrow) {
     const int tiles = ((a.M + 255) / 256) * ((a.N + 63) / 64);

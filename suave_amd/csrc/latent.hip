@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void k_posterior_stats(const float* __restrict
 // ---- host launchers -----------------------------------------------------------
 int launch_expand(const suave_plan* p, const int32_t* enc_src_dev, const suave_batch_t& b, float* x, hipStream_t s) {
   if (b.n_rows <= 0) return 0;
+  ProfScope prof_scope(kProfExpand, s);
   const int grid = std::min((b.n_rows + 3) / 4, 4096);
   hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), 0, s, enc_src_dev, p->cols_dev, b, p->ldI, x);
   SUAVE_CHECK_HIP(hipGetLastError());
@@ -232,6 +233,7 @@ int launch_expand(const suave_plan* p, const int32_t* enc_src_dev, const suave_b
 int launch_latent_fwd(const LatentFwdArgs& a, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
   const int grid = std::min((a.n_rows + 63) / 64, 2048);
+  ProfScope prof_scope(kProfLatent, s);
   hipLaunchKernelGGL(k_latent_fwd, dim3(grid), dim3(256), 0, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
@@ -240,6 +242,7 @@ int launch_latent_fwd(const LatentFwdArgs& a, hipStream_t s) {
 int launch_latent_bwd(const LatentBwdArgs& a, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
   const int grid = std::min((a.n_rows + 63) / 64, 2048);
+  ProfScope prof_scope(kProfLatent, s);
   hipLaunchKernelGGL(k_latent_bwd, dim3(grid), dim3(256), 0, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
@@ -249,6 +252,7 @@ int launch_posterior_stats(const float* encout, int ldE, int K, int D, int n_row
                            float* post_mean, float* post_logvar, float* probs, hipStream_t s) {
   if (n_rows <= 0) return 0;
   const int grid = std::min((n_rows + 63) / 64, 2048);
+  ProfScope prof_scope(kProfLatent, s);
   hipLaunchKernelGGL(k_posterior_stats, dim3(grid), dim3(256), 0, s, encout, ldE, K, D, n_rows, inv_temp, enc_out_user,
                      post_mean, post_logvar, probs);
   SUAVE_CHECK_HIP(hipGetLastError());

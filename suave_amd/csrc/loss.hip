@@ -88,6 +88,8 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
         if (c0 + 3 >= 0 && c0 + 3 < ch.y_len) dst[c0 + 3] = v.w;
       }
       (void)yq;
+      for (int idx = tid; idx < (64 - nrows) * ch.y_len; idx += 256)  // rows past the table: finite zeros
+        ytile[(nrows + idx / ch.y_len) * a.ldy + idx % ch.y_len] = 0.f;
       if (tid < 64) {
         const int r = r0 + tid;
         int k = 0;
@@ -146,9 +148,11 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
         if (col.type == SUAVE_TYPE_POS) nll += xr;
         recon += obs ? -nll : 0.f;
         if (GRAD) {
-          const float ga = u * (rr / cc) * col.scale;
-          const float gb = (vs >= kEps ? u * (-0.5f) * (1.0f / cc - rr * rr / (cc * cc)) : 0.f) *
-                           (col.scale * col.scale) * softplus_grad_f(bv);
+          // masked / out-of-tile lanes get an exact zero (select, not 0 * x: x may be inf or NaN there)
+          const float ga = obs ? u * (rr / cc) * col.scale : 0.f;
+          const float gb = (obs && vs >= kEps) ? u * (-0.5f) * (1.0f / cc - rr * rr / (cc * cc)) *
+                                                      (col.scale * col.scale) * softplus_grad_f(bv)
+                                                : 0.f;
           for (int i = 0; i < yd; ++i) {
             const float t = wave_sum_dpp(ga * yb[i]);
             acc_add(hw, i, t, lane);
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
         const float lp = (cnt == 0.f ? 0.f : cnt * __logf(rc)) - rc - lgammaf(cnt + 1.0f);
         recon += obs ? lp : 0.f;
         if (GRAD) {
-          const float gr = u * (cnt / rc - 1.0f) * softplus_grad_f(rho);
+          const float gr = obs ? u * (cnt / rc - 1.0f) * softplus_grad_f(rho) : 0.f;
           for (int i = 0; i < yd; ++i) {
             const float t = wave_sum_dpp(gr * yb[i]);
             acc_add(hw, i, t, lane);
@@ -209,11 +213,11 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
         const bool has = code >= 0 && code < C;
         recon += (obs && has) ? (lcode - lse) : 0.f;
         if (GRAD) {
-          const float ux = has ? u : 0.f;  // all-zero one-hot: sum(x) = 0 -> zero gradient
+          const bool live = obs && has;     // all-zero one-hot: sum(x) = 0 -> zero gradient
           // sweep 2: g_c = u * (x_c - softmax_c); weight gradients while y is intact
           for (int cl = 1; cl < C; ++cl) {
             const float p = __expf(gsw[cl * 64] - lse);
-            const float g = ux * ((cl == code ? 1.0f : 0.f) - p);
+            const float g = live ? u * ((cl == code ? 1.0f : 0.f) - p) : 0.f;
             gsw[cl * 64] = g;
             float* hr = hw + (cl - 1) * ldw;
             for (int i = 0; i < yd; ++i) {
@@ -256,9 +260,9 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
         const float p = fminf(fmaxf(p_raw, kEps), 1.0f);
         recon += obs ? __logf(p) : 0.f;
         if (GRAD) {
-          const float gp = (p_raw >= kEps && p_raw <= 1.0f) ? u / p : 0.f;
-          const float du_t = (t < C - 1) ? gp * sg_t * (1.0f - sg_t) : 0.f;
-          const float du_tm1 = (t > 0) ? -gp * sg_tm1 * (1.0f - sg_tm1) : 0.f;
+          const float gp = (obs && p_raw >= kEps && p_raw <= 1.0f) ? u / p : 0.f;
+          const float du_t = (gp != 0.f && t < C - 1) ? gp * sg_t * (1.0f - sg_t) : 0.f;
+          const float du_tm1 = (gp != 0.f && t > 0) ? -gp * sg_tm1 * (1.0f - sg_tm1) : 0.f;
           const float gmean = -(du_t + du_tm1);
           for (int i = 0; i < yd; ++i) {
             const float s = wave_sum_dpp(gmean * yb[i]);
@@ -420,6 +424,7 @@ static int launch_loss_k(const LossArgs& a, bool grad, int grid_x, int n_chunks,
 
 int launch_loss(const LossArgs& a, bool grad, int kmax, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
+  ProfScope prof_scope(kProfLoss, s);
   if (kmax <= 8) return launch_loss_k<8>(a, grad, grid_x, n_chunks, lds_bytes, s);
   if (kmax <= 16) return launch_loss_k<16>(a, grad, grid_x, n_chunks, lds_bytes, s);
   return launch_loss_k<32>(a, grad, grid_x, n_chunks, lds_bytes, s);

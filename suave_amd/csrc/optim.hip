@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
 
 int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s) {
   int gx = std::max(1, std::min((max_elems + 255) / 256, 256));
+  ProfScope prof_scope(kProfReduce, s);
   hipLaunchKernelGGL(k_reduce, dim3(gx, a.n_segs + 1), dim3(256), 0, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
@@ -96,6 +97,7 @@ extern "C" int suave_adam_step(float* params, const float* grads, float* exp_avg
   const int n = a.begin[n_groups];
   if (n <= 0) return 0;
   const int grid = std::min((n + 255) / 256, 2048);
+  ProfScope prof_scope(kProfAdam, static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;

@@ -361,6 +361,7 @@ int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const f
   }
   const int64_t tiles = (n + 63) / 64;
   const int grid = (int)std::min<int64_t>(tiles, 2 * (int64_t)p->n_cu);
+  ProfScope prof_scope(kProfSample, st);
   hipLaunchKernelGGL(k_sample_heads, dim3(grid), dim3(256), lds, st, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
