@@ -156,13 +156,13 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
   size_t slab = 0;
   for (const suave_layer_t* l : all_layers(p)) {
     const int ldc = round_up(l->n_in + 1, 4);
-    slab += (size_t)tn_splits(p, l->n_out, l->n_in + 1, rows) * l->n_out * ldc;
+    slab += (size_t)tn_splits(p, l->n_out, l->n_in, rows) * l->n_out * ldc;
   }
   const int lg = loss_grid(p, rows);
   slab += (size_t)lg * m.head_len;
   {
-    const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components + 1;
-    slab += (size_t)tn_splits(p, Mt, Nt, rows) * Mt * round_up(Nt, 4);
+    const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components;
+    slab += (size_t)tn_splits(p, Mt, Nt, rows) * Mt * round_up(Nt + 1, 4);
   }
   w->slab_floats = slab;
   w->slab = c.take<float>(slab);
@@ -226,10 +226,10 @@ int bwd_data(const suave_plan* p, const float* params, const suave_layer_t& l, c
 int bwd_weight(const suave_plan* p, const suave_layer_t& l, const float* dC, int lddc, const float* A, int lda,
                int rows, float* slab_base, size_t* slab_off, ReduceArgs* red, int* max_elems, hipStream_t s) {
   const int ldc = round_up(l.n_in + 1, 4);
-  const int splits = tn_splits(p, l.n_out, l.n_in + 1, rows);
+  const int splits = tn_splits(p, l.n_out, l.n_in, rows);
   GemmArgs g = gemm_base();
   g.A = dC; g.B = A; g.C = slab_base + *slab_off;
-  g.M = l.n_out; g.N = l.n_in + 1; g.K = rows;
+  g.M = l.n_out; g.N = l.n_in; g.K = rows;
   g.lda = lddc; g.ldb = lda; g.ldc = ldc;
   g.a_kmajor = 1; g.b_kmajor = 1;
   g.epi = kEpiSlab;
@@ -406,8 +406,8 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     }
     // ---- prior gradients: (prior_terms^T * [onehot(k) | 1]) via the split GEMM ----
     {
-      const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components + 1;
-      const int ldc = round_up(Nt, 4);
+      const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components;
+      const int ldc = round_up(Nt + 1, 4);
       const int splits = tn_splits(p, Mt, Nt, B);
       float* onehot = w.onehot;  // [B, ldK] one-hot of the selected component
       const int ld1 = p->ldK;

@@ -40,7 +40,7 @@ __device__ __forceinline__ bool drop_keep(uint32_t key, uint32_t row_id, uint32_
   return h >= thr;
 }
 
-template <int WAVES_M, int WAVES_N>
+template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   constexpr int LDAS = BM + PAD, LDBS = BN + PAD;
@@ -85,67 +85,62 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 
   float4 ra[NA], rb[NB];
 
+  // Loads only issue the (predicated) global reads; the ragged-edge masking is done by
+  // fix_tiles() right before the LDS store so the reads stay in flight during the MFMAs.
   auto load_a = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
       const int idx = tid + p * 256;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!a.a_kmajor) {
+      if (!A_KM) {
         const int row = idx >> 2, kq = idx & 3;
         const int gi = m0 + row, gk = k0 + kq * 4;
-        if (gi < a.M && gk < k_end) {
-          v = *reinterpret_cast<const float4*>(a.A + (size_t)gi * a.lda + gk);
-          if (gk + 1 >= k_end) v.y = 0.f;
-          if (gk + 2 >= k_end) v.z = 0.f;
-          if (gk + 3 >= k_end) v.w = 0.f;
-        }
+        if (gi < a.M && gk < k_end) v = *reinterpret_cast<const float4*>(a.A + (size_t)gi * a.lda + gk);
       } else {
         const int krow = idx / (BM / 4), iq = idx % (BM / 4);
         const int gk = k0 + krow, gi = m0 + iq * 4;
-        if (gk < k_end && gi < a.M) {
-          v = *reinterpret_cast<const float4*>(a.A + (size_t)gk * a.lda + gi);
-          if (gi + 1 >= a.M) v.y = 0.f;
-          if (gi + 2 >= a.M) v.z = 0.f;
-          if (gi + 3 >= a.M) v.w = 0.f;
-        }
+        if (gk < k_end && gi < a.M) v = *reinterpret_cast<const float4*>(a.A + (size_t)gk * a.lda + gi);
       }
       ra[p] = v;
     }
   };
   auto load_b = [&](int k0) {
-    const int n_real = a.ones_col >= 0 ? a.ones_col : a.N;
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       const int idx = tid + p * 256;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!a.b_kmajor) {
+      if (!B_KM) {
         const int row = idx >> 2, kq = idx & 3;
         const int gj = n0 + row, gk = k0 + kq * 4;
-        if (gj < a.N && gk < k_end) {
-          v = *reinterpret_cast<const float4*>(a.B + (size_t)gj * a.ldb + gk);
-          if (gk + 1 >= k_end) v.y = 0.f;
-          if (gk + 2 >= k_end) v.z = 0.f;
-          if (gk + 3 >= k_end) v.w = 0.f;
-        }
+        if (gj < a.N && gk < k_end) v = *reinterpret_cast<const float4*>(a.B + (size_t)gj * a.ldb + gk);
       } else {
         const int krow = idx / (BN / 4), jq = idx % (BN / 4);
         const int gk = k0 + krow, gj = n0 + jq * 4;
-        if (gk < k_end) {
-          if (gj < n_real) {
-            v = *reinterpret_cast<const float4*>(a.B + (size_t)gk * a.ldb + gj);
-            if (gj + 1 >= n_real) v.y = 0.f;
-            if (gj + 2 >= n_real) v.z = 0.f;
-            if (gj + 3 >= n_real) v.w = 0.f;
-          }
-          if (a.ones_col >= 0) {  // virtual all-ones column: bias gradient
-            if (gj == a.ones_col) v.x = 1.f;
-            if (gj + 1 == a.ones_col) v.y = 1.f;
-            if (gj + 2 == a.ones_col) v.z = 1.f;
-            if (gj + 3 == a.ones_col) v.w = 1.f;
-          }
-        }
+        if (gk < k_end && gj < a.N) v = *reinterpret_cast<const float4*>(a.B + (size_t)gk * a.ldb + gj);
       }
       rb[p] = v;
+    }
+  };
+  auto fix_tiles = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      const int idx = tid + p * 256;
+      const int lim = !A_KM ? k_end - (k0 + (idx & 3) * 4) : a.M - (m0 + (idx % (BM / 4)) * 4);
+      if (lim < 4) {
+        if (lim < 2) ra[p].y = 0.f;
+        if (lim < 3) ra[p].z = 0.f;
+        ra[p].w = 0.f;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+      const int idx = tid + p * 256;
+      const int lim = !B_KM ? k_end - (k0 + (idx & 3) * 4) : a.N - (n0 + (idx % (BN / 4)) * 4);
+      if (lim < 4) {
+        if (lim < 2) rb[p].y = 0.f;
+        if (lim < 3) rb[p].z = 0.f;
+        rb[p].w = 0.f;
+      }
     }
   };
   auto store_tiles = [&](int buf) {
@@ -154,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
       const int idx = tid + p * 256;
-      if (!a.a_kmajor) {
+      if (!A_KM) {
         const int row = idx >> 2, kq = idx & 3;
         Ab[(kq * 4 + 0) * LDAS + row] = ra[p].x;
         Ab[(kq * 4 + 1) * LDAS + row] = ra[p].y;
@@ -168,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       const int idx = tid + p * 256;
-      if (!a.b_kmajor) {
+      if (!B_KM) {
         const int row = idx >> 2, kq = idx & 3;
         Bb[(kq * 4 + 0) * LDBS + row] = rb[p].x;
         Bb[(kq * 4 + 1) * LDBS + row] = rb[p].y;
@@ -196,8 +191,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   if (nk > 0) {
     load_a(k_begin);
     load_b(k_begin);
+    fix_tiles(k_begin);
     store_tiles(0);
   }
+  // bias gradient (weight-gradient form): column sums of the A operand, taken from the LDS tile
+  float bias_acc = 0.f;
+  const bool do_bias = a.epi == kEpiSlab && a.ones_col >= 0 && n0 == 0 && tid < BM;
   __syncthreads();
   const int kh = lane >> 5, l31 = lane & 31;
   for (int t = 0; t < nk; ++t) {
@@ -220,12 +219,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         if (act_m1 && act_n1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
       }
     }
-    if (t + 1 < nk) store_tiles(buf ^ 1);
+    if (do_bias) {
+      const float* Ac = As + buf * BK * LDAS + tid;
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) bias_acc += Ac[kk * LDAS];
+    }
+    if (t + 1 < nk) {
+      fix_tiles(k_begin + (t + 1) * BK);
+      store_tiles(buf ^ 1);
+    }
     __syncthreads();
   }
 
   // ---- epilogue -------------------------------------------------------------
   float* Cout = a.C + (a.epi == kEpiSlab ? (size_t)blockIdx.z * a.slab_stride : 0);
+  if (do_bias && m0 + tid < a.M) Cout[(size_t)(m0 + tid) * a.ldc + a.ones_col] = bias_acc;
   const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const uint32_t thr = a.drop_p > 0.f ? static_cast<uint32_t>(fminf(a.drop_p * 4294967296.0f, 4294967040.0f)) : 0u;
   const uint32_t key = hash32(static_cast<uint32_t>(a.seed) ^ hash32(static_cast<uint32_t>(a.seed >> 32) + a.stream_id)) ^
@@ -278,22 +286,27 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0,
                 "gemm: operands must be 16-byte aligned");
   SUAVE_REQUIRE(a.a_kmajor ? a.lda >= a.M : a.lda >= a.K, "gemm: lda too small");
-  const int b_cols = a.ones_col >= 0 ? a.ones_col : a.N;
-  SUAVE_REQUIRE(a.b_kmajor ? a.ldb >= b_cols : a.ldb >= a.K, "gemm: ldb too small");
-  SUAVE_REQUIRE(a.ldc >= a.N, "gemm: ldc too small");
+  SUAVE_REQUIRE(a.b_kmajor ? a.ldb >= a.N : a.ldb >= a.K, "gemm: ldb too small");
+  SUAVE_REQUIRE(a.ldc >= a.N + (a.ones_col >= 0 ? 1 : 0), "gemm: ldc too small");
+  SUAVE_REQUIRE(a.ones_col < 0 || a.ones_col == a.N, "gemm: the bias column sits right after the N real columns");
   SUAVE_REQUIRE(a.epi != kEpiSlab || a.splits >= 1, "gemm: bad split count");
   const int splits = a.epi == kEpiSlab ? a.splits : 1;
   GemmArgs args = a;
   args.splits = splits;
   ProfScope prof_scope(kProfGemm, stream);
   const bool narrow = a.N <= 64;
-  if (narrow) {
-    const int tiles = ((a.M + 255) / 256) * ((a.N + 63) / 64);
-    hipLaunchKernelGGL((gemm_kernel<4, 1>), dim3(tiles, 1, splits), dim3(256), 0, stream, args);
-  } else {
-    const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    hipLaunchKernelGGL((gemm_kernel<2, 2>), dim3(tiles, 1, splits), dim3(256), 0, stream, args);
-  }
+  const int tiles = narrow ? ((a.M + 255) / 256) * ((a.N + 63) / 64) : ((a.M + 127) / 128) * ((a.N + 127) / 128);
+  const dim3 grid(tiles, 1, splits), block(256);
+#define SUAVE_GEMM_LAUNCH(AKM, BKM)                                                              \
+  do {                                                                                           \
+    if (narrow) hipLaunchKernelGGL((gemm_kernel<4, 1, AKM, BKM>), grid, block, 0, stream, args); \
+    else hipLaunchKernelGGL((gemm_kernel<2, 2, AKM, BKM>), grid, block, 0, stream, args);        \
+  } while (0)
+  if (!a.a_kmajor && !a.b_kmajor) SUAVE_GEMM_LAUNCH(false, false);
+  else if (!a.a_kmajor && a.b_kmajor) SUAVE_GEMM_LAUNCH(false, true);
+  else if (a.a_kmajor && a.b_kmajor) SUAVE_GEMM_LAUNCH(true, true);
+  else SUAVE_REQUIRE(false, "gemm: unsupported operand layout (A k-major with B k-contiguous)");
+#undef SUAVE_GEMM_LAUNCH
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }
