@@ -98,7 +98,7 @@ struct Carver {
 int tn_splits(const suave_plan* p, int n_out, int n_in1, int64_t rows) {
   const bool narrow = n_in1 <= 64;
   const int tiles = narrow ? ((n_out + 255) / 256) * ((n_in1 + 63) / 64) : ((n_out + 127) / 128) * ((n_in1 + 127) / 128);
-  int64_t s = (2 * (int64_t)p->n_cu + tiles - 1) / tiles;
+  int64_t s = ((int64_t)p->n_cu + tiles - 1) / tiles;
   s = std::min<int64_t>(s, std::max<int64_t>(1, rows / 256));
   return (int)std::max<int64_t>(1, std::min<int64_t>(s, 512));
 }
@@ -339,6 +339,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     a.catkl = w.catkl; a.gausskl = w.gausskl; a.gkl_logit = w.gkl_logit; a.gkl_mu = w.gkl_mu; a.gkl_lv = w.gkl_lv;
     a.prior_terms = w.prior_terms; a.head_slab = grad ? head_slab : nullptr; a.sums_slab = w.sums_slab;
     a.head_off = m.head_off; a.head_len = m.head_len; a.hw_max = p->hw_max;
+    a.xsrc = p->xsrc_dev; a.ldx = p->loss_ldx; a.ldm = p->loss_ldm;
     if (int rc = launch_loss(a, grad, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
   }
   const float* recon_final = w.recon_part;
@@ -563,8 +564,13 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
     hw_max = std::max(hw_max, m.head_off + m.head_len - hw_start);
     max_y = std::max(max_y, cur.y_len);
     p->max_chunk_y = max_y;
+    hw_max = round_up(hw_max, 4);
     p->hw_max = hw_max;
-    p->loss_lds_bytes = loss_lds_bytes(max_y | 1, K, hw_max, max_classes);
+    int max_cc = 1;
+    for (const ColChunk& cc : p->chunks_host) max_cc = std::max(max_cc, cc.col_end - cc.col_begin);
+    p->loss_ldx = max_cc | 1;
+    p->loss_ldm = (round_up(max_cc, 4) / 4 | 1) * 4;
+    p->loss_lds_bytes = loss_lds_bytes(max_y | 1, K, hw_max, max_classes, p->loss_ldx, p->loss_ldm);
     if (p->loss_lds_bytes > 150 * 1024)
       return fail("plan_create: schema needs more than 150 KB of LDS in the likelihood kernel (very wide categorical "
                   "columns need the GEMM head path, which this build does not have yet)");
@@ -593,6 +599,13 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
   if (hipMalloc(&p->chunks_dev, sizeof(ColChunk) * p->chunks_host.size()) != hipSuccess) return dfail("plan_create: hipMalloc failed");
   if (hipMalloc(&p->enc_src_dev, sizeof(int32_t) * p->ldI) != hipSuccess) return dfail("plan_create: hipMalloc failed");
   if (hipMalloc(&p->cls_off_dev, sizeof(int32_t) * m.n_cols) != hipSuccess) return dfail("plan_create: hipMalloc failed");
+  if (hipMalloc(&p->xsrc_dev, sizeof(int32_t) * m.n_cols) != hipSuccess) return dfail("plan_create: hipMalloc failed");
+  {
+    std::vector<int32_t> xsrc(m.n_cols);
+    for (int c = 0; c < m.n_cols; ++c) xsrc[c] = cols[c].x_index | (cols[c].type >= SUAVE_TYPE_CAT ? (1 << 30) : 0);
+    if (hipMemcpy(p->xsrc_dev, xsrc.data(), sizeof(int32_t) * m.n_cols, hipMemcpyHostToDevice) != hipSuccess)
+      return dfail("plan_create: hipMemcpy failed");
+  }
   {
     std::vector<int32_t> cls_off(m.n_cols, 0);
     int acc = 0;
@@ -619,6 +632,7 @@ extern "C" int suave_plan_destroy(suave_plan* p) {
   if (p->chunks_dev) (void)hipFree(p->chunks_dev);
   if (p->enc_src_dev) (void)hipFree(p->enc_src_dev);
   if (p->cls_off_dev) (void)hipFree(p->cls_off_dev);
+  if (p->xsrc_dev) (void)hipFree(p->xsrc_dev);
   delete p;
   return 0;
 }

@@ -55,6 +55,8 @@ struct suave_plan {
   int n_cu = 256;
   int32_t* enc_src_dev = nullptr;
   int32_t* cls_off_dev = nullptr;
+  int32_t* xsrc_dev = nullptr;
+  int loss_ldx = 1, loss_ldm = 4;
   // padded leading dimensions (floats)
   int ldI, ldE, ldK, ldD, ldY;
   int ldH[SUAVE_MAX_HIDDEN];
@@ -123,7 +125,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }
+// softplus with torch's threshold; log1p(t) by its series below t = 0.02 (relative error < 2e-6)
+__device__ __forceinline__ float softplus_f(float x) {
+  if (x > 20.0f) return x;
+  const float t = __expf(x);
+  return t < 0.02f ? t * (1.0f - t * (0.5f - t * (1.0f / 3.0f))) : __logf(1.0f + t);
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float softplus_grad_f(float x) { return x > 20.0f ? 1.0f : sigmoid_f(x); }
 

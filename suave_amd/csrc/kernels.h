@@ -32,6 +32,8 @@ struct LossArgs {
   float* head_slab;    // [gridDim.x, head_len]
   double* sums_slab;   // [gridDim.x * gridDim.y, 4]
   int head_off, head_len, hw_max;
+  const int32_t* xsrc;  // [n_cols] x_index | (1 << 30 for cat / ordinal)
+  int ldx, ldm;         // LDS row strides of the staged cells (ints) and masks (bytes)
 };
 
 struct LatentFwdArgs {
@@ -87,7 +89,7 @@ struct ReduceArgs {
   double n_rows;
 };
 
-size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes);
+size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes, int ldx, int ldm);
 int loss_set_lds_limit(size_t lds_bytes);
 int launch_loss(const LossArgs& a, bool grad, int kmax, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s);
 int launch_expand(const suave_plan* p, const int32_t* enc_src_dev, const suave_batch_t& b, float* x, hipStream_t s);

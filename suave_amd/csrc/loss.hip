@@ -25,6 +25,8 @@ namespace suave {
 
 namespace {
 
+constexpr int kMissing = 0x7FC0DEAD;  // cell sentinel: masked / unobserved
+
 // Sum over the 64 lanes with DPP row operations; result is wave-uniform.
 __device__ __forceinline__ float wave_sum_dpp(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
@@ -36,8 +38,17 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Fire-and-forget LDS add (ds_add_f32, no return value to wait for).  Every index is only ever
+// touched by one wavefront, in program order, so the sum order is fixed (deterministic).
 __device__ __forceinline__ void acc_add(float* hw, int idx, float v, int lane) {
-  if (lane == 0) hw[idx] += v;
+  if (lane == 0) (void)__hip_atomic_fetch_add(hw + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Per-lane LDS add: lane r adds its value at the slot of its own component.  Lanes that share a
+// component collide on one address and are serialised by the LDS unit in a fixed order, and no other
+// wavefront ever touches these slots, so the result is reproducible run to run.
+__device__ __forceinline__ void acc_add_lanes(float* slot, float v) {
+  (void)__hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 }  // namespace
@@ -47,14 +58,17 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int K = a.K;
   float* ytile = lds;                         // [64][ldy]
-  float* ds_w = ytile + 64 * a.ldy;           // [4][64][K]
-  float* recon_w = ds_w + 4 * 64 * K;         // [4][64]
-  float* hw_acc = recon_w + 4 * 64;           // [hw_max]
+  float* hw_acc = ytile + 64 * a.ldy;         // [hw_max]
   float* gs = hw_acc + a.hw_max;              // [4][max_classes][64]
   int* k_s = reinterpret_cast<int*>(gs + 4 * a.max_classes * 64);  // [64]
   float* up_s = reinterpret_cast<float*>(k_s + 64);                // [64]
   float* red_s = up_s + 64;                   // [16]
-
+  long long* trow_s = reinterpret_cast<long long*>(red_s + 16);    // [64] table row of each tile row
+  float* wsm = reinterpret_cast<float*>(trow_s + 64);              // [hw_max] this chunk's head weights
+  int* xsrc_s = reinterpret_cast<int*>(wsm + a.hw_max);            // [ldx] cell source of each chunk column
+  int* xs = xsrc_s + a.ldx;                   // [64][ldx] cell: float bits / code, kMissing when masked
+  float* ds_w = reinterpret_cast<float*>(xs); // [4][64][K]  (aliases xs: used after the column phase)
+  float* recon_w = ds_w + 4 * 64 * K;         // [4][64]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,8 +79,16 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
   const int yq = (ch.y_len + 3) / 4;  // float4 per row of the chunk (ldY % 4 == 0, y_begin % 4 handled below)
   double sum_recon = 0.0, sum_cat = 0.0, sum_gauss = 0.0;
 
-  if (GRAD)
-    for (int i = tid; i < a.hw_max; i += 256) hw_acc[i] = 0.f;
+  const int ncc = ch.col_end - ch.col_begin;
+  {
+    const int hw_next = (chunk_id + 1 < (int)gridDim.y) ? a.cols[a.chunks[chunk_id + 1].col_begin].w_off
+                                                        : a.head_off + a.head_len;
+    const int hw_len = min(a.hw_max, hw_next - hw_begin);
+    for (int i = tid; i < hw_len; i += 256) wsm[i] = a.params[hw_begin + i];
+    for (int i = tid; i < ncc; i += 256) xsrc_s[i] = a.xsrc[ch.col_begin + i];
+    if (GRAD)
+      for (int i = tid; i < a.hw_max; i += 256) hw_acc[i] = 0.f;
+  }
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int r0 = tile * 64;
@@ -77,29 +99,65 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
       const int ybase = ch.y_begin & ~3;              // aligned start column
       const int lead = ch.y_begin - ybase;
       const int nq = (lead + ch.y_len + 3) / 4;
-      for (int idx = tid; idx < nrows * nq; idx += 256) {
-        const int lr = idx / nq, q = idx % nq;
-        const float4 v = *reinterpret_cast<const float4*>(a.y + (size_t)(r0 + lr) * a.ldY + ybase + q * 4);
-        const int c0 = q * 4 - lead;
+      for (int lr = wave; lr < 64; lr += 4) {
         float* dst = ytile + lr * a.ldy;
-        if (c0 >= 0 && c0 < ch.y_len) dst[c0] = v.x;
-        if (c0 + 1 >= 0 && c0 + 1 < ch.y_len) dst[c0 + 1] = v.y;
-        if (c0 + 2 >= 0 && c0 + 2 < ch.y_len) dst[c0 + 2] = v.z;
-        if (c0 + 3 >= 0 && c0 + 3 < ch.y_len) dst[c0 + 3] = v.w;
+        if (lr < nrows) {
+          const float* src = a.y + (size_t)(r0 + lr) * a.ldY + ybase;
+          for (int q = lane; q < nq; q += 64) {
+            const float4 v = *reinterpret_cast<const float4*>(src + q * 4);
+            const int c0 = q * 4 - lead;
+            if (c0 >= 0 && c0 < ch.y_len) dst[c0] = v.x;
+            if (c0 + 1 >= 0 && c0 + 1 < ch.y_len) dst[c0 + 1] = v.y;
+            if (c0 + 2 >= 0 && c0 + 2 < ch.y_len) dst[c0 + 2] = v.z;
+            if (c0 + 3 >= 0 && c0 + 3 < ch.y_len) dst[c0 + 3] = v.w;
+          }
+        } else {  // rows past the table: finite zeros
+          for (int cc = lane; cc < ch.y_len; cc += 64) dst[cc] = 0.f;
+        }
       }
       (void)yq;
-      for (int idx = tid; idx < (64 - nrows) * ch.y_len; idx += 256)  // rows past the table: finite zeros
-        ytile[(nrows + idx / ch.y_len) * a.ldy + idx % ch.y_len] = 0.f;
       if (tid < 64) {
         const int r = r0 + tid;
         int k = 0;
         float up = 0.f;
+        long long trow = 0;
         if (tid < nrows) {
           k = a.kidx ? a.kidx[r] : (r % a.vdiv);
           up = a.c_up * (a.row_weight ? a.row_weight[r] : 1.0f);
+          const int64_t drow = (int64_t)(r / a.vdiv);
+          trow = a.batch.row_index ? (long long)a.batch.row_index[drow] : (long long)(a.batch.row_begin + drow);
         }
         k_s[tid] = k;
         up_s[tid] = up;
+        trow_s[tid] = trow;
+      }
+    }
+    __syncthreads();
+    // stage the tile's cells (mask folded in): wave = row, lane = column, 4 rows of loads in flight
+    for (int j0 = 0; j0 < ncc; j0 += 64) {
+      const int cc = j0 + lane;
+      const bool cok = cc < ncc;
+      const int src = cok ? xsrc_s[cc] : 0;
+      for (int lr0 = wave; lr0 < nrows; lr0 += 16) {
+        int v[4];
+        unsigned char mk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int lr = lr0 + 4 * u;
+          v[u] = 0;
+          mk[u] = 0;
+          if (cok && lr < nrows) {
+            const long long trow = trow_s[lr];
+            if (src & (1 << 30)) v[u] = (int)a.batch.codes[trow * a.batch.ld_disc + (src & 0xFFFFFF)];
+            else v[u] = __float_as_int(a.batch.xnum[trow * a.batch.ld_num + src]);
+            mk[u] = a.batch.mask[trow * a.batch.ld_mask + ch.col_begin + cc];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int lr = lr0 + 4 * u;
+          if (cok && lr < nrows) xs[lr * a.ldx + cc] = mk[u] ? v[u] : kMissing;
+        }
       }
     }
     __syncthreads();
@@ -107,11 +165,8 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
     // ---- column phase: lane = row, wave-uniform column ----
     const bool valid = lane < nrows;
     const int r = r0 + (valid ? lane : 0);
-    const int64_t drow_b = (int64_t)(r / a.vdiv);
-    const int64_t tr = a.batch.row_index ? (int64_t)a.batch.row_index[drow_b] : a.batch.row_begin + drow_b;
-    const float* xn = a.batch.xnum + tr * a.batch.ld_num;
-    const int16_t* cd = a.batch.codes + tr * a.batch.ld_disc;
-    const uint8_t* mk = a.batch.mask + tr * a.batch.ld_mask;
+    (void)r;
+    const int* xrow = xs + lane * a.ldx - ch.col_begin;
     const int k = k_s[lane];
     const float up = up_s[lane];
     float recon = 0.f;
@@ -125,19 +180,24 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
 
     for (int c = ch.col_begin + wave; c < ch.col_end; c += 4) {
       const suave_col_t col = a.cols[c];
-      const bool obs = valid && mk[c] != 0;
+      const int cell = valid ? xrow[c] : kMissing;
+      const bool obs = cell != kMissing;
       const float u = obs ? up : 0.f;
       float* yb = yrow + (col.y_off - ch.y_begin);
       const int yd = col.y_dim;
-      const float* w = a.params + col.w_off;
+      // head weights come from the block's LDS copy: a dependent scalar load from global per weight
+      // (s_load + s_waitcnt) costs hundreds of cycles each and serialises the column loop
+      const float* wl = wsm + (col.w_off - hw_begin);
+      const float* w = wl;
       float* hw = hw_acc + (col.w_off - hw_begin);
       if (col.type == SUAVE_TYPE_REAL || col.type == SUAVE_TYPE_POS) {
-        const float* wv = a.params + col.w2_off;
+        const float* wvl = wsm + (col.w2_off - hw_begin);
+        const float* wv = wvl;
         float* hwv = hw_acc + (col.w2_off - hw_begin);
-        float am = w[yd + k];
+        float am = wl[yd + k];
         for (int i = 0; i < yd; ++i) am += w[i] * yb[i];
-        const float bv = wv[k];
-        const float x = xn[col.x_index];
+        const float bv = wvl[k];
+        const float x = obs ? __int_as_float(cell) : 0.f;
         const float v = softplus_f(bv) + kEps;
         const float mean = am * col.scale + col.shift;
         const float vs = v * (col.scale * col.scale);
@@ -162,17 +222,15 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
           for (int j = 0; j < KMAX; ++j) {
             if (j < K) {
               ds[j] += ga * w[yd + j] + gb * wv[j];
-              const float ta = wave_sum_dpp(k == j ? ga : 0.f);
-              const float tb = wave_sum_dpp(k == j ? gb : 0.f);
-              acc_add(hw, yd + j, ta, lane);
-              acc_add(hwv, j, tb, lane);
             }
           }
+          acc_add_lanes(hw + yd + k, ga);
+          acc_add_lanes(hwv + k, gb);
         }
       } else if (col.type == SUAVE_TYPE_COUNT) {
-        float rho = w[yd + k];
+        float rho = wl[yd + k];
         for (int i = 0; i < yd; ++i) rho += w[i] * yb[i];
-        const float x = xn[col.x_index];
+        const float x = obs ? __int_as_float(cell) : 0.f;
         const float rate = softplus_f(rho) + kEps;
         const float cnt = fmaxf(__expf(x) - col.shift, 0.f);
         const float rc = fmaxf(rate, kEps);
@@ -189,20 +247,19 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
           for (int j = 0; j < KMAX; ++j) {
             if (j < K) {
               ds[j] += gr * w[yd + j];
-              const float t = wave_sum_dpp(k == j ? gr : 0.f);
-              acc_add(hw, yd + j, t, lane);
             }
           }
+          acc_add_lanes(hw + yd + k, gr);
         }
       } else if (col.type == SUAVE_TYPE_CAT) {
         const int C = col.n_classes;
         const int ldw = yd + K;
-        const int code = valid ? (int)cd[col.x_index] : -1;
+        const int code = obs ? cell : -1;
         // sweep 1: logits, online log-sum-exp (logit 0 is pinned to 0)
         float mx = 0.f, se = 1.f, lcode = 0.f;
         for (int cl = 1; cl < C; ++cl) {
           const float* wr = w + (cl - 1) * ldw;
-          float L = wr[yd + k];
+          float L = wl[(cl - 1) * ldw + yd + k];
           for (int i = 0; i < yd; ++i) L += wr[i] * yb[i];
           gsw[cl * 64] = L;
           if (L > mx) { se = se * __expf(mx - L) + 1.0f; mx = L; }
@@ -229,10 +286,9 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
             for (int j = 0; j < KMAX; ++j) {
               if (j < K) {
                 ds[j] += g * wr[yd + j];
-                const float t = wave_sum_dpp(k == j ? g : 0.f);
-                acc_add(hr, yd + j, t, lane);
               }
             }
+            acc_add_lanes(hr + yd + k, g);
           }
           // sweep 3: dY
           for (int i = 0; i < yd; ++i) {
@@ -243,15 +299,16 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
         }
       } else {  // ordinal: cumulative link
         const int C = col.n_classes;
-        const float* wm = a.params + col.w2_off;  // mean_layer [yd + K]
+        const float* wml = wsm + (col.w2_off - hw_begin);  // mean_layer [yd + K]
+        const float* wm = wml;
         float* hwm = hw_acc + (col.w2_off - hw_begin);
-        const int code = valid ? (int)cd[col.x_index] : -1;
+        const int code = obs ? cell : -1;
         const int t = max(code, 0);  // target = max(round(sum thermo) - 1, 0)
-        float mo = wm[yd + k];
+        float mo = wml[yd + k];
         for (int i = 0; i < yd; ++i) mo += wm[i] * yb[i];
         float thr = 0.f, sg_t = 1.0f, sg_tm1 = 0.f;
         for (int j = 0; j < C - 1; ++j) {
-          thr += softplus_f(w[j * K + k]) + kEps;
+          thr += softplus_f(wl[j * K + k]) + kEps;
           const float sgj = sigmoid_f(thr - mo);
           if (j == t) sg_t = sgj;
           if (j == t - 1) sg_tm1 = sgj;
@@ -273,27 +330,26 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
           for (int j = 0; j < KMAX; ++j) {
             if (j < K) {
               ds[j] += gmean * wm[yd + j];
-              const float s = wave_sum_dpp(k == j ? gmean : 0.f);
-              acc_add(hwm, yd + j, s, lane);
             }
           }
+          acc_add_lanes(hwm + yd + k, gmean);
           for (int jj = 0; jj < C - 1; ++jj) {
             const float dsp = (jj <= t - 1 ? du_tm1 : 0.f) + (jj <= t ? du_t : 0.f);
-            const float gpart = dsp * softplus_grad_f(w[jj * K + k]);
+            const float gpart = dsp * softplus_grad_f(wl[jj * K + k]);
 #pragma unroll
             for (int j = 0; j < KMAX; ++j) {
               if (j < K) {
                 ds[j] += gpart * w[jj * K + j];
-                const float s = wave_sum_dpp(k == j ? gpart : 0.f);
-                acc_add(hw, jj * K + j, s, lane);
               }
             }
+            acc_add_lanes(hw + jj * K + k, gpart);
           }
         }
       }
     }
 
-    // ---- cross-wave reduction of the per-row terms ----
+    // ---- cross-wave reduction of the per-row terms (ds_w / recon_w alias the cell tile) ----
+    __syncthreads();
     recon_w[wave * 64 + lane] = recon;
     if (GRAD) {
 #pragma unroll
@@ -308,18 +364,19 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
       if (tid == 0) sum_recon += (double)tot;
     }
     if (GRAD && a.ds_part) {
-      for (int idx = tid; idx < nrows * K; idx += 256) {
-        const int lr = idx / K, j = idx % K;
-        const float v = ds_w[(0 * 64 + lr) * K + j] + ds_w[(1 * 64 + lr) * K + j] + ds_w[(2 * 64 + lr) * K + j] +
-                        ds_w[(3 * 64 + lr) * K + j];
-        a.ds_part[((size_t)chunk_id * a.n_rows + r0 + lr) * a.ldK + j] = v;
+      if (tid < nrows) {
+        float* dst = a.ds_part + ((size_t)chunk_id * a.n_rows + r0 + tid) * a.ldK;
+        for (int j = 0; j < K; ++j)
+          dst[j] = ds_w[(0 * 64 + tid) * K + j] + ds_w[(1 * 64 + tid) * K + j] + ds_w[(2 * 64 + tid) * K + j] +
+                   ds_w[(3 * 64 + tid) * K + j];
       }
     }
     // ---- write dY back (coalesced) ----
     if (GRAD) {
-      for (int idx = tid; idx < nrows * ch.y_len; idx += 256) {
-        const int lr = idx / ch.y_len, cc = idx % ch.y_len;
-        a.y[(size_t)(r0 + lr) * a.ldY + ch.y_begin + cc] = ytile[lr * a.ldy + cc];
+      for (int lr = wave; lr < nrows; lr += 4) {
+        float* dst = a.y + (size_t)(r0 + lr) * a.ldY + ch.y_begin;
+        const float* src = ytile + lr * a.ldy;
+        for (int cc = lane; cc < ch.y_len; cc += 64) dst[cc] = src[cc];
       }
     }
 
@@ -407,8 +464,10 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
   }
 }
 
-size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes) {
-  size_t floats = (size_t)64 * ldy + (size_t)4 * 64 * K + 4 * 64 + hw_max + (size_t)4 * max_classes * 64 + 64 + 64 + 16;
+size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes, int ldx, int ldm) {
+  (void)ldm;
+  const size_t cells = std::max((size_t)64 * ldx, (size_t)4 * 64 * K + 4 * 64);
+  size_t floats = (size_t)64 * ldy + 2 * (size_t)hw_max + (size_t)4 * max_classes * 64 + 64 + 64 + 16 + 2 * 64 + ldx + cells;
   return floats * sizeof(float);
 }
 

@@ -24,8 +24,17 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int i = (int)(e / sg.cols), j = (int)(e % sg.cols);
     const float* src = a.slab + sg.src_off + (int64_t)i * sg.src_ld + j;
+    // fixed summation order; 16 independent loads in flight per thread
     float t = 0.f;
-    for (int s = 0; s < sg.n_slabs; ++s) t += src[(int64_t)s * sg.slab_stride];
+    int s = 0;
+    for (; s + 16 <= sg.n_slabs; s += 16) {
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = src[(int64_t)(s + q) * sg.slab_stride];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += v[q];
+    }
+    for (; s < sg.n_slabs; ++s) t += src[(int64_t)s * sg.slab_stride];
     a.dst[sg.dst_off + (int64_t)i * sg.dst_si + (int64_t)j * sg.dst_sj] = t;
   }
 }
