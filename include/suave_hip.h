@@ -207,12 +207,15 @@ int suave_conditional_latents(const suave_plan* plan, const int64_t* class_offse
  * with component [n].  Output, columnar in the packed-table layout:
  * out_num float32 [n, ld_num] (real, pos, count as float), out_codes int16
  * [n, ld_disc].  noise_normal [n, n_cols], noise_uniform [n, n_cols],
- * noise_exp [n, total classes] inject draws (any may be NULL). */
+ * noise_exp [n, total classes] inject draws (any may be NULL).  y_full_out
+ * [n, total_y] optionally receives decoder.y_projection's output (the input of
+ * the heads, decoder.py:344) -- NULL to skip. */
 int suave_decode_sample(const suave_plan* plan, const float* params, const float* z, const float* s,
                         const int32_t* component, int64_t n, const float* noise_normal,
                         const float* noise_uniform, const float* noise_exp, uint64_t seed,
                         int64_t row_offset, void* workspace, size_t workspace_bytes, void* stream,
-                        float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc);
+                        float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc,
+                        float* y_full_out);
 
 /* Measurement aid (no counterpart in the reference): when enabled, every kernel
  * launch of the library is bracketed by HIP events on its stream;

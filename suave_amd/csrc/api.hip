@@ -694,7 +694,8 @@ extern "C" int suave_decode_sample(const suave_plan* p, const float* params, con
                                    const int32_t* component, int64_t n, const float* noise_normal,
                                    const float* noise_uniform, const float* noise_exp, uint64_t seed,
                                    int64_t row_offset, void* workspace, size_t workspace_bytes, void* stream,
-                                   float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc) {
+                                   float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc,
+                                   float* y_full_out) {
   SUAVE_REQUIRE(p && params && z, "decode_sample: null argument");
   SUAVE_REQUIRE(s_dense != nullptr || component != nullptr, "decode_sample: need dense assignments or component indices");
   const suave_model_t& m = p->model;
@@ -721,6 +722,9 @@ extern "C" int suave_decode_sample(const suave_plan* p, const float* params, con
   }
   if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, &dummy, nullptr, 0, 1, st))
     return rc;
+  if (y_full_out)
+    SUAVE_CHECK_HIP(hipMemcpy2DAsync(y_full_out, sizeof(float) * m.total_y, w.y, sizeof(float) * p->ldY,
+                                     sizeof(float) * m.total_y, B, hipMemcpyDeviceToDevice, st));
   return launch_sample_heads(p, p->cls_off_dev, params, w.y, s_dense, component, n, noise_normal, noise_uniform,
                              noise_exp, seed, row_offset, out_num, ld_num, out_codes, ld_disc, st);
 }

@@ -10,7 +10,10 @@ pids=()
 for f in gemm loss latent optim sample api; do
   [ -f $f.hip ] || continue
   if [ ! -f $OBJ/$f.o ] || [ $f.hip -nt $OBJ/$f.o ] || [ common.h -nt $OBJ/$f.o ] || [ kernels.h -nt $OBJ/$f.o ] || [ detmath.h -nt $OBJ/$f.o ] || [ ../../include/suave_hip.h -nt $OBJ/$f.o ]; then
-    hipcc $FLAGS -c $f.hip -o $OBJ/$f.o &
+    extra=""
+    # deterministic binary32 paths (detmath.h): no FMA contraction, correctly rounded sqrt / divide
+    if [ $f = sample ] || [ $f = latent ]; then extra="-ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt"; fi
+    hipcc $FLAGS $extra -c $f.hip -o $OBJ/$f.o &
     pids+=($!)
   fi
 done

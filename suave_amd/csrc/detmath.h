@@ -10,10 +10,17 @@
 
 namespace detm {
 
-__device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ float sub(float a, float b) { return __fsub_rn(a, b); }
-__device__ __forceinline__ float dvd(float a, float b) { return __fdiv_rn(a, b); }
+// NOTE: HIP's __fmul_rn / __fadd_rn are plain operators and are contracted into FMAs under the
+// default -ffp-contract=fast-honor-pragmas, and __fsqrt_rn is the 1-ulp v_sqrt_f32.  Contraction is
+// therefore switched off for everything in this header, translation units that use it are built
+// with -ffp-contract=off (build.sh), and sqrt / divide go through the correctly rounded default
+// lowering of sqrtf() and operator/.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float add(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float dvd(float a, float b) { return a / b; }
+__device__ __forceinline__ float sqrt_rn(float a) { return sqrtf(a); }
 
 __device__ __forceinline__ float exp(float x) {
   const float LN2_HI = 6.9313812256e-01f, LN2_LO = 9.0580006145e-06f, INV_LN2 = 1.4426950216e+00f;

@@ -40,7 +40,7 @@ __device__ float poisson_from_noise(float rate, float u, float n) {
     k = fi;
     go = (u > cdf) && ((p > 1e-30f) || (fi <= r));
   }
-  float big = floorf(detm::add(detm::add(rate, detm::mul(__fsqrt_rn(rate), n)), 0.5f));
+  float big = floorf(detm::add(detm::add(rate, detm::mul(detm::sqrt_rn(rate), n)), 0.5f));
   big = fmaxf(big, 0.f);
   return small ? k : big;
 }
@@ -134,12 +134,12 @@ __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
           const float bv = dot(a.params + col.w2_off, yb, 0);
           const float v = detm::add(detm::softplus(bv), kEps);
           if (col.type == SUAVE_TYPE_REAL) {  // decoder.py:90-91
-            const float sd = __fsqrt_rn(fmaxf(v, kEps));
+            const float sd = detm::sqrt_rn(fmaxf(v, kEps));
             val = detm::add(detm::mul(detm::add(am, detm::mul(nrm, sd)), col.scale), col.shift);
           } else {  // decoder.py:139
             const float mean = detm::add(detm::mul(am, col.scale), col.shift);
             const float vs = detm::mul(v, detm::mul(col.scale, col.scale));
-            const float sd = __fsqrt_rn(fmaxf(vs, kEps));
+            const float sd = detm::sqrt_rn(fmaxf(vs, kEps));
             val = detm::sub(detm::exp(detm::add(mean, detm::mul(nrm, sd))), 1.0f);
           }
         }

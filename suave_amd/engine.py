@@ -225,7 +225,7 @@ class Engine:
 
     def decode_sample(self, z: torch.Tensor, *, component: Optional[torch.Tensor] = None,
                       assignments: Optional[torch.Tensor] = None, noise_normal=None, noise_uniform=None,
-                      noise_exp=None, seed: int = 0, row_offset: int = 0):
+                      noise_exp=None, seed: int = 0, row_offset: int = 0, want_y: bool = False):
         n = int(z.shape[0])
         L = self.layout
         ws = self.workspace(n)
@@ -233,10 +233,13 @@ class Engine:
         nbytes = ws.numel() - (base - ws.data_ptr())
         out_num = torch.empty((n, max(L.n_num, 1)), dtype=torch.float32, device=self.device)
         out_codes = torch.empty((n, max(L.n_disc, 1)), dtype=torch.int16, device=self.device)
+        y_out = torch.empty((n, L.total_y), dtype=torch.float32, device=self.device) if want_y else None
         rc = self.lib.suave_decode_sample(self._plan, self.params.data_ptr(), z.data_ptr(), _ptr(assignments),
                                           _ptr(component), n, _ptr(noise_normal), _ptr(noise_uniform),
                                           _ptr(noise_exp), int(seed), int(row_offset), base, nbytes, self._stream(),
                                           out_num.data_ptr(), int(out_num.shape[1]), out_codes.data_ptr(),
-                                          int(out_codes.shape[1]))
+                                          int(out_codes.shape[1]), _ptr(y_out))
         _lib.check(rc, "suave_decode_sample")
+        if want_y:
+            return out_num[:, : L.n_num], out_codes[:, : L.n_disc], y_out
         return out_num[:, : L.n_num], out_codes[:, : L.n_disc]

@@ -68,7 +68,7 @@ def load():
     lib.suave_encode.argtypes = [vp, vp, C.POINTER(BatchT), f32, vp, sz, vp, vp, vp, vp, vp]
     lib.suave_prior_latents.argtypes = [vp, vp, vp, vp, vp, u64, i64, i64, vp, vp, vp]
     lib.suave_conditional_latents.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, i64, i64, vp, vp, vp]
-    lib.suave_decode_sample.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, u64, i64, vp, sz, vp, vp, i32, vp, i32]
+    lib.suave_decode_sample.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, u64, i64, vp, sz, vp, vp, i32, vp, i32, vp]
     lib.suave_profile_enable.argtypes = [C.c_int]
     lib.suave_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i64), i32]
     for name in EXPORTS:

@@ -1,0 +1,190 @@
+"""GPU parity of the generative decode (C-ABI) against the reference's golden vectors and the CPU oracle.
+
+Sampled categorical / ordinal / count values and mixture components must be bit-exact on identical
+inputs and injected noise; real / positive samples within 1e-4 (they are bit-exact too, given y_full).
+"""
+
+import numpy as np
+import pytest
+
+from oracle import sampling_oracle as sorc
+from oracle import suave_oracle as orc
+from tests.helpers import fixture_model, layout_from_columns, load_golden, rel_err, s64_columns
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _engine(om, P):
+    from suave_amd.engine import Engine
+
+    eng = Engine(layout_from_columns(om.columns, K=om.K, D=om.D, hidden=om.hidden, dropout=om.dropout,
+                                     behaviour=om.behaviour), "cuda:0")
+    eng.load_state(P)
+    return eng
+
+
+def _pack_noise(om, layout, per_col, B):
+    nn = np.zeros((B, len(om.columns)), np.float32)
+    nu = np.zeros((B, len(om.columns)), np.float32)
+    ne = np.ones((B, max(layout.total_classes, 1)), np.float32)
+    for j, c in enumerate(om.columns):
+        nz = per_col[c.name]
+        if c.type in ("real", "pos", "count"):
+            nn[:, j] = np.asarray(nz["normal"]).reshape(-1)
+        if c.type == "count":
+            nu[:, j] = np.asarray(nz["uniform"]).reshape(-1)
+        if c.type in ("cat", "ordinal"):
+            off = layout.class_offsets[c.name]
+            ne[:, off:off + c.n_classes] = nz["exp"]
+    return nn, nu, ne
+
+
+def _unpack(om, layout, onum, ocodes):
+    out = {}
+    i_num = i_disc = 0
+    for c in om.columns:
+        if c.type in ("real", "pos", "count"):
+            out[c.name] = onum[:, i_num]
+            i_num += 1
+        else:
+            out[c.name] = ocodes[:, i_disc].astype(np.int64)
+            i_disc += 1
+    return out
+
+
+@pytest.mark.parametrize("name", ["decode_mixed12", "decode_ydim"])
+def test_golden_decode(name):
+    import torch
+
+    fx = load_golden(name)
+    om, P, meta = fixture_model(fx)
+    eng = _engine(om, P)
+    B = meta["B"]
+    per_col = {c.name: {k.split("/")[-1]: v for k, v in fx.items() if k.startswith(f"noise/{c.name}/")} for c in om.columns}
+    nn, nu, ne = _pack_noise(om, eng.layout, per_col, B)
+    dev = eng.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    onum, ocodes = eng.decode_sample(t(fx["z"]), component=t(fx["k"].astype(np.int32)), noise_normal=t(nn),
+                                     noise_uniform=t(nu), noise_exp=t(ne))
+    got = _unpack(om, eng.layout, onum.cpu().numpy(), ocodes.cpu().numpy())
+    for c in om.columns:
+        ref = fx[f"out/{c.name}/frame"]
+        if c.type in ("real", "pos"):
+            assert rel_err(got[c.name], ref) < TOL, c.name
+        else:  # reference's sampled values, bit for bit
+            assert np.array_equal(np.rint(got[c.name]).astype(np.int64), ref.astype(np.int64)), c.name
+
+
+@pytest.mark.parametrize("dense_s", [False, True])
+def test_s64_decode_bit_exact_given_y(dense_s):
+    import torch
+
+    cols = s64_columns(64, real_variant="scaled")
+    om = orc.OracleModel(cols, n_components=10, latent_dim=32, hidden=(256, 128))
+    P = om.init_params(seed=7)
+    rng = np.random.default_rng(8)
+    for k in P:
+        if ".heads." in k:
+            P[k] = (0.5 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    eng = _engine(om, P)
+    n = 5000
+    z = rng.standard_normal((n, 32)).astype(np.float32)
+    comp = rng.integers(0, 10, n).astype(np.int32)
+    if dense_s:
+        s = rng.dirichlet(np.ones(10), n).astype(np.float32)
+    else:
+        s = np.eye(10, dtype=np.float32)[comp]
+    per_col = {}
+    for c in cols:
+        if c.type in ("real", "pos"):
+            per_col[c.name] = {"normal": rng.standard_normal(n).astype(np.float32)}
+        elif c.type == "count":
+            per_col[c.name] = {"normal": rng.standard_normal(n).astype(np.float32), "uniform": rng.random(n).astype(np.float32)}
+        else:
+            per_col[c.name] = {"exp": rng.exponential(size=(n, c.n_classes)).astype(np.float32)}
+    nn, nu, ne = _pack_noise(om, eng.layout, per_col, n)
+    dev = eng.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    onum, ocodes, y = eng.decode_sample(t(z), component=None if dense_s else t(comp), assignments=t(s) if dense_s else None,
+                                        noise_normal=t(nn), noise_uniform=t(nu), noise_exp=t(ne), want_y=True)
+    y = y.cpu().numpy()
+    y_ref, _ = orc.decoder_trunk_forward(om, P, z)
+    assert rel_err(y, y_ref) < TOL
+    ref = sorc.sample_heads(om, P, y, s, per_col)  # the oracle's maps on the GPU's own y_full
+    got = _unpack(om, eng.layout, onum.cpu().numpy(), ocodes.cpu().numpy())
+    for c in cols:
+        if c.type in ("real", "pos"):
+            assert np.array_equal(got[c.name], ref[c.name]), c.name  # same binary32 operation sequence
+        else:
+            assert np.array_equal(np.rint(got[c.name]).astype(np.int64), ref[c.name]), c.name
+
+
+def test_prior_and_conditional_latents():
+    import torch
+
+    cols = s64_columns(10)
+    K, D = 5, 6
+    om = orc.OracleModel(cols, n_components=K, latent_dim=D, hidden=(16,))
+    P = om.init_params(seed=2)
+    eng = _engine(om, P)
+    dev = eng.device
+    rng = np.random.default_rng(3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    n = 3000
+    u = rng.random(n).astype(np.float32)
+    eps = rng.standard_normal((n, D)).astype(np.float32)
+    cdf = sorc.prior_cdf(P["prior.logits"])
+    z, comp = eng.prior_latents(n, t(cdf), u=t(u), eps=t(eps))
+    z_ref, k_ref = sorc.prior_latents(P["prior.logits"], P["prior.mu"], P["prior.logvar"], u, eps)
+    assert np.array_equal(comp.cpu().numpy().astype(np.int64), k_ref)
+    assert rel_err(z.cpu().numpy(), z_ref) < 1e-5
+    # conditional: cached training posteriors of N rows, labels over 3 classes
+    N = 400
+    train_probs = rng.dirichlet(np.ones(K), N).astype(np.float32)
+    train_mu = rng.standard_normal((N, K, D)).astype(np.float32)
+    train_lv = (0.3 * rng.standard_normal((N, K, D))).astype(np.float32)
+    targets = rng.integers(0, 3, N)
+    class_rows = np.concatenate([np.flatnonzero(targets == c) for c in range(3)]).astype(np.int64)
+    class_off = np.concatenate([[0], np.cumsum([(targets == c).sum() for c in range(3)])]).astype(np.int64)
+    labels = rng.integers(0, 3, n).astype(np.int32)
+    u_row = rng.random(n).astype(np.float32)
+    e_comp = rng.exponential(size=(n, K)).astype(np.float32)
+    z, comp = eng.conditional_latents(t(labels), t(class_off), t(class_rows), t(train_probs), t(train_mu), t(train_lv),
+                                      u_row=t(u_row), e_comp=t(e_comp), eps=t(eps))
+    z_ref, k_ref, _ = sorc.conditional_latents(class_off, class_rows, labels, train_probs, train_mu, train_lv, u_row,
+                                               e_comp, eps)
+    assert np.array_equal(comp.cpu().numpy().astype(np.int64), k_ref)
+    assert rel_err(z.cpu().numpy(), z_ref) < 1e-5
+    # generated noise: every row gets a component in range and finite latents; same seed -> same draws
+    z1, c1 = eng.prior_latents(n, t(cdf), seed=5, row_offset=100)
+    z2, c2 = eng.prior_latents(n, t(cdf), seed=5, row_offset=100)
+    assert torch.equal(z1, z2) and torch.equal(c1, c2)
+    assert int(c1.min()) >= 0 and int(c1.max()) < K and bool(torch.isfinite(z1).all())
+    # row-sharded generation is independent of the shard boundaries (counter = global row index)
+    za, ca = eng.prior_latents(1000, t(cdf), seed=5, row_offset=100)
+    zb, cb = eng.prior_latents(2000, t(cdf), seed=5, row_offset=1100)
+    assert torch.equal(torch.cat([za, zb]), z1) and torch.equal(torch.cat([ca, cb]), c1)
+
+
+def test_encode_matches_reference():
+    import torch
+    from suave_amd.engine import PackedTable
+
+    fx = load_golden("posterior_mixed7")
+    om, P, meta = fixture_model(fx)
+    eng = _engine(om, P)
+    table = PackedTable(fx["xnum"], fx["codes"], fx["mask"], eng.device)
+    B, K, D = meta["B"], om.K, om.D
+    out = eng.encode(table, 0, B)
+    enc = out["enc_out"].cpu().numpy()
+    assert rel_err(enc[:, :K], fx["out/logits"]) < TOL
+    assert rel_err(enc[:, K:K + K * D], fx["out/mu"].reshape(B, -1)) < TOL
+    assert rel_err(enc[:, K + K * D:], fx["out/logvar"].reshape(B, -1)) < TOL
+    assert rel_err(out["mean"].cpu().numpy(), fx["out/post_mean"]) < TOL
+    assert rel_err(out["logvar"].cpu().numpy(), fx["out/post_logvar"]) < TOL
+    assert rel_err(out["probs"].cpu().numpy(), fx["out/post_probs"]) < TOL
+    out = eng.encode(table, 0, B, temperature=0.5)
+    assert rel_err(out["mean"].cpu().numpy(), fx["out/post_mean_t05"]) < TOL
+    assert rel_err(out["logvar"].cpu().numpy(), fx["out/post_logvar_t05"]) < TOL
+    assert rel_err(out["probs"].cpu().numpy(), fx["out/post_probs_t05"]) < TOL
