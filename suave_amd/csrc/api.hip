@@ -149,7 +149,8 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
   w->gkl_logit = c.take<float>(R * p->ldK);
   w->gkl_mu = c.take<float>(R * p->ldD);
   w->gkl_lv = c.take<float>(R * p->ldD);
-  const int ldT = round_up(2 * m.latent_dim + m.n_components, 4);
+  const int ldT = m.behaviour == 0 ? round_up(2 * m.latent_dim + m.n_components, 4)
+                                   : round_up(m.n_components * m.latent_dim + m.latent_dim, 4);
   w->prior_terms = c.take<float>(R * ldT);
   w->onehot = c.take<float>(R * p->ldK);
   // slabs: every weight-gradient GEMM + the head slab + the prior slab
@@ -164,6 +165,7 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
     const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components;
     slab += (size_t)tn_splits(p, Mt, Nt, rows) * Mt * round_up(Nt + 1, 4);
   }
+  if (m.behaviour == 1) slab += (size_t)lg * (m.n_components * m.latent_dim + m.latent_dim);
   w->slab_floats = slab;
   w->slab = c.take<float>(slab);
   w->sums_slab = c.take<double>((size_t)lg * nch * 4);
@@ -260,13 +262,185 @@ __global__ void k_sum_chunks(const float* part, int n_chunks, int n_rows, float*
   }
 }
 
+
+// Unsupervised (expectation-form) ELBO: SUAVE._forward_elbo_batch with behaviour="unsupervised"
+// (model.py:1576-1580, :1619-1654).  The decoder runs on B*K virtual rows (row v = b*K + k uses the
+// latent of component k and the one-hot assignment k); tau <= 0 means "temperature is None".
+int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_t* batch, const suave_noise_t* noise,
+                    float beta_scale, float tau, int training, int64_t global_rows, void* workspace,
+                    size_t workspace_bytes, hipStream_t s, const suave_elbo_out_t* out, float* grads) {
+  const suave_model_t& m = p->model;
+  const bool grad = grads != nullptr;
+  const int B = batch->n_rows, K = m.n_components, D = m.latent_dim;
+  if (B == 0) return 0;
+  const int64_t V64 = (int64_t)B * K;
+  SUAVE_REQUIRE(V64 < (int64_t(1) << 31), "unsupervised step: B*K too large");
+  const int V = (int)V64;
+  SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(params) & 15) == 0, "params must be 16-byte aligned");
+  SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
+  Workspace w;
+  carve(p, V, workspace, &w);
+  SUAVE_REQUIRE(workspace_bytes >= w.total_bytes, "workspace too small (size it for B*K rows in the unsupervised branch)");
+  const float drop_p = training ? m.dropout : 0.f;
+  const int nh = m.n_hidden;
+  suave_noise_t nz_default;
+  std::memset(&nz_default, 0, sizeof(nz_default));
+  const suave_noise_t* nz = noise ? noise : &nz_default;
+  const float tau_c = tau > 0.f ? std::max(tau, 1e-6f) : 0.f;
+
+  if (int rc = launch_expand(p, p->enc_src_dev, *batch, w.x, s)) return rc;
+  const float* act = w.x;
+  int ld_act = p->ldI;
+  for (int i = 0; i < nh; ++i) {
+    if (int rc = fwd_layer(p, params, m.enc[i], act, ld_act, w.he[i], p->ldH[i], B, true, drop_p, nz->enc_keep[i], batch,
+                           nz, kStreamEncDrop + i, 1, s))
+      return rc;
+    act = w.he[i];
+    ld_act = p->ldH[i];
+  }
+  if (int rc = fwd_layer(p, params, m.enc_head, act, ld_act, w.encout, p->ldE, B, false, 0.f, nullptr, batch, nz, 0, 1, s))
+    return rc;
+  float* wflat = w.gkl_mu;  // [V]
+  {
+    MixFwdArgs a{};
+    a.encout = w.encout; a.ldE = p->ldE; a.K = K; a.D = D; a.ldK = p->ldK; a.ldD = p->ldD; a.n_rows = B;
+    a.row_index = batch->row_index; a.row_begin = batch->row_begin; a.exp_noise = nz->exp_noise; a.eps_in = nz->eps;
+    a.seed = nz->seed; a.step = nz->step; a.tau = tau_c; a.w = w.ysoft; a.wflat = wflat; a.z_all = w.z;
+    a.eps_buf = w.eps; a.latent_out = out ? out->latent : nullptr;
+    if (int rc = launch_mix_fwd(a, s)) return rc;
+  }
+  act = w.z;
+  ld_act = p->ldD;
+  for (int i = 0; i < nh; ++i) {
+    if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], V, true, drop_p, nz->dec_keep[i], batch,
+                           nz, kStreamDecDrop + i, K, s))
+      return rc;
+    act = w.hd[i];
+    ld_act = p->ldH[i];
+  }
+  if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, V, false, 0.f, nullptr, batch, nz, 0, K, s))
+    return rc;
+  const int n_chunks = (int)p->chunks_host.size();
+  const int lgrid = loss_grid(p, V);
+  const int ldT = round_up(K * D + D, 4);
+  size_t slab_off = 0;
+  float* head_slab = w.slab;
+  slab_off += (size_t)lgrid * m.head_len;
+  {
+    LossArgs a{};
+    a.cols = p->cols_dev; a.chunks = p->chunks_dev; a.params = params; a.y = w.y; a.batch = *batch;
+    a.n_rows = V; a.vdiv = K; a.kidx = nullptr; a.row_weight = wflat;
+    a.c_up = -1.0f / (float)global_rows; a.bk = beta_scale / (float)global_rows;
+    a.K = K; a.D = D; a.ldY = p->ldY; a.ldy = p->max_chunk_y | 1; a.ldK = p->ldK; a.ldD = p->ldD; a.ldE = p->ldE;
+    a.ldT = ldT; a.max_classes = p->max_classes; a.recon_part = w.recon_part; a.ds_part = nullptr; a.do_kl = 0;
+    a.head_slab = grad ? head_slab : nullptr; a.sums_slab = nullptr;
+    a.head_off = m.head_off; a.head_len = m.head_len; a.hw_max = p->hw_max;
+    a.xsrc = p->xsrc_dev; a.ldx = p->loss_ldx; a.ldm = p->loss_ldm;
+    if (int rc = launch_loss(a, grad, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
+  }
+  ReduceArgs red{};
+  red.n_segs = 0; red.slab = w.slab; red.dst = grads;
+  int max_elems = 256;
+  if (grad) {
+    const float* hlast = nh ? w.hd[nh - 1] : w.z;
+    const int ldh = nh ? p->ldH[nh - 1] : p->ldD;
+    if (int rc = bwd_weight(p, m.y_proj, w.y, p->ldY, hlast, ldh, V, w.slab, &slab_off, &red, &max_elems, s)) return rc;
+    const float* dcur = w.y;
+    int lddcur = p->ldY;
+    const suave_layer_t* lcur = &m.y_proj;
+    for (int i = nh - 1; i >= 0; --i) {
+      if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dhd[i], p->ldH[i], V, w.hd[i], drop_p, s)) return rc;
+      const float* ain = i > 0 ? w.hd[i - 1] : w.z;
+      const int ldain = i > 0 ? p->ldH[i - 1] : p->ldD;
+      if (int rc = bwd_weight(p, m.dec[i], w.dhd[i], p->ldH[i], ain, ldain, V, w.slab, &slab_off, &red, &max_elems, s))
+        return rc;
+      dcur = w.dhd[i];
+      lddcur = p->ldH[i];
+      lcur = &m.dec[i];
+    }
+    if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dz, p->ldD, V, nullptr, 0.f, s)) return rc;
+  }
+  const int fgrid = std::max(1, std::min((B + 63) / 64, 2 * p->n_cu));
+  {
+    MixFinArgs a{};
+    a.encout = w.encout; a.ldE = p->ldE; a.K = K; a.D = D; a.ldK = p->ldK; a.ldD = p->ldD; a.n_rows = B;
+    a.n_chunks = n_chunks; a.ldT = ldT; a.params = params; a.pm_w_off = m.pm_w_off; a.pm_b_off = m.pm_b_off;
+    a.w = w.ysoft; a.eps_buf = w.eps; a.recon_part = w.recon_part; a.dz_all = w.dz; a.tau = tau_c;
+    a.c_up = -1.0f / (float)global_rows; a.bk = beta_scale / (float)global_rows;
+    a.recon = w.recon; a.catkl = w.catkl; a.gausskl = w.gausskl; a.dencout = w.dencout; a.prior_terms = w.prior_terms;
+    a.sums_slab = w.sums_slab;
+    if (int rc = launch_mix_finalize(a, grad, fgrid, s)) return rc;
+  }
+  red.sums_slab = w.sums_slab;
+  red.n_sum_slabs = fgrid;
+  red.sums_out = out ? out->sums : nullptr;
+  red.n_rows = (double)B;
+  if (grad) {
+    const float* helast = nh ? w.he[nh - 1] : w.x;
+    const int ldhe = nh ? p->ldH[nh - 1] : p->ldI;
+    if (int rc = bwd_weight(p, m.enc_head, w.dencout, p->ldE, helast, ldhe, B, w.slab, &slab_off, &red, &max_elems, s))
+      return rc;
+    const float* dcur = w.dencout;
+    int lddcur = p->ldE;
+    const suave_layer_t* lcur = &m.enc_head;
+    for (int i = nh - 1; i >= 0; --i) {
+      if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dhe[i], p->ldH[i], B, w.he[i], drop_p, s)) return rc;
+      const float* ain = i > 0 ? w.he[i - 1] : w.x;
+      const int ldain = i > 0 ? p->ldH[i - 1] : p->ldI;
+      if (int rc = bwd_weight(p, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, B, w.slab, &slab_off, &red, &max_elems, s))
+        return rc;
+      dcur = w.dhe[i];
+      lddcur = p->ldH[i];
+      lcur = &m.enc[i];
+    }
+    // PriorMean gradients: column sums of prior_terms -> linear.weight[d,k] and linear.bias[d]
+    {
+      const int ncol = K * D + D;
+      const int nb = std::max(1, std::min(lgrid, (B + 255) / 256));
+      if (int rc = launch_colsum(w.prior_terms, ldT, B, ncol, w.slab + slab_off, nb, s)) return rc;
+      SUAVE_REQUIRE(red.n_segs + 3 <= kMaxReduceSegs, "too many reduction segments");
+      ReduceSeg sw{};
+      sw.src_off = (int64_t)slab_off; sw.slab_stride = ncol; sw.n_slabs = nb; sw.rows = K; sw.cols = D; sw.src_ld = D;
+      sw.dst_off = m.pm_w_off; sw.dst_si = 1; sw.dst_sj = K;
+      red.segs[red.n_segs++] = sw;
+      ReduceSeg sb = sw;
+      sb.src_off += (int64_t)K * D; sb.rows = 1; sb.cols = D; sb.dst_off = m.pm_b_off; sb.dst_si = 0; sb.dst_sj = 1;
+      red.segs[red.n_segs++] = sb;
+      slab_off += (size_t)nb * ncol;
+    }
+    ReduceSeg sh{};
+    sh.src_off = 0; sh.slab_stride = m.head_len; sh.n_slabs = lgrid; sh.rows = 1; sh.cols = m.head_len;
+    sh.src_ld = m.head_len; sh.dst_off = m.head_off; sh.dst_si = 0; sh.dst_sj = 1;
+    red.segs[red.n_segs++] = sh;
+    max_elems = std::max(max_elems, m.head_len);
+    SUAVE_REQUIRE(slab_off <= w.slab_floats, "internal: slab overflow");
+  }
+  if (grad || red.sums_out) {
+    if (int rc = launch_reduce(red, max_elems, s)) return rc;
+  }
+  if (out) {
+    if (out->reconstruction)
+      SUAVE_CHECK_HIP(hipMemcpyAsync(out->reconstruction, w.recon, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+    if (out->categorical_kl)
+      SUAVE_CHECK_HIP(hipMemcpyAsync(out->categorical_kl, w.catkl, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+    if (out->gaussian_kl)
+      SUAVE_CHECK_HIP(hipMemcpyAsync(out->gaussian_kl, w.gausskl, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+    if (out->enc_out)
+      if (int rc = launch_posterior_stats(w.encout, p->ldE, K, D, B, 1.0f, out->enc_out, nullptr, nullptr, nullptr, s))
+        return rc;
+  }
+  return 0;
+}
+
 int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* batch, const suave_noise_t* noise,
               float beta_scale, float tau, int training, int64_t global_rows, void* workspace,
               size_t workspace_bytes, hipStream_t s, const suave_elbo_out_t* out, float* grads) {
   SUAVE_REQUIRE(p != nullptr && params != nullptr, "plan/params is null");
   if (int rc = check_batch(p, batch)) return rc;
   const suave_model_t& m = p->model;
-  SUAVE_REQUIRE(m.behaviour == 0, "unsupervised ELBO branch goes through suave_elbo_*_unsup");
+  if (m.behaviour == 1)
+    return elbo_unsup_impl(p, params, batch, noise, beta_scale, tau, training, global_rows, workspace, workspace_bytes, s,
+                           out, grads);
   const bool grad = grads != nullptr;
   const int B = batch->n_rows;
   if (B == 0) return 0;

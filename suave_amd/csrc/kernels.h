@@ -89,6 +89,45 @@ struct ReduceArgs {
   double n_rows;
 };
 
+// ---- unsupervised (expectation-form) ELBO: model.py:1576-1580, :1619-1654 ----
+struct MixFwdArgs {
+  const float* encout;     // [B, ldE]
+  int ldE, K, D, ldK, ldD, n_rows;
+  const int32_t* row_index;
+  int64_t row_begin;
+  const float* exp_noise;  // [B,K] or null
+  const float* eps_in;     // [B,K,D] or null
+  uint64_t seed, step;
+  float tau;               // <= 0: no Gumbel relaxation, weights = softmax(logits)
+  float* w;                // [B, ldK] posterior weights
+  float* wflat;            // [B*K] the same weights per virtual row
+  float* z_all;            // [B*K, ldD]
+  float* eps_buf;          // [B*K, ldD]
+  float* latent_out;       // [B, D] or null: sum_k w_k z_k
+};
+
+struct MixFinArgs {
+  const float* encout;
+  int ldE, K, D, ldK, ldD, n_rows, n_chunks, ldT;
+  const float* params;
+  int pm_w_off, pm_b_off;
+  const float* w;          // [B, ldK]
+  const float* eps_buf;    // [B*K, ldD]
+  const float* recon_part; // [n_chunks, B*K] per-virtual-row log-likelihood
+  const float* dz_all;     // [B*K, ldD] (grad only)
+  float tau, c_up, bk;
+  float* recon;            // [B]
+  float* catkl;
+  float* gausskl;
+  float* dencout;          // [B, ldE] (grad only)
+  float* prior_terms;      // [B, ldT]: d loss / d prior-mean[k,d] | summed over k  (grad only)
+  double* sums_slab;       // [gridDim.x, 4]
+};
+
+int launch_mix_fwd(const MixFwdArgs& a, hipStream_t s);
+int launch_mix_finalize(const MixFinArgs& a, bool grad, int grid, hipStream_t s);
+int launch_colsum(const float* src, int ld, int n_rows, int n_cols, float* slab, int n_blocks, hipStream_t s);
+
 size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes, int ldx, int ldm);
 int loss_set_lds_limit(size_t lds_bytes);
 int launch_loss(const LossArgs& a, bool grad, int kmax, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s);

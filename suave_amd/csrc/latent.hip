@@ -220,7 +220,245 @@ __global__ __launch_bounds__(256) void k_posterior_stats(const float* __restrict
   }
 }
 
+// ---- unsupervised branch -------------------------------------------------------
+// Relaxed (hard=False) Gumbel-softmax weights over the components and a reparameterised latent for
+// EVERY component (model.py:1576-1580, :1620): virtual row v = b*K + k feeds the decoder.
+__global__ __launch_bounds__(256) void k_mix_fwd(MixFwdArgs a) {
+  __shared__ float w_s[64 * SUAVE_MAX_COMPONENTS];
+  const int tid = threadIdx.x;
+  const Philox rng(a.seed);
+  const int K = a.K, D = a.D;
+  for (int r0 = blockIdx.x * 64; r0 < a.n_rows; r0 += gridDim.x * 64) {
+    const int nrows = min(64, a.n_rows - r0);
+    __syncthreads();
+    if (tid < nrows) {
+      const int r = r0 + tid;
+      const uint32_t rid = a.row_index ? (uint32_t)a.row_index[r] : (uint32_t)(a.row_begin + r);
+      const float* lg = a.encout + (size_t)r * a.ldE;
+      float* ws = w_s + tid * SUAVE_MAX_COMPONENTS;
+      float best = -INFINITY;
+#pragma unroll 1
+      for (int j = 0; j < K; ++j) {
+        float tj = lg[j];
+        if (a.tau > 0.f) {
+          float e;
+          if (a.exp_noise) e = a.exp_noise[(size_t)r * K + j];
+          else {
+            const uint4 q = rng(rid, (uint32_t)(j >> 2), kStreamGumbel, (uint32_t)a.step);
+            const uint32_t word = (j & 3) == 0 ? q.x : (j & 3) == 1 ? q.y : (j & 3) == 2 ? q.z : q.w;
+            e = -__logf(u01(word));
+          }
+          tj = (tj - __logf(e)) / a.tau;
+        }
+        ws[j] = tj;
+        best = fmaxf(best, tj);
+      }
+      float sum = 0.f;
+#pragma unroll 1
+      for (int j = 0; j < K; ++j) { ws[j] = __expf(ws[j] - best); sum += ws[j]; }
+      const float inv = 1.0f / sum;
+#pragma unroll 1
+      for (int j = 0; j < K; ++j) {
+        const float wj = ws[j] * inv;
+        ws[j] = wj;
+        a.w[(size_t)r * a.ldK + j] = wj;
+        a.wflat[(size_t)r * K + j] = wj;
+      }
+    }
+    __syncthreads();
+    const int dq = (D + 3) / 4;
+    for (int idx = tid; idx < nrows * K * dq; idx += 256) {
+      const int lr = idx / (K * dq), rem = idx % (K * dq);
+      const int k = rem / dq, q = rem % dq;
+      const int r = r0 + lr;
+      const uint32_t rid = a.row_index ? (uint32_t)a.row_index[r] : (uint32_t)(a.row_begin + r);
+      float ev[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.eps_in == nullptr) {
+        const uint4 wd = rng(rid, (uint32_t)(k * dq + q), kStreamEps, (uint32_t)a.step);
+        const float2 n0 = normal2(wd.x, wd.y), n1 = normal2(wd.z, wd.w);
+        ev[0] = n0.x; ev[1] = n0.y; ev[2] = n1.x; ev[3] = n1.y;
+      }
+      const float* mu = a.encout + (size_t)r * a.ldE + K + k * D;
+      const float* lv = mu + K * D;
+      const size_t v = (size_t)r * K + k;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int d = q * 4 + e;
+        if (d >= D) break;
+        const float eps = a.eps_in ? a.eps_in[v * D + d] : ev[e];
+        const float lvc = fminf(fmaxf(lv[d], kLogvarMin), kLogvarMax);
+        a.z_all[v * a.ldD + d] = mu[d] + eps * __expf(0.5f * lvc);
+        a.eps_buf[v * a.ldD + d] = eps;
+      }
+    }
+    if (a.latent_out) {
+      __syncthreads();
+      for (int idx = tid; idx < nrows * D; idx += 256) {
+        const int lr = idx / D, d = idx % D;
+        const int r = r0 + lr;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc += w_s[lr * SUAVE_MAX_COMPONENTS + k] * a.z_all[((size_t)r * K + k) * a.ldD + d];
+        a.latent_out[(size_t)r * D + d] = acc;
+      }
+    }
+  }
+}
+
+// Expectation over the components: reconstruction = sum_k w_k log p_k, mixture KL (losses.py:60-84),
+// categorical KL, and (GRAD) the gradients w.r.t. the encoder head and the PriorMean layer.
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_mix_finalize(MixFinArgs a) {
+  __shared__ float w_s[64 * SUAVE_MAX_COMPONENTS];
+  __shared__ float kl_s[64 * SUAVE_MAX_COMPONENTS];
+  __shared__ float red_s[3 * 64];
+  const int tid = threadIdx.x;
+  const int K = a.K, D = a.D;
+  double s_rec = 0.0, s_cat = 0.0, s_gau = 0.0;
+  for (int r0 = blockIdx.x * 64; r0 < a.n_rows; r0 += gridDim.x * 64) {
+    const int nrows = min(64, a.n_rows - r0);
+    __syncthreads();
+    for (int idx = tid; idx < nrows * K; idx += 256) {
+      const int lr = idx / K, k = idx % K;
+      w_s[lr * SUAVE_MAX_COMPONENTS + k] = a.w[(size_t)(r0 + lr) * a.ldK + k];
+      kl_s[lr * SUAVE_MAX_COMPONENTS + k] = 0.f;
+    }
+    __syncthreads();
+    // per (row, component, latent dim): KL term and gradients of mu / logvar; KL summed over d per (row, k)
+    for (int idx = tid; idx < nrows * K; idx += 256) {
+      const int lr = idx / K, k = idx % K;
+      const int r = r0 + lr;
+      const float* mu = a.encout + (size_t)r * a.ldE + K + k * D;
+      const float* lv = mu + K * D;
+      const float wk = w_s[lr * SUAVE_MAX_COMPONENTS + k];
+      const size_t v = (size_t)r * K + k;
+      float kl = 0.f;
+      for (int d = 0; d < D; ++d) {
+        const float pm = a.params[a.pm_w_off + d * K + k] + a.params[a.pm_b_off + d];  // prior.py:31-39
+        const float raw = lv[d];
+        const float lvc = fminf(fmaxf(raw, kLogvarMin), kLogvarMax);
+        const float diff = mu[d] - pm;
+        const float elv = __expf(lvc);
+        kl += 0.5f * (-lvc + elv + diff * diff - 1.0f);  // prior logvar == 0 (model.py:541)
+        if (GRAD) {
+          const float dz = a.dz_all[v * a.ldD + d];
+          const float eps = a.eps_buf[v * a.ldD + d];
+          const float gm = a.bk * wk * diff;
+          a.dencout[(size_t)r * a.ldE + K + k * D + d] = dz + gm;
+          const bool in_range = raw >= kLogvarMin && raw <= kLogvarMax;
+          a.dencout[(size_t)r * a.ldE + K + K * D + k * D + d] =
+              in_range ? dz * eps * 0.5f * __expf(0.5f * lvc) + a.bk * wk * 0.5f * (elv - 1.0f) : 0.f;
+          a.prior_terms[(size_t)r * a.ldT + k * D + d] = -gm;
+        }
+      }
+      kl_s[lr * SUAVE_MAX_COMPONENTS + k] = kl;
+    }
+    __syncthreads();
+    if (tid < nrows) {
+      const int r = r0 + tid;
+      const float* lg = a.encout + (size_t)r * a.ldE;
+      const float* ws = w_s + tid * SUAVE_MAX_COMPONENTS;
+      float lp[SUAVE_MAX_COMPONENTS];
+      float rec = 0.f, gk = 0.f;
+#pragma unroll 1
+      for (int k = 0; k < K; ++k) {
+        float t = 0.f;
+        for (int c = 0; c < a.n_chunks; ++c) t += a.recon_part[(size_t)c * a.n_rows * K + (size_t)r * K + k];
+        lp[k] = t;
+        rec += ws[k] * t;
+        gk += ws[k] * kl_s[tid * SUAVE_MAX_COMPONENTS + k];
+      }
+      float mq = -INFINITY;
+      for (int k = 0; k < K; ++k) mq = fmaxf(mq, lg[k]);
+      float sq = 0.f;
+      for (int k = 0; k < K; ++k) sq += __expf(lg[k] - mq);
+      const float lse = mq + __logf(sq);
+      const float logp = -__logf((float)K);  // prior logits == 0
+      float ck = 0.f;
+      for (int k = 0; k < K; ++k) { const float lq = lg[k] - lse; ck += __expf(lq) * (lq - logp); }
+      a.recon[r] = rec;
+      a.catkl[r] = ck;
+      a.gausskl[r] = gk;
+      red_s[tid] = rec; red_s[64 + tid] = ck; red_s[128 + tid] = gk;
+      if (GRAD) {
+        // d loss / d w_k = c * lp_k + bk * KL_k, through the (relaxed Gumbel-)softmax Jacobian
+        float inner = 0.f;
+        float dw[SUAVE_MAX_COMPONENTS];
+#pragma unroll 1
+        for (int k = 0; k < K; ++k) {
+          dw[k] = a.c_up * lp[k] + a.bk * kl_s[tid * SUAVE_MAX_COMPONENTS + k];
+          inner += ws[k] * dw[k];
+        }
+        const float inv_tau = a.tau > 0.f ? 1.0f / a.tau : 1.0f;
+#pragma unroll 1
+        for (int k = 0; k < K; ++k) {
+          const float lq = lg[k] - lse;
+          const float q = __expf(lq);
+          a.dencout[(size_t)r * a.ldE + k] = ws[k] * (dw[k] - inner) * inv_tau + a.bk * q * ((lq - logp) - ck);
+        }
+      }
+    } else if (tid < 64) {
+      red_s[tid] = 0.f; red_s[64 + tid] = 0.f; red_s[128 + tid] = 0.f;
+    }
+    if (GRAD) {
+      // pad columns of d(enc_out) and the bias part of the prior-mean gradient (sum over k)
+      const int E = K + 2 * K * D;
+      for (int idx = tid; idx < nrows * (a.ldE - E); idx += 256)
+        a.dencout[(size_t)(r0 + idx / (a.ldE - E)) * a.ldE + E + idx % (a.ldE - E)] = 0.f;
+      __syncthreads();
+      for (int idx = tid; idx < nrows * D; idx += 256) {
+        const int lr = idx / D, d = idx % D;
+        float t = 0.f;
+        for (int k = 0; k < K; ++k) t += a.prior_terms[(size_t)(r0 + lr) * a.ldT + k * D + d];
+        a.prior_terms[(size_t)(r0 + lr) * a.ldT + K * D + d] = t;
+      }
+    }
+    __syncthreads();
+    if (tid == 0)
+      for (int i = 0; i < 64; ++i) { s_rec += red_s[i]; s_cat += red_s[64 + i]; s_gau += red_s[128 + i]; }
+  }
+  if (tid == 0 && a.sums_slab) {
+    double* s = a.sums_slab + (size_t)blockIdx.x * 4;
+    s[0] = s_rec; s[1] = s_cat; s[2] = s_gau; s[3] = 0.0;
+  }
+}
+
+// column sums of a [n_rows, n_cols] matrix into per-block slabs (fixed-order reduce follows)
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ src, int ld, int n_rows, int n_cols,
+                                                float* __restrict__ slab) {
+  const int rows_per = (n_rows + gridDim.x - 1) / gridDim.x;
+  const int rb = blockIdx.x * rows_per, re = min(n_rows, rb + rows_per);
+  for (int c = threadIdx.x; c < n_cols; c += 256) {
+    float t = 0.f;
+    for (int r = rb; r < re; ++r) t += src[(size_t)r * ld + c];
+    slab[(size_t)blockIdx.x * n_cols + c] = t;
+  }
+}
+
 // ---- host launchers -----------------------------------------------------------
+int launch_mix_fwd(const MixFwdArgs& a, hipStream_t s) {
+  if (a.n_rows <= 0) return 0;
+  ProfScope prof_scope(kProfLatent, s);
+  hipLaunchKernelGGL(k_mix_fwd, dim3(std::min((a.n_rows + 63) / 64, 2048)), dim3(256), 0, s, a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_mix_finalize(const MixFinArgs& a, bool grad, int grid, hipStream_t s) {
+  if (a.n_rows <= 0) return 0;
+  ProfScope prof_scope(kProfLatent, s);
+  if (grad) hipLaunchKernelGGL((k_mix_finalize<true>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_mix_finalize<false>), dim3(grid), dim3(256), 0, s, a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_colsum(const float* src, int ld, int n_rows, int n_cols, float* slab, int n_blocks, hipStream_t s) {
+  ProfScope prof_scope(kProfReduce, s);
+  hipLaunchKernelGGL(k_colsum, dim3(n_blocks), dim3(256), 0, s, src, ld, n_rows, n_cols, slab);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_expand(const suave_plan* p, const int32_t* enc_src_dev, const suave_batch_t& b, float* x, hipStream_t s) {
   if (b.n_rows <= 0) return 0;
   ProfScope prof_scope(kProfExpand, s);

@@ -126,7 +126,7 @@ class Engine:
 
     # -- ELBO step -------------------------------------------------------------
     def elbo(self, table: PackedTable, row_begin: int, n_rows: int, *, row_index: Optional[torch.Tensor] = None,
-             beta_scale: float, tau: float = 1.0, grad: bool = True, training: bool = True,
+             beta_scale: float, tau: Optional[float] = 1.0, grad: bool = True, training: bool = True,
              global_rows: Optional[int] = None, noise: Optional[Mapping[str, object]] = None, seed: int = 0,
              step: int = 0, want: Sequence[str] = (), accumulate_sums: bool = False) -> Dict[str, torch.Tensor]:
         """One ELBO forward (+ backward into ``self.grads``).  ``want`` selects
@@ -134,7 +134,10 @@ class Engine:
         latent, component, enc_out."""
 
         B = int(n_rows)
-        ws = self.workspace(B)
+        unsup = self.layout.behaviour != "supervised"
+        ws = self.workspace(B * (self.layout.n_components if unsup else 1))
+        if tau is None:
+            tau = 0.0  # unsupervised branch: temperature None -> plain softmax weights
         keep: list = []
         nz = self._noise(noise, seed, step, keep)
         batch = table.batch(row_begin, B, row_index)

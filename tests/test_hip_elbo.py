@@ -142,3 +142,64 @@ def test_row_index_gather_and_determinism():
     torch.cuda.synchronize()
     assert torch.equal(g1, g2)
     assert torch.equal(g2, eng.grads)
+
+
+UNSUP = ["elbo_unsup_mixed7_k3", "elbo_unsup_mixed12_notemp", "elbo_unsup_mixed7_drop"]
+
+
+@pytest.mark.parametrize("name", UNSUP)
+def test_golden_unsupervised_step(name):
+    """behaviour="unsupervised": K decoder passes, relaxed Gumbel weights, PriorMean prior (model.py:1619-1654)."""
+
+    import torch
+    from suave_amd.engine import PackedTable
+
+    fx = load_golden(name)
+    om, P, meta = fixture_model(fx)
+    eng = _engine(om, P)
+    table = PackedTable(fx["xnum"], fx["codes"], fx["mask"], eng.device)
+    nz = fixture_noise(fx, om, meta)
+    B, K = meta["B"], om.K
+    if nz.get("dec_drop") is not None:  # per-pass masks -> virtual-row layout v = b*K + k
+        nz["dec_drop"] = [np.stack([nz["dec_drop"][k][i] for k in range(K)], axis=1).reshape(B * K, -1)
+                          for i in range(len(om.hidden))]
+    noise = torch_noise(nz, eng.device)
+    res = eng.elbo(table, 0, B, beta_scale=meta["beta_scale"], tau=meta["temperature"], grad=True, noise=noise,
+                   want=("reconstruction", "categorical_kl", "gaussian_kl", "latent", "enc_out"), accumulate_sums=True)
+    torch.cuda.synchronize()
+    assert rel_err(res["reconstruction"].cpu().numpy(), fx["out/reconstruction"]) < TOL
+    assert rel_err(res["categorical_kl"].cpu().numpy(), fx["out/categorical_kl"]) < TOL
+    assert rel_err(res["gaussian_kl"].cpu().numpy(), fx["out/gaussian_kl"]) < TOL
+    assert rel_err(res["latent"].cpu().numpy(), fx["out/latent"]) < TOL
+    sums = eng.sums.cpu().numpy()
+    loss = -(sums[0] - meta["beta_scale"] * (sums[1] + sums[2])) / B
+    assert abs(loss - float(fx["out/loss"])) < TOL * abs(float(fx["out/loss"]))
+    ref_grads = {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")}
+    _grad_check(eng.grad_state(), ref_grads)
+    eng.adam_step(meta["lr"])
+    torch.cuda.synchronize()
+    new = eng.state()
+    for k in ref_grads:
+        upd_ref = fx["adam1/" + k] - fx["param/" + k]
+        upd = new[k] - fx["param/" + k]
+        nzm = np.abs(fx["grad/" + k]) > 1e-6
+        assert np.allclose(upd[nzm], upd_ref[nzm], atol=2e-3 * meta["lr"], rtol=0), k
+
+
+def test_forward_only_matches_backward_outputs():
+    """suave_elbo_forward (validation path, model.py:2497-2559) returns the same per-row terms as the training call."""
+
+    import torch
+    from suave_amd.engine import PackedTable
+
+    fx = load_golden("elbo_sup_mixed7_k3")
+    om, P, meta = fixture_model(fx)
+    eng = _engine(om, P)
+    table = PackedTable(fx["xnum"], fx["codes"], fx["mask"], eng.device)
+    noise = torch_noise(fixture_noise(fx, om, meta), eng.device)
+    res = eng.elbo(table, 0, meta["B"], beta_scale=meta["beta_scale"], tau=meta["tau"], grad=False, training=True,
+                   noise=noise, want=("reconstruction", "categorical_kl", "gaussian_kl"))
+    torch.cuda.synchronize()
+    assert rel_err(res["reconstruction"].cpu().numpy(), fx["out/reconstruction"]) < TOL
+    assert rel_err(res["categorical_kl"].cpu().numpy(), fx["out/categorical_kl"]) < TOL
+    assert rel_err(res["gaussian_kl"].cpu().numpy(), fx["out/gaussian_kl"]) < TOL
