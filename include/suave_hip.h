@@ -217,6 +217,26 @@ int suave_decode_sample(const suave_plan* plan, const float* params, const float
                         float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc,
                         float* y_full_out);
 
+/* Posterior draws for the Monte-Carlo predictive: SUAVE._posterior_draws
+ * (model.py:3304-3336).  enc_out [n_rows, K+2KD] as written by suave_encode;
+ * n_draws = L; e [L, n_rows, K] Exp(1) and eps [L, n_rows, D] N(0,1) inject the
+ * draws (NULL: generated from (seed, row_offset + l*n_rows + b)).  Outputs
+ * z [L*n_rows, D] and component [L*n_rows], draw-major like the reference's
+ * `.view(L * batch, ...)` (model.py:3368-3369). */
+int suave_posterior_draws(const suave_plan* plan, const float* enc_out, int64_t n_rows, int32_t n_draws,
+                          const float* e, const float* eps, uint64_t seed, int64_t row_offset, void* stream,
+                          float* z, int32_t* component);
+
+/* Decoder pass + parameters of ONE head: the `params` of
+ * SUAVE._posterior_predictive_params (model.py:3349-3386; head outputs
+ * decoder.py:89,134-138,173,215,259).  out_params [n, width] with width from
+ * suave_head_params_width: real {mean, var}; pos {mean_log, var_log, mean};
+ * count {rate}; cat / ordinal {probs[C]}. */
+int suave_head_params_width(const suave_plan* plan, int32_t col_index, int32_t* width);
+int suave_decode_params(const suave_plan* plan, const float* params, const float* z, const float* s,
+                        const int32_t* component, int64_t n, int32_t col_index, void* workspace,
+                        size_t workspace_bytes, void* stream, float* out_params);
+
 /* Measurement aid (no counterpart in the reference): when enabled, every kernel
  * launch of the library is bracketed by HIP events on its stream;
  * suave_profile_read synchronises and returns the summed device time (ms) and

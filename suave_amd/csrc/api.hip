@@ -928,3 +928,44 @@ extern "C" int suave_profile_read(double* ms_by_class, int64_t* launches_by_clas
   }
   return 0;
 }
+
+extern "C" int suave_head_params_width(const suave_plan* p, int32_t col_index, int32_t* width) {
+  SUAVE_REQUIRE(p && width, "head_params_width: null argument");
+  SUAVE_REQUIRE(col_index >= 0 && col_index < p->model.n_cols, "head_params_width: column out of range");
+  const suave_col_t& c = p->cols_host[col_index];
+  *width = c.type == SUAVE_TYPE_REAL ? 2 : c.type == SUAVE_TYPE_POS ? 3 : c.type == SUAVE_TYPE_COUNT ? 1 : c.n_classes;
+  return 0;
+}
+
+extern "C" int suave_decode_params(const suave_plan* p, const float* params, const float* z, const float* s_dense,
+                                   const int32_t* component, int64_t n, int32_t col_index, void* workspace,
+                                   size_t workspace_bytes, void* stream, float* out_params) {
+  SUAVE_REQUIRE(p && params && z && out_params, "decode_params: null argument");
+  SUAVE_REQUIRE(s_dense != nullptr || component != nullptr, "decode_params: need dense assignments or component indices");
+  SUAVE_REQUIRE(col_index >= 0 && col_index < p->model.n_cols, "decode_params: column out of range");
+  SUAVE_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "decode_params: row count out of range");
+  if (n == 0) return 0;
+  const suave_model_t& m = p->model;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace w;
+  carve(p, n, workspace, &w);
+  SUAVE_REQUIRE(workspace_bytes >= w.total_bytes, "workspace too small (see suave_workspace_bytes)");
+  const int B = (int)n;
+  SUAVE_CHECK_HIP(hipMemcpy2DAsync(w.z, sizeof(float) * p->ldD, z, sizeof(float) * m.latent_dim,
+                                   sizeof(float) * m.latent_dim, B, hipMemcpyDeviceToDevice, st));
+  suave_batch_t dummy;
+  std::memset(&dummy, 0, sizeof(dummy));
+  const float* act = w.z;
+  int ld_act = p->ldD;
+  for (int i = 0; i < m.n_hidden; ++i) {
+    if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], B, true, 0.f, nullptr, &dummy, nullptr, 0, 1, st))
+      return rc;
+    act = w.hd[i];
+    ld_act = p->ldH[i];
+  }
+  if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, &dummy, nullptr, 0, 1, st))
+    return rc;
+  int32_t width = 0;
+  if (int rc = suave_head_params_width(p, col_index, &width)) return rc;
+  return launch_head_params(p, col_index, params, w.y, s_dense, component, n, out_params, width, st);
+}

@@ -140,6 +140,8 @@ int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const f
                         const float* s, const int32_t* comp, int64_t n, const float* nn, const float* nu,
                         const float* ne, uint64_t seed, int64_t row_offset, float* out_num, int ld_num,
                         int16_t* out_codes, int ld_disc, hipStream_t st);
+int launch_head_params(const suave_plan* p, int col_index, const float* params, const float* y, const float* s,
+                       const int32_t* comp, int64_t n, float* out, int width, hipStream_t st);
 int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s);
 
 }  // namespace suave

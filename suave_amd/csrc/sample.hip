@@ -336,7 +336,133 @@ __global__ __launch_bounds__(256) void k_cond_latents(CondArgs a) {
   }
 }
 
+
+// Posterior draws for the Monte-Carlo predictive (SUAVE._posterior_draws, model.py:3304-3336):
+// L component draws per row (Gumbel-max on the logits == Categorical(logits).sample) and the
+// reparameterised latent of the drawn component.  Output row l*B + b.
+struct PostDrawArgs {
+  const float* enc_out;  // [B, K + 2KD] logits | mu | clamped logvar (suave_encode layout)
+  const float* e;        // [L,B,K] Exp(1) or null
+  const float* eps;      // [L,B,D] or null
+  uint64_t seed;
+  int64_t row_offset;
+  int B, L, K, D;
+  float* z;              // [L*B, D]
+  int32_t* comp;         // [L*B]
+};
+
+__global__ __launch_bounds__(256) void k_posterior_draws(PostDrawArgs a) {
+  const Philox rng(a.seed);
+  const int64_t total = (int64_t)a.L * a.B;
+  const int E = a.K + 2 * a.K * a.D;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    const int b = (int)(v % a.B);
+    const uint64_t gid = (uint64_t)(a.row_offset + v);
+    const float* row = a.enc_out + (size_t)b * E;
+    float best = -INFINITY;
+    int kb = 0;
+    for (int j = 0; j < a.K; ++j) {
+      float e;
+      if (a.e) e = a.e[(size_t)v * a.K + j];
+      else e = -__logf(philox_u(rng, (uint32_t)gid, (uint32_t)j, kStreamCondExp, (uint32_t)(gid >> 32)));
+      const float sc = detm::sub(row[j], detm::log(e));
+      if (sc > best) { best = sc; kb = j; }
+    }
+    a.comp[v] = kb;
+    const float* mu = row + a.K + kb * a.D;
+    const float* lv = mu + a.K * a.D;
+    for (int d = 0; d < a.D; d += 2) {
+      float e0, e1 = 0.f;
+      if (a.eps) {
+        e0 = a.eps[(size_t)v * a.D + d];
+        if (d + 1 < a.D) e1 = a.eps[(size_t)v * a.D + d + 1];
+      } else {
+        const uint4 w = rng((uint32_t)gid, (uint32_t)(d >> 1), kStreamPriorEps, (uint32_t)(gid >> 32));
+        const float2 n2 = normal2(w.x, w.y);
+        e0 = n2.x; e1 = n2.y;
+      }
+      a.z[(size_t)v * a.D + d] = mu[d] + e0 * __expf(0.5f * lv[d]);
+      if (d + 1 < a.D) a.z[(size_t)v * a.D + d + 1] = mu[d + 1] + e1 * __expf(0.5f * lv[d + 1]);
+    }
+  }
+}
+
+// Parameters of ONE likelihood head (the ``params`` dict of the reference heads, decoder.py:89,
+// 134-138,173,215,259) for every row: real -> mean, var; pos -> mean_log, var_log, mean;
+// count -> rate; cat -> probs[C]; ordinal -> probs[C].
+struct HeadParamArgs {
+  suave_col_t col;
+  const float* params;
+  const float* y;    // [n, ldY]
+  const float* s;    // [n, K] or null
+  const int32_t* comp;
+  int64_t n;
+  int K, ldY, width;
+  float* out;        // [n, width]
+};
+
+__global__ __launch_bounds__(256) void k_head_params(HeadParamArgs a) {
+  const suave_col_t col = a.col;
+  const int yd = col.y_dim, K = a.K;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < a.n; r += (int64_t)gridDim.x * 256) {
+    const float* yb = a.y + (size_t)r * a.ldY + col.y_off;
+    const float* srow = a.s ? a.s + (size_t)r * K : nullptr;
+    const int kc = a.s ? 0 : a.comp[r];
+    auto dot = [&](const float* w, int ydim) {
+      float acc = 0.f;
+      for (int i = 0; i < ydim; ++i) acc += w[i] * yb[i];
+      if (srow) { for (int j = 0; j < K; ++j) acc += w[ydim + j] * srow[j]; }
+      else acc += w[ydim + kc];
+      return acc;
+    };
+    float* o = a.out + (size_t)r * a.width;
+    const float* w = a.params + col.w_off;
+    if (col.type == SUAVE_TYPE_REAL || col.type == SUAVE_TYPE_POS) {
+      const float am = dot(w, yd);
+      const float v = softplus_f(dot(a.params + col.w2_off, 0)) + kEps;
+      const float mean = am * col.scale + col.shift, vs = v * (col.scale * col.scale);
+      o[0] = mean;
+      o[1] = vs;
+      if (col.type == SUAVE_TYPE_POS) o[2] = __expf(mean + 0.5f * fmaxf(vs, 0.f)) - 1.0f;
+    } else if (col.type == SUAVE_TYPE_COUNT) {
+      o[0] = softplus_f(dot(w, yd)) + kEps;
+    } else if (col.type == SUAVE_TYPE_CAT) {
+      const int C = col.n_classes, ldw = yd + K;
+      float mx = 0.f;
+      o[0] = 0.f;
+      for (int c = 1; c < C; ++c) { o[c] = dot(w + (c - 1) * ldw, yd); mx = fmaxf(mx, o[c]); }
+      float sum = 0.f;
+      for (int c = 0; c < C; ++c) { o[c] = __expf(o[c] - mx); sum += o[c]; }
+      for (int c = 0; c < C; ++c) o[c] /= sum;
+    } else {
+      const int C = col.n_classes;
+      const float mo = dot(a.params + col.w2_off, yd);
+      float thr = 0.f, prev = 0.f;
+      for (int c = 0; c < C - 1; ++c) {
+        thr += softplus_f(dot(w + c * K, 0)) + kEps;
+        const float sg = sigmoid_f(thr - mo);
+        o[c] = fminf(fmaxf(sg - prev, kEps), 1.0f);
+        prev = sg;
+      }
+      o[C - 1] = fminf(fmaxf(1.0f - prev, kEps), 1.0f);
+    }
+  }
+}
+
 }  // namespace
+
+int launch_head_params(const suave_plan* p, int col_index, const float* params, const float* y, const float* s,
+                       const int32_t* comp, int64_t n, float* out, int width, hipStream_t st) {
+  if (n <= 0) return 0;
+  HeadParamArgs a{};
+  a.col = p->cols_host[col_index];
+  a.params = params; a.y = y; a.s = s; a.comp = comp; a.n = n; a.K = p->model.n_components; a.ldY = p->ldY;
+  a.width = width; a.out = out;
+  ProfScope prof_scope(kProfSample, st);
+  hipLaunchKernelGGL(k_head_params, dim3((int)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const float* params, const float* y,
                         const float* s, const int32_t* comp, int64_t n, const float* nn, const float* nu,
@@ -403,6 +529,23 @@ extern "C" int suave_conditional_latents(const suave_plan* p, const int64_t* cla
   a.z = z; a.comp = component;
   const int grid = (int)std::min<int64_t>((n + 63) / 64, 4096);
   hipLaunchKernelGGL(k_cond_latents, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int suave_posterior_draws(const suave_plan* p, const float* enc_out, int64_t n_rows, int32_t n_draws,
+                                     const float* e, const float* eps, uint64_t seed, int64_t row_offset, void* stream,
+                                     float* z, int32_t* component) {
+  SUAVE_REQUIRE(p && enc_out && z && component, "posterior_draws: null argument");
+  SUAVE_REQUIRE(n_draws >= 1, "posterior_draws: L must be a positive integer");  // model.py:3313-3314
+  SUAVE_REQUIRE(n_rows >= 0 && n_rows * (int64_t)n_draws < (int64_t(1) << 31), "posterior_draws: too many rows");
+  if (n_rows == 0) return 0;
+  PostDrawArgs a{};
+  a.enc_out = enc_out; a.e = e; a.eps = eps; a.seed = seed; a.row_offset = row_offset; a.B = (int)n_rows; a.L = n_draws;
+  a.K = p->model.n_components; a.D = p->model.latent_dim; a.z = z; a.comp = component;
+  const int64_t total = n_rows * n_draws;
+  hipLaunchKernelGGL(k_posterior_draws, dim3((int)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -246,3 +246,34 @@ class Engine:
         if want_y:
             return out_num[:, : L.n_num], out_codes[:, : L.n_disc], y_out
         return out_num[:, : L.n_num], out_codes[:, : L.n_disc]
+
+    # -- Monte-Carlo posterior predictive ------------------------------------------
+    def posterior_draws(self, enc_out: torch.Tensor, L: int, *, e=None, eps=None, seed: int = 0, row_offset: int = 0):
+        """SUAVE._posterior_draws: returns z [L*B, D] and component [L*B] (draw-major)."""
+
+        B = int(enc_out.shape[0])
+        D = self.layout.latent_dim
+        z = torch.empty((L * B, D), dtype=torch.float32, device=self.device)
+        comp = torch.empty((L * B,), dtype=torch.int32, device=self.device)
+        rc = self.lib.suave_posterior_draws(self._plan, enc_out.data_ptr(), B, int(L), _ptr(e), _ptr(eps), int(seed),
+                                            int(row_offset), self._stream(), z.data_ptr(), comp.data_ptr())
+        _lib.check(rc, "suave_posterior_draws")
+        return z, comp
+
+    def head_params_width(self, col_index: int) -> int:
+        w = C.c_int32()
+        _lib.check(self.lib.suave_head_params_width(self._plan, int(col_index), C.byref(w)), "suave_head_params_width")
+        return int(w.value)
+
+    def decode_params(self, z: torch.Tensor, col_index: int, *, component: Optional[torch.Tensor] = None,
+                      assignments: Optional[torch.Tensor] = None) -> torch.Tensor:
+        n = int(z.shape[0])
+        ws = self.workspace(n)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        nbytes = ws.numel() - (base - ws.data_ptr())
+        out = torch.empty((n, self.head_params_width(col_index)), dtype=torch.float32, device=self.device)
+        rc = self.lib.suave_decode_params(self._plan, self.params.data_ptr(), z.data_ptr(), _ptr(assignments),
+                                          _ptr(component), n, int(col_index), base, nbytes, self._stream(),
+                                          out.data_ptr())
+        _lib.check(rc, "suave_decode_params")
+        return out

@@ -26,6 +26,9 @@ EXPORTS = (
     "suave_prior_latents",
     "suave_conditional_latents",
     "suave_decode_sample",
+    "suave_posterior_draws",
+    "suave_head_params_width",
+    "suave_decode_params",
     "suave_profile_enable",
     "suave_profile_read",
 )
@@ -69,6 +72,9 @@ def load():
     lib.suave_prior_latents.argtypes = [vp, vp, vp, vp, vp, u64, i64, i64, vp, vp, vp]
     lib.suave_conditional_latents.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, i64, i64, vp, vp, vp]
     lib.suave_decode_sample.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, u64, i64, vp, sz, vp, vp, i32, vp, i32, vp]
+    lib.suave_posterior_draws.argtypes = [vp, vp, i64, i32, vp, vp, u64, i64, vp, vp, vp]
+    lib.suave_head_params_width.argtypes = [vp, i32, C.POINTER(i32)]
+    lib.suave_decode_params.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, sz, vp, vp]
     lib.suave_profile_enable.argtypes = [C.c_int]
     lib.suave_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i64), i32]
     for name in EXPORTS:

@@ -422,8 +422,41 @@ def gen_posterior(name, kind, K, D, hidden, B, seed, L=8):
     print("wrote", name)
 
 
+def gen_tensorise(name, seed, n=40):
+    """standardize -> _apply_training_normalization -> _prepare_training_tensors on a frame with NaNs
+    (data.py:133-266, model.py:3116-3213, 2784-2922): raw columns in, encoder_inputs + stats out."""
+
+    import pandas as pd
+    from suave import data as ref_data
+
+    rng = np.random.default_rng(seed)
+    raw = {
+        "r0": rng.normal(50, 12, n), "p0": rng.lognormal(1.0, 0.5, n), "n0": rng.poisson(3.0, n).astype(float),
+        "c0": rng.integers(0, 3, n).astype(float), "o0": rng.integers(0, 4, n).astype(float),
+        "r1": rng.normal(0, 1, n), "n1": (rng.poisson(2.0, n) + 1).astype(float), "c1": rng.integers(0, 5, n).astype(float),
+    }
+    for k in raw:
+        raw[k][rng.random(n) < 0.2] = np.nan
+    X = pd.DataFrame(raw)
+    schema = Schema({"r0": {"type": "real"}, "p0": {"type": "pos"}, "n0": {"type": "count"},
+                     "c0": {"type": "cat", "n_classes": 3}, "o0": {"type": "ordinal", "n_classes": 4},
+                     "r1": {"type": "real"}, "n1": {"type": "count"}, "c1": {"type": "cat", "n_classes": 5}})
+    _, stats = ref_data.standardize(X, schema)
+    model = SUAVE(schema, latent_dim=4, n_components=2)
+    model._norm_stats_per_col = stats
+    enc = model._prepare_inference_inputs(X)
+    rec = {"enc_inputs": enc.numpy(), "schema": json.dumps(schema.to_dict()),
+           "stats": json.dumps({k: {kk: (vv if not isinstance(vv, (np.floating, np.integer)) else float(vv))
+                                    for kk, vv in v.items()} for k, v in stats.items()})}
+    for k, v in raw.items():
+        rec["raw/" + k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print("wrote", name)
+
+
 def main():
     check_multinomial_equivalence()
+    gen_tensorise("tensorise_mixed8", 51)
     gen_elbo("elbo_sup_mixed7_k3", "mixed7", 3, 6, (16, 8), 64, 0.3, 0.0, "supervised", 11)
     gen_elbo("elbo_sup_mixed7_k1", "mixed7", 1, 2, (8,), 4, 0.0, 0.0, "supervised", 12)
     gen_elbo("elbo_sup_mixed12_drop", "mixed12", 3, 6, (32, 16), 64, 0.3, 0.1, "supervised", 13, tau=0.7)

@@ -1,0 +1,102 @@
+"""End-to-end checks of the SUAVE-compatible class on the GPU (API semantics of the reference's
+tests/test_minimal.py, test_impute.py:149-236 and test_posterior_predictive.py:58-129)."""
+
+import numpy as np
+import pandas as pd
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(n, seed=0, with_nan=True):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 2, n)
+    df = pd.DataFrame({
+        "age": rng.normal(50 + 10 * g, 8, n),
+        "lab": rng.lognormal(1.0 + 0.5 * g, 0.4, n),
+        "visits": rng.poisson(2 + 3 * g, n).astype(float),
+        "sex": rng.integers(0, 2, n).astype(float),
+        "grade": np.clip(rng.integers(0, 3, n) + g, 0, 3).astype(float),
+    })
+    if with_nan:
+        for c in df.columns:
+            df.loc[rng.random(n) < 0.1, c] = np.nan
+    return df, g
+
+
+def _schema():
+    from suave_amd.types import Schema
+
+    return Schema({"age": {"type": "real"}, "lab": {"type": "pos"}, "visits": {"type": "count"},
+                   "sex": {"type": "cat", "n_classes": 2}, "grade": {"type": "ordinal", "n_classes": 4}})
+
+
+@pytest.mark.parametrize("behaviour", ["unsupervised", "supervised"])
+def test_fit_encode_sample_impute_predict(behaviour):
+    import torch
+    from suave_amd.model import SUAVE
+
+    df, g = _frame(1200, seed=1)
+    model = SUAVE(_schema(), behaviour=behaviour, latent_dim=8, n_components=3, hidden_dims=(32, 16), dropout=0.1,
+                  batch_size=128, learning_rate=3e-3, random_state=0)
+    model.fit(df, y=g if behaviour == "supervised" else None, epochs=12, kl_warmup_epochs=4)
+    hist = model._train_history
+    assert len(hist) == 12 and len(model._warmup_val_history) == 12
+    assert hist[-1]["reconstruction"] > hist[0]["reconstruction"] + 0.5  # training improves the log-likelihood
+    assert all(np.isfinite(list(h.values())).all() for h in hist + model._warmup_val_history)
+    # encode
+    z = model.encode(df)
+    assert z.shape == (len(df), 8) and np.isfinite(z).all()
+    comps = model.encode(df.iloc[:10], return_components=True)
+    assert comps["assignments"].shape == (10, 3) and np.allclose(comps["assignments"].sum(1), 1.0)
+    assert model.encode(df.iloc[:0]).shape == (0, 8)
+    # sample: dtypes of sampling.decoder_outputs_to_frame, chunking invariance
+    s1 = model.sample(500, batch_size=500, seed=7)
+    s2 = model.sample(500, batch_size=64, seed=7)
+    pd.testing.assert_frame_equal(s1, s2)
+    assert s1["age"].dtype == np.float32 and s1["visits"].dtype == np.int64 and (s1["visits"] >= 0).all()
+    assert isinstance(s1["sex"].dtype, pd.CategoricalDtype) and s1["grade"].cat.ordered
+    assert abs(s1["age"].mean() - df["age"].mean()) < 15 and s1["lab"].min() > -1.0
+    if behaviour == "supervised":
+        sc = model.sample(300, conditional=True, y=np.array([0, 1] * 150), seed=3)
+        assert len(sc) == 300
+        with pytest.raises(ValueError):
+            model.sample(2, conditional=True, y=np.array([0, 5]))
+    # impute: observed cells preserved, no NaN left (test_impute.py:149-186)
+    sub = df.iloc[:200]
+    imp = model.impute(sub)
+    assert imp.isna().sum().sum() == 0 and list(imp.columns) == list(sub.columns)
+    obs = sub["age"].notna()
+    assert np.allclose(imp.loc[obs, "age"].astype(float), sub.loc[obs, "age"].astype(float), rtol=1e-6)
+    for strat in ("soft", "hard", "sample"):
+        assert model.impute(sub, assignment_strategy=strat).isna().sum().sum() == 0
+    with pytest.raises(ValueError):
+        model.impute(sub, assignment_strategy="bogus")
+    full = model.impute(sub, only_missing=False)
+    assert full.shape == sub.shape
+    # posterior predictive probabilities (test_posterior_predictive.py:58-72)
+    p = model.predict_proba(sub, attr="grade", L=16)
+    assert p.shape == (200, 4) and torch.allclose(p.sum(dim=1), torch.ones(200), atol=1e-5) and bool((p > 0).all())
+    p2 = model.predict_proba(sub, attr=3, L=16)
+    assert p2.shape == (200, 2)
+    with pytest.raises(ValueError):
+        model.predict_proba(sub, attr="age")
+    with pytest.raises(ValueError):
+        model.predict_proba(sub, attr="grade", L=0)
+
+
+def test_unfitted_and_validation_errors():
+    from suave_amd.model import SUAVE
+
+    df, _ = _frame(10)
+    m = SUAVE(_schema(), behaviour="unsupervised")
+    with pytest.raises(RuntimeError):
+        m.encode(df)
+    with pytest.raises(RuntimeError):
+        m.sample(3)
+    with pytest.raises(RuntimeError):
+        m.impute(df)
+    with pytest.raises(ValueError):
+        SUAVE(_schema(), behaviour="supervised").fit(df)  # targets required
+    with pytest.raises(ValueError):
+        SUAVE(_schema(), n_components=0)
