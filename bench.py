@@ -163,6 +163,7 @@ def main():
     import torch
 
     from suave_amd import lib as slib
+    from suave_amd import parallel
     from suave_amd.engine import Engine, PackedTable
     from suave_amd.plan import ModelLayout
     from suave_amd.types import Schema
@@ -190,6 +191,7 @@ def main():
     table.xnum, table.codes, table.mask = xnum, codes, mask
     table.n_rows, table.ld_num, table.ld_disc, table.ld_mask = rows, xnum.shape[1], codes.shape[1], mask.shape[1]
 
+    buckets = parallel.gradient_buckets(layout)
     n_batches = max(1, rows // B)
     warmup_steps = max(1, 10 * n_batches)  # kl_warmup_epochs = 10 (model.py:59, :1448)
     state = {"perm": None, "step": 0}
@@ -204,8 +206,8 @@ def main():
         beta = 1.5 * min(state["step"], warmup_steps) / warmup_steps  # losses.kl_warmup
         eng.elbo(table, 0, B, row_index=idx, beta_scale=beta, tau=1.0, grad=True, global_rows=B * world,
                  seed=1234, step=state["step"], accumulate_sums=True)
-        if dist is not None:
-            dist.all_reduce(eng.grads)  # RCCL sum of the flat gradient (each rank already scaled by 1/global_rows)
+        if dist is not None:  # RCCL sum of the flat gradient (each rank already scaled by 1/global_rows)
+            parallel.allreduce_gradients(eng.grads, buckets)
         eng.adam_step(lr)
 
     def fence():

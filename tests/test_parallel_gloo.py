@@ -1,0 +1,107 @@
+"""Data-parallel host logic on CPU with gloo, world_size 2.
+
+The product's compute needs a GPU, so each rank's shard gradient comes from the CPU oracle here (test
+infrastructure); what is under test is the sharding arithmetic of suave_amd.parallel: with every rank
+scaling by 1/global_rows, the SUM all-reduce of shard gradients equals the single-batch gradient, also
+for ragged shards, and epoch metric sums agree on all ranks.
+"""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import suave_oracle as orc
+from suave_amd import parallel
+from tests.helpers import layout_from_columns, s64_columns, synth_packed
+
+
+def test_shard_rows_cover_and_balance():
+    for n in (0, 1, 7, 64, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_rows(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_gradient_buckets_cover_everything():
+    cols = s64_columns(64)
+    layout = layout_from_columns(cols, K=10, D=32, hidden=(256, 128))
+    assert parallel.gradient_buckets(layout) == [(0, layout.n_params)]
+    small = parallel.gradient_buckets(layout, max_bucket_floats=50000)
+    covered = np.zeros(layout.n_params, bool)
+    for b, e in small:
+        assert not covered[b:e].any()
+        covered[b:e] = True
+    assert covered.all()
+    assert small[0][0] == layout.group_ranges["decoder"][0]  # decoder side first: ready first in backward
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, B, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    cols = s64_columns(12)
+    om = orc.OracleModel(cols, n_components=3, latent_dim=4, hidden=(16, 8))
+    P = om.init_params(seed=1)
+    layout = layout_from_columns(cols, K=3, D=4, hidden=(16, 8))
+    xnum, codes, mask = synth_packed(cols, B, 0.2, seed=5)
+    rng = np.random.default_rng(6)
+    noise = {"exp": rng.exponential(size=(B, 3)).astype(np.float32), "eps": rng.standard_normal((B, 4)).astype(np.float32)}
+    b, e = parallel.shard_rows(B, rank, world)
+    x_enc, data, masks = orc.dense_from_packed(om, xnum[b:e], codes[b:e], mask[b:e])
+    loc = orc.elbo_supervised(om, P, x_enc, data, masks, {k: v[b:e] for k, v in noise.items()}, beta_scale=1.0)
+    n_glob = parallel.global_batch_rows(e - b)
+    scale = (e - b) / n_glob  # the oracle normalises by the local batch; the HIP entry point takes global_rows
+    flat = torch.from_numpy(layout.pack({k: np.asarray(v, np.float32).reshape(layout.slots[k].shape) * scale
+                                         for k, v in loc["grads"].items()}))
+    parallel.allreduce_gradients(flat, parallel.gradient_buckets(layout, 300))
+    sums = torch.tensor([loc["reconstruction"].sum(), loc["categorical_kl"].sum(), loc["gaussian_kl"].sum(), e - b],
+                        dtype=torch.float64)
+    parallel.allreduce_sums(sums)
+    out_q.put((rank, n_glob, flat.numpy(), sums.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [64, 51])
+def test_two_rank_gradient_equals_single_batch(B):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cols = s64_columns(12)
+    om = orc.OracleModel(cols, n_components=3, latent_dim=4, hidden=(16, 8))
+    P = om.init_params(seed=1)
+    layout = layout_from_columns(cols, K=3, D=4, hidden=(16, 8))
+    xnum, codes, mask = synth_packed(cols, B, 0.2, seed=5)
+    rng = np.random.default_rng(6)
+    noise = {"exp": rng.exponential(size=(B, 3)).astype(np.float32), "eps": rng.standard_normal((B, 4)).astype(np.float32)}
+    x_enc, data, masks = orc.dense_from_packed(om, xnum, codes, mask)
+    full = orc.elbo_supervised(om, P, x_enc, data, masks, noise, beta_scale=1.0)
+    ref = layout.pack({k: np.asarray(v, np.float32).reshape(layout.slots[k].shape) for k, v in full["grads"].items()})
+    for rank, n_glob, flat, sums in results:
+        assert n_glob == B
+        assert np.allclose(flat, ref, rtol=1e-4, atol=1e-6)
+        assert abs(sums[0] - float(full["reconstruction"].sum())) < 1e-3 and sums[3] == B
+    assert np.array_equal(results[0][2], results[1][2])  # replicas stay bit-identical
