@@ -83,11 +83,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   }
   const int nk = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
 
-  float4 ra[NA], rb[NB];
-
   // Loads only issue the (predicated) global reads; the ragged-edge masking is done by
   // fix_tiles() right before the LDS store so the reads stay in flight during the MFMAs.
-  auto load_a = [&](int k0) {
+  auto load_tiles = [&](int k0, float4 (&ra)[NA], float4 (&rb)[NB]) {
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
       const int idx = tid + p * 256;
@@ -103,8 +101,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
       }
       ra[p] = v;
     }
-  };
-  auto load_b = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       const int idx = tid + p * 256;
@@ -121,57 +117,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
       rb[p] = v;
     }
   };
-  auto fix_tiles = [&](int k0) {
+  auto store_tiles = [&](int k0, int buf, float4 (&ra)[NA], float4 (&rb)[NB]) {
+    float* Ab = As + buf * BK * LDAS;
+    float* Bb = Bs + buf * BK * LDBS;
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
       const int idx = tid + p * 256;
       const int lim = !A_KM ? k_end - (k0 + (idx & 3) * 4) : a.M - (m0 + (idx % (BM / 4)) * 4);
+      float4 v = ra[p];
       if (lim < 4) {
-        if (lim < 2) ra[p].y = 0.f;
-        if (lim < 3) ra[p].z = 0.f;
-        ra[p].w = 0.f;
+        if (lim < 2) v.y = 0.f;
+        if (lim < 3) v.z = 0.f;
+        v.w = 0.f;
+      }
+      if (!A_KM) {
+        const int row = idx >> 2, kq = idx & 3;
+        Ab[(kq * 4 + 0) * LDAS + row] = v.x;
+        Ab[(kq * 4 + 1) * LDAS + row] = v.y;
+        Ab[(kq * 4 + 2) * LDAS + row] = v.z;
+        Ab[(kq * 4 + 3) * LDAS + row] = v.w;
+      } else {
+        const int krow = idx / (BM / 4), iq = idx % (BM / 4);
+        *reinterpret_cast<float4*>(Ab + krow * LDAS + iq * 4) = v;
       }
     }
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       const int idx = tid + p * 256;
       const int lim = !B_KM ? k_end - (k0 + (idx & 3) * 4) : a.N - (n0 + (idx % (BN / 4)) * 4);
+      float4 v = rb[p];
       if (lim < 4) {
-        if (lim < 2) rb[p].y = 0.f;
-        if (lim < 3) rb[p].z = 0.f;
-        rb[p].w = 0.f;
+        if (lim < 2) v.y = 0.f;
+        if (lim < 3) v.z = 0.f;
+        v.w = 0.f;
       }
-    }
-  };
-  auto store_tiles = [&](int buf) {
-    float* Ab = As + buf * BK * LDAS;
-    float* Bb = Bs + buf * BK * LDBS;
-#pragma unroll
-    for (int p = 0; p < NA; ++p) {
-      const int idx = tid + p * 256;
-      if (!A_KM) {
-        const int row = idx >> 2, kq = idx & 3;
-        Ab[(kq * 4 + 0) * LDAS + row] = ra[p].x;
-        Ab[(kq * 4 + 1) * LDAS + row] = ra[p].y;
-        Ab[(kq * 4 + 2) * LDAS + row] = ra[p].z;
-        Ab[(kq * 4 + 3) * LDAS + row] = ra[p].w;
-      } else {
-        const int krow = idx / (BM / 4), iq = idx % (BM / 4);
-        *reinterpret_cast<float4*>(Ab + krow * LDAS + iq * 4) = ra[p];
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < NB; ++p) {
-      const int idx = tid + p * 256;
       if (!B_KM) {
         const int row = idx >> 2, kq = idx & 3;
-        Bb[(kq * 4 + 0) * LDBS + row] = rb[p].x;
-        Bb[(kq * 4 + 1) * LDBS + row] = rb[p].y;
-        Bb[(kq * 4 + 2) * LDBS + row] = rb[p].z;
-        Bb[(kq * 4 + 3) * LDBS + row] = rb[p].w;
+        Bb[(kq * 4 + 0) * LDBS + row] = v.x;
+        Bb[(kq * 4 + 1) * LDBS + row] = v.y;
+        Bb[(kq * 4 + 2) * LDBS + row] = v.z;
+        Bb[(kq * 4 + 3) * LDBS + row] = v.w;
       } else {
         const int krow = idx / (BN / 4), jq = idx % (BN / 4);
-        *reinterpret_cast<float4*>(Bb + krow * LDBS + jq * 4) = rb[p];
+        *reinterpret_cast<float4*>(Bb + krow * LDBS + jq * 4) = v;
       }
     }
   };
@@ -187,36 +175,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   // 32-row / 32-column sub-tiles entirely outside the matrix are skipped (wave-uniform).
   const bool act_m0 = m0 + wm * 64 < a.M, act_m1 = m0 + wm * 64 + 32 < a.M;
   const bool act_n0 = n0 + wn * 64 < a.N, act_n1 = n0 + wn * 64 + 32 < a.N;
-
-  if (nk > 0) {
-    load_a(k_begin);
-    load_b(k_begin);
-    fix_tiles(k_begin);
-    store_tiles(0);
-  }
+  const int kh = lane >> 5, l31 = lane & 31;
   // bias gradient (weight-gradient form): column sums of the A operand, taken from the LDS tile
   float bias_acc = 0.f;
   const bool do_bias = a.epi == kEpiSlab && a.ones_col >= 0 && n0 == 0 && tid < BM;
-  __syncthreads();
-  const int kh = lane >> 5, l31 = lane & 31;
-  for (int t = 0; t < nk; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nk) {
-      load_a(k_begin + (t + 1) * BK);
-      load_b(k_begin + (t + 1) * BK);
-    }
+
+  // One K step on LDS buffer `buf`; operand fragments of step kk+1 are fetched before the MFMAs of kk.
+  auto compute = [&](int buf) {
     const float* Ab = As + buf * BK * LDAS + wm * 64 + l31;
     const float* Bb = Bs + buf * BK * LDBS + wn * 64 + l31;
     if (act_m0 && act_n0) {
+      float a0 = Ab[kh * LDAS], a1 = Ab[kh * LDAS + 32];
+      float b0 = Bb[kh * LDBS], b1 = Bb[kh * LDBS + 32];
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
-        const int kr = kk * 2 + kh;
-        const float a0 = Ab[kr * LDAS], a1 = Ab[kr * LDAS + 32];
-        const float b0 = Bb[kr * LDBS], b1 = Bb[kr * LDBS + 32];
+        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+        if (kk + 1 < BK / 2) {
+          const int kr = (kk + 1) * 2 + kh;
+          na0 = Ab[kr * LDAS]; na1 = Ab[kr * LDAS + 32];
+          nb0 = Bb[kr * LDBS]; nb1 = Bb[kr * LDBS + 32];
+        }
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
         if (act_n1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
         if (act_m1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
         if (act_m1 && act_n1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
       }
     }
     if (do_bias) {
@@ -224,11 +207,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
       for (int kk = 0; kk < BK; ++kk) bias_acc += Ac[kk * LDAS];
     }
-    if (t + 1 < nk) {
-      fix_tiles(k_begin + (t + 1) * BK);
-      store_tiles(buf ^ 1);
-    }
+  };
+
+  // Two register sets: while tile t is multiplied out of LDS, the global loads of tiles t+1 and t+2
+  // are in flight (the chip needs ~2 us of loads in flight per CU; one K step is < 1 us of MFMA).
+  float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+  if (nk > 0) {
+    load_tiles(k_begin, ra0, rb0);
+    store_tiles(k_begin, 0, ra0, rb0);
+    if (nk > 1) load_tiles(k_begin + BK, ra0, rb0);
+    if (nk > 2) load_tiles(k_begin + 2 * BK, ra1, rb1);
+  }
+  __syncthreads();
+  for (int t = 0; t < nk; t += 2) {
+    compute(0);
+    if (t + 1 < nk) store_tiles(k_begin + (t + 1) * BK, 1, ra0, rb0);
+    if (t + 3 < nk) load_tiles(k_begin + (t + 3) * BK, ra0, rb0);
     __syncthreads();
+    if (t + 1 < nk) {
+      compute(1);
+      if (t + 2 < nk) store_tiles(k_begin + (t + 2) * BK, 0, ra1, rb1);
+      if (t + 4 < nk) load_tiles(k_begin + (t + 4) * BK, ra1, rb1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue -------------------------------------------------------------
