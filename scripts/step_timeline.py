@@ -8,7 +8,7 @@ last = rows[idx[-1]:]
 t0 = int(last[0]["Start_Timestamp"])
 tot = 0
 for r in last:
-    name = r["Kernel_Name"].split("(")[0].replace("void suave::", "").replace("(anonymous namespace)::", "").replace("suave::", "")
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void suave::", "").replace("suave::", "")
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     tot += dur
     print(f"{name:36s} grid={int(r['Grid_Size_X'])//int(r['Workgroup_Size_X']):6d}x{r['Grid_Size_Y']}x{r['Grid_Size_Z']:>4s} "

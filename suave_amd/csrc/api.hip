@@ -76,6 +76,10 @@ struct Workspace {
   int32_t* kidx;
   float *recon_part, *ds_part, *catkl, *gausskl, *gkl_logit, *gkl_mu, *gkl_lv, *prior_terms, *recon;
   float* onehot;
+  // selected-component encoder head (supervised branch)
+  float *sel, *dsel, *gslab;
+  int32_t *perm, *lrank, *blk_cnt, *blk_base, *chunk_comp, *chunk_begin;
+  int n_blocks, n_chunks_max;
   float* slab;
   double* sums_slab;
   size_t slab_floats;
@@ -153,6 +157,22 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
                                    : round_up(m.n_components * m.latent_dim + m.latent_dim, 4);
   w->prior_terms = c.take<float>(R * ldT);
   w->onehot = c.take<float>(R * p->ldK);
+  {
+    const int ldS = p->ldK + 2 * p->ldD;
+    const bool sup = m.behaviour == 0;
+    const size_t Rg = sup ? R : 1;
+    w->n_blocks = (int)((Rg + 255) / 256);
+    w->n_chunks_max = (int)((Rg + kGroupRows - 1) / kGroupRows) + m.n_components;
+    w->sel = c.take<float>(Rg * ldS);
+    w->dsel = c.take<float>(Rg * ldS);
+    w->perm = c.take<int32_t>((size_t)w->n_chunks_max * kGroupRows);
+    w->lrank = c.take<int32_t>(Rg);
+    w->blk_cnt = c.take<int32_t>((size_t)w->n_blocks * m.n_components);
+    w->blk_base = c.take<int32_t>((size_t)w->n_blocks * m.n_components);
+    w->chunk_comp = c.take<int32_t>(w->n_chunks_max);
+    w->chunk_begin = c.take<int32_t>(m.n_components + 1);
+    w->gslab = c.take<float>(sup ? (size_t)w->n_chunks_max * ldS * round_up(m.enc_head.n_in + 1, 4) : 1);
+  }
   // slabs: every weight-gradient GEMM + the head slab + the prior slab
   size_t slab = 0;
   for (const suave_layer_t* l : all_layers(p)) {
@@ -468,19 +488,48 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     act = w.he[i];
     ld_act = p->ldH[i];
   }
-  if (int rc = fwd_layer(p, params, m.enc_head, act, ld_act, w.encout, p->ldE, B, false, 0.f, nullptr, batch, nz, 0, 1, s))
-    return rc;
-  // ---- assignment + reparameterisation ----
+  // ---- encoder head, selected component only ----
+  // Only the logits and the selected component's mu / logvar enter the supervised loss (model.py:1587-1598,
+  // losses.py:60-84), so the head is: logits GEMM -> assignment -> stable sort of the rows by component ->
+  // one grouped GEMM whose row tiles each use the 2*D weight rows of their component.
+  const int K = m.n_components, D = m.latent_dim;
+  const int ldS = p->ldK + 2 * p->ldD;
+  const float* hlast_e = act;
+  const int ldhe_last = ld_act;
+  const int Vg = w.n_chunks_max * kGroupRows;
+  LatentFwdArgs la{};
+  la.sel = w.sel; la.ldS = ldS; la.K = K; la.D = D; la.ldK = p->ldK; la.ldD = p->ldD;
+  la.n_rows = B; la.row_index = batch->row_index; la.row_begin = batch->row_begin;
+  la.exp_noise = nz->exp_noise; la.eps_in = nz->eps; la.seed = nz->seed; la.step = nz->step; la.tau = tau_c;
+  la.ysoft = w.ysoft; la.kidx = w.kidx; la.z = w.z; la.eps_buf = w.eps;
+  la.latent_out = out ? out->latent : nullptr;
+  la.comp_out = out ? out->component : nullptr;
+  la.lrank = w.lrank; la.blk_cnt = w.blk_cnt;
+  GroupArgs ga{};
+  ga.K = K; ga.n_rows = B; ga.n_blocks = w.n_blocks; ga.n_chunks_max = w.n_chunks_max; ga.kidx = w.kidx;
+  ga.lrank = w.lrank; ga.blk_cnt = w.blk_cnt; ga.blk_base = w.blk_base; ga.chunk_comp = w.chunk_comp;
+  ga.chunk_begin = w.chunk_begin; ga.perm = w.perm;
+  auto head_geometry = [&](GemmArgs& g) {
+    g.perm = w.perm; g.chunk_comp = w.chunk_comp; g.hK = K; g.hD = D; g.hldK = p->ldK; g.hldD = p->ldD;
+  };
   {
-    LatentFwdArgs a{};
-    a.encout = w.encout; a.ldE = p->ldE; a.K = m.n_components; a.D = m.latent_dim; a.ldK = p->ldK; a.ldD = p->ldD;
-    a.n_rows = B; a.row_index = batch->row_index; a.row_begin = batch->row_begin;
-    a.exp_noise = nz->exp_noise; a.eps_in = nz->eps; a.seed = nz->seed; a.step = nz->step; a.tau = tau_c;
-    a.ysoft = w.ysoft; a.kidx = w.kidx; a.z = w.z; a.eps_buf = w.eps;
-    a.latent_out = out ? out->latent : nullptr;
-    a.comp_out = out ? out->component : nullptr;
-    if (int rc = launch_latent_fwd(a, s)) return rc;
+    GemmArgs g = gemm_base();  // logits = h * W[0:K]^T + b[0:K]  -> sel[:, 0:K]
+    g.A = hlast_e; g.B = params + m.enc_head.w_off; g.C = w.sel; g.bias = params + m.enc_head.b_off;
+    g.M = B; g.N = K; g.K = m.enc_head.n_in; g.lda = ldhe_last; g.ldb = m.enc_head.ld; g.ldc = ldS;
+    g.epi = kEpiBias;
+    if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
   }
+  if (int rc = launch_assign(la, s)) return rc;
+  if (int rc = launch_group(ga, s)) return rc;
+  {
+    GemmArgs g = gemm_base();  // [mu_k | logvar_k] of each row's own component -> sel[:, ldK:]
+    g.A = hlast_e; g.B = params + m.enc_head.w_off; g.C = w.sel + p->ldK; g.bias = params + m.enc_head.b_off;
+    g.M = Vg; g.N = 2 * p->ldD; g.K = m.enc_head.n_in; g.lda = ldhe_last; g.ldb = m.enc_head.ld; g.ldc = ldS;
+    g.epi = kEpiBias; g.grouped = 1; g.q0 = p->ldK;
+    head_geometry(g);
+    if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
+  }
+  if (int rc = launch_reparam(la, s)) return rc;
   // ---- decoder trunk ----
   act = w.z;
   ld_act = p->ldD;
@@ -508,7 +557,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     a.bk = beta_scale / (float)global_rows;
     a.K = m.n_components; a.D = m.latent_dim; a.ldY = p->ldY; a.ldy = p->max_chunk_y | 1; a.ldK = p->ldK;
     a.ldD = p->ldD; a.ldE = p->ldE; a.ldT = ldT; a.max_classes = p->max_classes;
-    a.recon_part = w.recon_part; a.ds_part = w.ds_part; a.do_kl = 1; a.encout = w.encout;
+    a.recon_part = w.recon_part; a.ds_part = w.ds_part; a.do_kl = 1; a.encout = w.sel; a.ldE = ldS;
     a.prior_logits_off = m.prior_logits_off; a.prior_mu_off = m.prior_mu_off; a.prior_logvar_off = m.prior_logvar_off;
     a.catkl = w.catkl; a.gausskl = w.gausskl; a.gkl_logit = w.gkl_logit; a.gkl_mu = w.gkl_mu; a.gkl_lv = w.gkl_lv;
     a.prior_terms = w.prior_terms; a.head_slab = grad ? head_slab : nullptr; a.sums_slab = w.sums_slab;
@@ -555,29 +604,45 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     // ---- latent backward ----
     {
       LatentBwdArgs a{};
-      a.encout = w.encout; a.ldE = p->ldE; a.K = m.n_components; a.D = m.latent_dim; a.ldK = p->ldK; a.ldD = p->ldD;
+      a.sel = w.sel; a.ldS = ldS; a.K = K; a.D = D; a.ldK = p->ldK; a.ldD = p->ldD;
       a.n_rows = B; a.n_chunks = n_chunks; a.ysoft = w.ysoft; a.kidx = w.kidx; a.eps_buf = w.eps; a.dz = w.dz;
       a.ds_part = w.ds_part; a.gkl_logit = w.gkl_logit; a.gkl_mu = w.gkl_mu; a.gkl_lv = w.gkl_lv; a.tau = tau_c;
-      a.dencout = w.dencout;
+      a.dsel = w.dsel;
       if (int rc = launch_latent_bwd(a, s)) return rc;
     }
-    // ---- encoder backward ----
-    const float* helast = nh ? w.he[nh - 1] : w.x;
-    const int ldhe = nh ? p->ldH[nh - 1] : p->ldI;
-    if (int rc = bwd_weight(p, m.enc_head, w.dencout, p->ldE, helast, ldhe, B, w.slab, &slab_off, &red, &max_elems, s))
-      return rc;
-    dcur = w.dencout;
-    lddcur = p->ldE;
-    lcur = &m.enc_head;
+    // ---- encoder head backward (grouped by component) ----
+    {
+      const suave_layer_t& l = m.enc_head;
+      const int ldc = round_up(l.n_in + 1, 4);
+      GemmArgs g = gemm_base();  // per-chunk slabs of dsel^T * h (+ column sums = bias gradient)
+      g.A = w.dsel; g.B = hlast_e; g.C = w.gslab;
+      g.M = ldS; g.N = l.n_in; g.K = Vg; g.lda = ldS; g.ldb = ldhe_last; g.ldc = ldc;
+      g.a_kmajor = 1; g.b_kmajor = 1; g.epi = kEpiSlab; g.splits = w.n_chunks_max;
+      g.slab_stride = (int64_t)ldS * ldc; g.ones_col = l.n_in; g.grouped = 2;
+      head_geometry(g);
+      if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
+      HeadReduceArgs h{};
+      h.slab = w.gslab; h.chunk_begin = w.chunk_begin; h.K = K; h.D = D; h.ldK = p->ldK; h.ldD = p->ldD; h.ldS = ldS;
+      h.n_in = l.n_in; h.ldc = ldc; h.grads = grads; h.w_off = l.w_off; h.b_off = l.b_off; h.ld = l.ld;
+      if (int rc = launch_head_reduce(h, s)) return rc;
+    }
+    if (nh > 0) {
+      GemmArgs g = gemm_base();  // d h = dsel * W[rows of the row's component], relu/dropout mask of h
+      g.A = w.dsel; g.B = params + m.enc_head.w_off; g.C = w.dhe[nh - 1];
+      g.M = Vg; g.N = m.enc_head.n_in; g.K = ldS; g.lda = ldS; g.ldb = m.enc_head.ld; g.ldc = p->ldH[nh - 1];
+      g.b_kmajor = 1; g.epi = kEpiMaskBwd; g.H = w.he[nh - 1]; g.drop_p = drop_p; g.grouped = 1; g.q0 = 0;
+      head_geometry(g);
+      if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
+    }
+    // ---- encoder trunk backward ----
     for (int i = nh - 1; i >= 0; --i) {
-      if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dhe[i], p->ldH[i], B, w.he[i], drop_p, s)) return rc;
       const float* ain = i > 0 ? w.he[i - 1] : w.x;
       const int ldain = i > 0 ? p->ldH[i - 1] : p->ldI;
       if (int rc = bwd_weight(p, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, B, w.slab, &slab_off, &red, &max_elems, s))
         return rc;
-      dcur = w.dhe[i];
-      lddcur = p->ldH[i];
-      lcur = &m.enc[i];
+      if (i > 0)
+        if (int rc = bwd_data(p, params, m.enc[i], w.dhe[i], p->ldH[i], w.dhe[i - 1], p->ldH[i - 1], B, w.he[i - 1], drop_p, s))
+          return rc;
     }
     // ---- prior gradients: (prior_terms^T * [onehot(k) | 1]) via the split GEMM ----
     {
@@ -595,7 +660,6 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
       g.slab_stride = (int64_t)Mt * ldc; g.ones_col = m.n_components;
       if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
       SUAVE_REQUIRE(red.n_segs + 4 <= kMaxReduceSegs, "too many reduction segments");
-      const int D = m.latent_dim, K = m.n_components;
       ReduceSeg sm{};  // prior.mu[k][d] = out[d][k]
       sm.src_off = (int64_t)slab_off; sm.slab_stride = g.slab_stride; sm.n_slabs = splits;
       sm.rows = D; sm.cols = K; sm.src_ld = ldc; sm.dst_off = m.prior_mu_off; sm.dst_si = 1; sm.dst_sj = D;
@@ -630,10 +694,13 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
       SUAVE_CHECK_HIP(hipMemcpyAsync(out->categorical_kl, w.catkl, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     if (out->gaussian_kl)
       SUAVE_CHECK_HIP(hipMemcpyAsync(out->gaussian_kl, w.gausskl, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
-    if (out->enc_out)
+    if (out->enc_out) {  // the full head is only evaluated when the caller asks for it
+      if (int rc = fwd_layer(p, params, m.enc_head, hlast_e, ldhe_last, w.encout, p->ldE, B, false, 0.f, nullptr, batch, nz, 0, 1, s))
+        return rc;
       if (int rc = launch_posterior_stats(w.encout, p->ldE, m.n_components, m.latent_dim, B, 1.0f, out->enc_out, nullptr,
                                           nullptr, nullptr, s))
         return rc;
+    }
   }
   return 0;
 }

@@ -161,7 +161,29 @@ struct GemmArgs {
   float drop_p;
   uint64_t seed, step;
   uint32_t stream_id;
+  // Selected-component encoder head (rows sorted by component, see latent.hip k_assign / k_group_scan):
+  //   grouped == 1: rows of A and C are sorted positions, read / written through perm; row r of B is
+  //                 weight row head_row(q0 + r, component of the tile)        (forward and data gradient)
+  //   grouped == 2: the k rows of A and B are sorted positions read through perm; split s is chunk s
+  //                 of kGroupRows positions                                    (weight gradient)
+  int grouped;
+  const int32_t* perm;        // sorted position -> batch row, -1 = padding
+  const int32_t* chunk_comp;  // chunk of kGroupRows sorted positions -> component, -1 = unused chunk
+  int hK, hD, hldK, hldD, q0;
 };
+
+// Sorted positions are handed out in chunks of kGroupRows rows of one component (multiple of every GEMM row tile).
+constexpr int kGroupRows = 256;
+
+// Compact per-row head layout [logits (ldK) | mu_k (ldD) | logvar_k (ldD)] -> row of the stacked encoder head
+// [logits (K) ; mu (K*D) ; logvar (K*D)] for component c; -1 for pad columns.
+__host__ __device__ __forceinline__ int head_row(int q, int c, int K, int D, int ldK, int ldD) {
+  if (q < ldK) return q < K ? q : -1;
+  q -= ldK;
+  if (q < ldD) return q < D ? K + c * D + q : -1;
+  q -= ldD;
+  return q < D ? K + K * D + c * D + q : -1;
+}
 
 int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream);
 

@@ -33,20 +33,21 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   return x;
 }
 
-// Stateless dropout decision keyed by (seed, step, stream, table row, column).
-__device__ __forceinline__ bool drop_keep(uint32_t key, uint32_t row_id, uint32_t col, uint32_t thr) {
-  uint32_t h = hash32(row_id * 0x9E3779B1u + key);
-  h = hash32(h ^ (col * 0x85EBCA77u));
-  return h >= thr;
+// Stateless dropout decision keyed by (seed, step, stream, table row, column): row part, then column part.
+__device__ __forceinline__ uint32_t drop_row_hash(uint32_t key, uint32_t row_id) { return hash32(row_id * 0x9E3779B1u + key); }
+__device__ __forceinline__ bool drop_keep(uint32_t hrow, uint32_t col, uint32_t thr) {
+  return hash32(hrow ^ (col * 0x85EBCA77u)) >= thr;
 }
 
-template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM>
+template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int GRP, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   constexpr int LDAS = BM + PAD, LDBS = BN + PAD;
   constexpr int NA = BM * BK / 4 / 256;  // float4 loads per thread for the A tile
   constexpr int NB = BN * BK / 4 / 256;
+  static_assert(kGroupRows % BM == 0, "a row tile never straddles two component chunks");
   __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDAS + LDBS)];
+  __shared__ int perm_s[GRP == 2 ? kGroupRows : 1];
   float* As = smem;
   float* Bs = smem + 2 * BK * LDAS;
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   int k_begin = 0, k_end = a.K;
-  if (a.splits > 1) {
+  if (a.splits > 1 || GRP == 2) {
     int chunk = (a.K + a.splits - 1) / a.splits;
     chunk = (chunk + BK - 1) / BK * BK;
     k_begin = blockIdx.z * chunk;
@@ -83,53 +84,90 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   }
   const int nk = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
 
-  // Loads only issue the (predicated) global reads; the ragged-edge masking is done by
-  // fix_tiles() right before the LDS store so the reads stay in flight during the MFMAs.
-  auto load_tiles = [&](int k0, float4 (&ra)[NA], float4 (&rb)[NB]) {
+  // Grouped forms: the component of this tile / chunk; unused chunks have no work (block-uniform exit).
+  int comp = 0;
+  if (GRP == 1) comp = a.chunk_comp[m0 / kGroupRows];
+  if (GRP == 2) comp = a.chunk_comp[blockIdx.z];
+  if (GRP != 0 && comp < 0) return;
+  if (GRP == 2) {
+    perm_s[tid] = a.perm[k_begin + tid];  // kGroupRows == blockDim.x
+    __syncthreads();
+  }
+  // Row gathers that do not depend on the K step.
+  int arow[NA], brow[NB];
+#pragma unroll
+  for (int p = 0; p < NA; ++p) arow[p] = (GRP == 1 && !A_KM) ? a.perm[m0 + ((tid + p * 256) >> 2)] : 0;
+#pragma unroll
+  for (int p = 0; p < NB; ++p)
+    brow[p] = (GRP == 1 && !B_KM) ? head_row(a.q0 + n0 + ((tid + p * 256) >> 2), comp, a.hK, a.hD, a.hldK, a.hldD) : 0;
+
+  // Loads are unconditional (an out-of-range element reads the operand's first float4 instead) so that the
+  // main loop has no control flow around them and the waits on them are exact counts; `okm` remembers which
+  // were real and the LDS store zeroes the others and the ragged edges.
+  auto load_tiles = [&](int k0, float4 (&ra)[NA], float4 (&rb)[NB], uint32_t& okm) {
+    okm = 0;
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
       const int idx = tid + p * 256;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      bool ok;
+      size_t off;
       if (!A_KM) {
         const int row = idx >> 2, kq = idx & 3;
         const int gi = m0 + row, gk = k0 + kq * 4;
-        if (gi < a.M && gk < k_end) v = *reinterpret_cast<const float4*>(a.A + (size_t)gi * a.lda + gk);
+        if (GRP == 1) { ok = arow[p] >= 0 && gk < k_end; off = (size_t)arow[p] * a.lda + gk; }
+        else { ok = gi < a.M && gk < k_end; off = (size_t)gi * a.lda + gk; }
       } else {
         const int krow = idx / (BM / 4), iq = idx % (BM / 4);
         const int gk = k0 + krow, gi = m0 + iq * 4;
-        if (gk < k_end && gi < a.M) v = *reinterpret_cast<const float4*>(a.A + (size_t)gk * a.lda + gi);
+        if (GRP == 2) {
+          const int sr = perm_s[min(gk - k_begin, kGroupRows - 1)];
+          ok = sr >= 0 && gk < k_end && gi < a.M;
+          off = (size_t)sr * a.lda + gi;
+        } else { ok = gk < k_end && gi < a.M; off = (size_t)gk * a.lda + gi; }
       }
-      ra[p] = v;
+      ra[p] = *reinterpret_cast<const float4*>(ok ? a.A + off : a.A);
+      okm |= ok ? (1u << p) : 0u;
     }
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       const int idx = tid + p * 256;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      bool ok;
+      size_t off;
       if (!B_KM) {
         const int row = idx >> 2, kq = idx & 3;
         const int gj = n0 + row, gk = k0 + kq * 4;
-        if (gj < a.N && gk < k_end) v = *reinterpret_cast<const float4*>(a.B + (size_t)gj * a.ldb + gk);
+        if (GRP == 1) { ok = brow[p] >= 0 && gj < a.N && gk < k_end; off = (size_t)brow[p] * a.ldb + gk; }
+        else { ok = gj < a.N && gk < k_end; off = (size_t)gj * a.ldb + gk; }
       } else {
         const int krow = idx / (BN / 4), jq = idx % (BN / 4);
         const int gk = k0 + krow, gj = n0 + jq * 4;
-        if (gk < k_end && gj < a.N) v = *reinterpret_cast<const float4*>(a.B + (size_t)gk * a.ldb + gj);
+        if (GRP == 1) {
+          const int br = head_row(a.q0 + gk, comp, a.hK, a.hD, a.hldK, a.hldD);
+          ok = br >= 0 && gk < k_end && gj < a.N;
+          off = (size_t)br * a.ldb + gj;
+        } else if (GRP == 2) {
+          const int sr = perm_s[min(gk - k_begin, kGroupRows - 1)];
+          ok = sr >= 0 && gk < k_end && gj < a.N;
+          off = (size_t)sr * a.ldb + gj;
+        } else { ok = gk < k_end && gj < a.N; off = (size_t)gk * a.ldb + gj; }
       }
-      rb[p] = v;
+      rb[p] = *reinterpret_cast<const float4*>(ok ? a.B + off : a.B);
+      okm |= ok ? (1u << (8 + p)) : 0u;
     }
   };
-  auto store_tiles = [&](int k0, int buf, float4 (&ra)[NA], float4 (&rb)[NB]) {
+  auto store_tiles = [&](int k0, int buf, const float4 (&ra)[NA], const float4 (&rb)[NB], uint32_t okm) {
     float* Ab = As + buf * BK * LDAS;
     float* Bb = Bs + buf * BK * LDBS;
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
       const int idx = tid + p * 256;
-      const int lim = !A_KM ? k_end - (k0 + (idx & 3) * 4) : a.M - (m0 + (idx % (BM / 4)) * 4);
+      int lim = !A_KM ? k_end - (k0 + (idx & 3) * 4) : a.M - (m0 + (idx % (BM / 4)) * 4);
+      if (!((okm >> p) & 1u)) lim = 0;
       float4 v = ra[p];
-      if (lim < 4) {
-        if (lim < 2) v.y = 0.f;
-        if (lim < 3) v.z = 0.f;
-        v.w = 0.f;
-      }
+      v.x = lim > 0 ? v.x : 0.f;
+      v.y = lim > 1 ? v.y : 0.f;
+      v.z = lim > 2 ? v.z : 0.f;
+      v.w = lim > 3 ? v.w : 0.f;
       if (!A_KM) {
         const int row = idx >> 2, kq = idx & 3;
         Ab[(kq * 4 + 0) * LDAS + row] = v.x;
@@ -144,13 +182,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       const int idx = tid + p * 256;
-      const int lim = !B_KM ? k_end - (k0 + (idx & 3) * 4) : a.N - (n0 + (idx % (BN / 4)) * 4);
+      int lim = !B_KM ? k_end - (k0 + (idx & 3) * 4) : a.N - (n0 + (idx % (BN / 4)) * 4);
+      if (!((okm >> (8 + p)) & 1u)) lim = 0;
       float4 v = rb[p];
-      if (lim < 4) {
-        if (lim < 2) v.y = 0.f;
-        if (lim < 3) v.z = 0.f;
-        v.w = 0.f;
-      }
+      v.x = lim > 0 ? v.x : 0.f;
+      v.y = lim > 1 ? v.y : 0.f;
+      v.z = lim > 2 ? v.z : 0.f;
+      v.w = lim > 3 ? v.w : 0.f;
       if (!B_KM) {
         const int row = idx >> 2, kq = idx & 3;
         Bb[(kq * 4 + 0) * LDBS + row] = v.x;
@@ -172,19 +210,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // 32-row / 32-column sub-tiles entirely outside the matrix are skipped (wave-uniform).
-  const bool act_m0 = m0 + wm * 64 < a.M, act_m1 = m0 + wm * 64 + 32 < a.M;
-  const bool act_n0 = n0 + wn * 64 < a.N, act_n1 = n0 + wn * 64 + 32 < a.N;
+  // A wave whose 64x64 tile lies entirely outside the matrix skips the MFMAs (wave-uniform); partly
+  // outside sub-tiles multiply the zero rows the LDS store wrote (one straight-line MFMA stream).
+  const bool act = m0 + wm * 64 < a.M && n0 + wn * 64 < a.N;
   const int kh = lane >> 5, l31 = lane & 31;
   // bias gradient (weight-gradient form): column sums of the A operand, taken from the LDS tile
   float bias_acc = 0.f;
-  const bool do_bias = a.epi == kEpiSlab && a.ones_col >= 0 && n0 == 0 && tid < BM;
+  const bool do_bias = EPI == kEpiSlab && a.ones_col >= 0 && n0 == 0 && tid < BM;
 
   // One K step on LDS buffer `buf`; operand fragments of step kk+1 are fetched before the MFMAs of kk.
   auto compute = [&](int buf) {
-    const float* Ab = As + buf * BK * LDAS + wm * 64 + l31;
-    const float* Bb = Bs + buf * BK * LDBS + wn * 64 + l31;
-    if (act_m0 && act_n0) {
+    if (act) {
+      const float* Ab = As + buf * BK * LDAS + wm * 64 + l31;
+      const float* Bb = Bs + buf * BK * LDBS + wn * 64 + l31;
       float a0 = Ab[kh * LDAS], a1 = Ab[kh * LDAS + 32];
       float b0 = Bb[kh * LDBS], b1 = Bb[kh * LDBS + 32];
 #pragma unroll
@@ -195,10 +233,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
           na0 = Ab[kr * LDAS]; na1 = Ab[kr * LDAS + 32];
           nb0 = Bb[kr * LDBS]; nb1 = Bb[kr * LDBS + 32];
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the fetch of step kk+1 ahead of the MFMAs of step kk
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        if (act_n1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        if (act_m1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        if (act_m1 && act_n1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
       }
     }
@@ -211,65 +251,80 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 
   // Two register sets: while tile t is multiplied out of LDS, the global loads of tiles t+1 and t+2
   // are in flight (the chip needs ~2 us of loads in flight per CU; one K step is < 1 us of MFMA).
+  // Tiles past the end load nothing real and store zeros into a buffer nobody multiplies.
   float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
-  if (nk > 0) {
-    load_tiles(k_begin, ra0, rb0);
-    store_tiles(k_begin, 0, ra0, rb0);
-    if (nk > 1) load_tiles(k_begin + BK, ra0, rb0);
-    if (nk > 2) load_tiles(k_begin + 2 * BK, ra1, rb1);
-  }
+  uint32_t ok0 = 0, ok1 = 0;
+  load_tiles(k_begin, ra0, rb0, ok0);
+  store_tiles(k_begin, 0, ra0, rb0, ok0);
+  load_tiles(k_begin + BK, ra0, rb0, ok0);
+  load_tiles(k_begin + 2 * BK, ra1, rb1, ok1);
   __syncthreads();
-  for (int t = 0; t < nk; t += 2) {
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
     compute(0);
-    if (t + 1 < nk) store_tiles(k_begin + (t + 1) * BK, 1, ra0, rb0);
-    if (t + 3 < nk) load_tiles(k_begin + (t + 3) * BK, ra0, rb0);
+    store_tiles(k_begin + (t + 1) * BK, 1, ra0, rb0, ok0);
+    load_tiles(k_begin + (t + 3) * BK, ra0, rb0, ok0);
     __syncthreads();
-    if (t + 1 < nk) {
-      compute(1);
-      if (t + 2 < nk) store_tiles(k_begin + (t + 2) * BK, 0, ra1, rb1);
-      if (t + 4 < nk) load_tiles(k_begin + (t + 4) * BK, ra1, rb1);
-      __syncthreads();
-    }
+    compute(1);
+    store_tiles(k_begin + (t + 2) * BK, 0, ra1, rb1, ok1);
+    load_tiles(k_begin + (t + 4) * BK, ra1, rb1, ok1);
+    __syncthreads();
   }
+  if (t < nk) compute(0);
 
   // ---- epilogue -------------------------------------------------------------
-  float* Cout = a.C + (a.epi == kEpiSlab ? (size_t)blockIdx.z * a.slab_stride : 0);
+  float* Cout = a.C + (EPI == kEpiSlab ? (size_t)blockIdx.z * a.slab_stride : 0);
   if (do_bias && m0 + tid < a.M) Cout[(size_t)(m0 + tid) * a.ldc + a.ones_col] = bias_acc;
   const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const uint32_t thr = a.drop_p > 0.f ? static_cast<uint32_t>(fminf(a.drop_p * 4294967296.0f, 4294967040.0f)) : 0u;
   const uint32_t key = hash32(static_cast<uint32_t>(a.seed) ^ hash32(static_cast<uint32_t>(a.seed >> 32) + a.stream_id)) ^
                        hash32(static_cast<uint32_t>(a.step) * 0x9E3779B1u + 0x632BE5ABu);
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  const bool hashed_drop = EPI == kEpiReluDrop && a.drop_p > 0.f && a.keep == nullptr;
+  float bias[2] = {0.f, 0.f};
+  if ((EPI == kEpiBias || EPI == kEpiReluDrop) && a.bias != nullptr) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int col = n0 + wn * 64 + ni * 32 + l31;
-      const int row_base = m0 + wm * 64 + mi * 32 + 4 * kh;
-      if (row_base - 4 * kh >= a.M || n0 + wn * 64 + ni * 32 >= a.N) continue;
-      float bias = 0.f;
-      if ((a.epi == kEpiBias || a.epi == kEpiReluDrop) && a.bias != nullptr && col < a.N) bias = a.bias[col];
+      if (col < a.N) {
+        const int bi = GRP == 1 ? head_row(a.q0 + col, comp, a.hK, a.hD, a.hldK, a.hldD) : col;
+        if (bi >= 0) bias[ni] = a.bias[bi];
+      }
+    }
+  }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row_base + (r & 3) + 8 * (r >> 2);
-        if (row >= a.M || col >= a.N) continue;
+  for (int mi = 0; mi < 2; ++mi) {
+    const int row_base = m0 + wm * 64 + mi * 32 + 4 * kh;
+    if (row_base - 4 * kh >= a.M) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row_base + (r & 3) + 8 * (r >> 2);
+      if (row >= a.M) continue;
+      int orow = row;
+      if (GRP == 1) {
+        orow = a.perm[row];
+        if (orow < 0) continue;
+      }
+      uint32_t hrow = 0;
+      if (hashed_drop) {
+        const uint32_t rid = a.row_ids ? static_cast<uint32_t>(a.row_ids[row]) : static_cast<uint32_t>(a.row_begin + row);
+        hrow = drop_row_hash(key, rid);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = n0 + wn * 64 + ni * 32 + l31;
+        if (col >= a.N) continue;
         float v = acc[mi][ni][r];
-        const size_t off = (size_t)row * a.ldc + col;
-        if (a.epi == kEpiBias) {
-          v += bias;
-        } else if (a.epi == kEpiReluDrop) {
-          v = fmaxf(v + bias, 0.f);
+        const size_t off = (size_t)orow * a.ldc + col;
+        if (EPI == kEpiBias) {
+          v += bias[ni];
+        } else if (EPI == kEpiReluDrop) {
+          v = fmaxf(v + bias[ni], 0.f);
           if (a.drop_p > 0.f) {
-            bool keep;
-            if (a.keep != nullptr) {
-              keep = a.keep[(size_t)row * a.N + col] != 0;
-            } else {
-              const uint32_t rid = a.row_ids ? static_cast<uint32_t>(a.row_ids[row])
-                                             : static_cast<uint32_t>(a.row_begin + row);
-              keep = drop_keep(key, rid, static_cast<uint32_t>(col), thr);
-            }
+            const bool keep = a.keep != nullptr ? a.keep[(size_t)row * a.N + col] != 0
+                                                : drop_keep(hrow, static_cast<uint32_t>(col), thr);
             v = keep ? v * inv_keep : 0.f;
           }
-        } else if (a.epi == kEpiMaskBwd) {
+        } else if (EPI == kEpiMaskBwd) {
           v = a.H[off] > 0.f ? v * inv_keep : 0.f;
         }
         Cout[off] = v;
@@ -286,8 +341,15 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   SUAVE_REQUIRE(a.lda % 4 == 0 && a.ldb % 4 == 0, "gemm: leading dimensions must be multiples of 4 floats");
   SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0,
                 "gemm: operands must be 16-byte aligned");
-  SUAVE_REQUIRE(a.a_kmajor ? a.lda >= a.M : a.lda >= a.K, "gemm: lda too small");
-  SUAVE_REQUIRE(a.b_kmajor ? a.ldb >= a.N : a.ldb >= a.K, "gemm: ldb too small");
+  if (a.grouped == 0) {
+    SUAVE_REQUIRE(a.a_kmajor ? a.lda >= a.M : a.lda >= a.K, "gemm: lda too small");
+    SUAVE_REQUIRE(a.b_kmajor ? a.ldb >= a.N : a.ldb >= a.K, "gemm: ldb too small");
+  } else {
+    SUAVE_REQUIRE(a.perm != nullptr && a.chunk_comp != nullptr, "gemm: grouped form needs perm and chunk_comp");
+    SUAVE_REQUIRE((a.grouped == 1 ? a.M : a.K) % kGroupRows == 0, "gemm: grouped extent must be whole chunks");
+    SUAVE_REQUIRE(a.grouped == 1 ? !a.a_kmajor : (a.a_kmajor && a.b_kmajor && a.epi == kEpiSlab && a.splits == a.K / kGroupRows),
+                  "gemm: unsupported grouped operand layout");
+  }
   SUAVE_REQUIRE(a.ldc >= a.N + (a.ones_col >= 0 ? 1 : 0), "gemm: ldc too small");
   SUAVE_REQUIRE(a.ones_col < 0 || a.ones_col == a.N, "gemm: the bias column sits right after the N real columns");
   SUAVE_REQUIRE(a.epi != kEpiSlab || a.splits >= 1, "gemm: bad split count");
@@ -298,15 +360,23 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   const bool narrow = a.N <= 64;
   const int tiles = narrow ? ((a.M + 255) / 256) * ((a.N + 63) / 64) : ((a.M + 127) / 128) * ((a.N + 127) / 128);
   const dim3 grid(tiles, 1, splits), block(256);
-#define SUAVE_GEMM_LAUNCH(AKM, BKM)                                                              \
-  do {                                                                                           \
-    if (narrow) hipLaunchKernelGGL((gemm_kernel<4, 1, AKM, BKM>), grid, block, 0, stream, args); \
-    else hipLaunchKernelGGL((gemm_kernel<2, 2, AKM, BKM>), grid, block, 0, stream, args);        \
+#define SUAVE_GEMM_LAUNCH(AKM, BKM, GRP, EPI)                                                              \
+  do {                                                                                                     \
+    if (narrow) hipLaunchKernelGGL((gemm_kernel<4, 1, AKM, BKM, GRP, EPI>), grid, block, 0, stream, args); \
+    else hipLaunchKernelGGL((gemm_kernel<2, 2, AKM, BKM, GRP, EPI>), grid, block, 0, stream, args);        \
   } while (0)
-  if (!a.a_kmajor && !a.b_kmajor) SUAVE_GEMM_LAUNCH(false, false);
-  else if (!a.a_kmajor && a.b_kmajor) SUAVE_GEMM_LAUNCH(false, true);
-  else if (a.a_kmajor && a.b_kmajor) SUAVE_GEMM_LAUNCH(true, true);
-  else SUAVE_REQUIRE(false, "gemm: unsupported operand layout (A k-major with B k-contiguous)");
+  const int e = a.epi;
+  if (a.grouped == 1 && !a.b_kmajor && e == kEpiBias) SUAVE_GEMM_LAUNCH(false, false, 1, kEpiBias);
+  else if (a.grouped == 1 && a.b_kmajor && e == kEpiMaskBwd) SUAVE_GEMM_LAUNCH(false, true, 1, kEpiMaskBwd);
+  else if (a.grouped == 1 && a.b_kmajor && e == kEpiBias) SUAVE_GEMM_LAUNCH(false, true, 1, kEpiBias);
+  else if (a.grouped == 2) SUAVE_GEMM_LAUNCH(true, true, 2, kEpiSlab);
+  else if (a.grouped != 0) SUAVE_REQUIRE(false, "gemm: unsupported grouped form");
+  else if (!a.a_kmajor && !a.b_kmajor && e == kEpiBias) SUAVE_GEMM_LAUNCH(false, false, 0, kEpiBias);
+  else if (!a.a_kmajor && !a.b_kmajor && e == kEpiReluDrop) SUAVE_GEMM_LAUNCH(false, false, 0, kEpiReluDrop);
+  else if (!a.a_kmajor && a.b_kmajor && e == kEpiBias) SUAVE_GEMM_LAUNCH(false, true, 0, kEpiBias);
+  else if (!a.a_kmajor && a.b_kmajor && e == kEpiMaskBwd) SUAVE_GEMM_LAUNCH(false, true, 0, kEpiMaskBwd);
+  else if (a.a_kmajor && a.b_kmajor && e == kEpiSlab) SUAVE_GEMM_LAUNCH(true, true, 0, kEpiSlab);
+  else SUAVE_REQUIRE(false, "gemm: unsupported operand layout / epilogue combination");
 #undef SUAVE_GEMM_LAUNCH
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;

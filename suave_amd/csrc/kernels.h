@@ -21,7 +21,7 @@ struct LossArgs {
   float* recon_part;   // [n_chunks, n_rows]
   float* ds_part;      // [n_chunks, n_rows, ldK]
   int do_kl;
-  const float* encout;
+  const float* encout;  // KL phase: compact head buffer sel[n_rows, ldE] (see LatentFwdArgs), ldE = ldK + 2*ldD
   int prior_logits_off, prior_mu_off, prior_logvar_off;
   float* catkl;
   float* gausskl;
@@ -36,9 +36,11 @@ struct LossArgs {
   int ldx, ldm;         // LDS row strides of the staged cells (ints) and masks (bytes)
 };
 
+// Supervised branch: the encoder head is evaluated for the selected component only, so the per-row
+// head buffer is compact: sel[B, ldS] = [logits (ldK) | mu_k (ldD) | raw logvar_k (ldD)], ldS = ldK + 2*ldD.
 struct LatentFwdArgs {
-  const float* encout;  // [B, ldE] logits | mu | raw logvar
-  int ldE, K, D, ldK, ldD;
+  const float* sel;  // [B, ldS]
+  int ldS, K, D, ldK, ldD;
   int n_rows;
   const int32_t* row_index;
   int64_t row_begin;
@@ -52,11 +54,35 @@ struct LatentFwdArgs {
   float* eps_buf; // [B, ldD] (eps actually used; read back by the backward)
   float* latent_out;    // [B, D] or null
   int32_t* comp_out;    // [B] or null
+  // rows sorted by component (stable): rank of the row inside its 256-row block, per-block counts
+  int32_t* lrank;       // [B]
+  int32_t* blk_cnt;     // [ceil(B/256), K]
+};
+
+// Stable counting sort of the batch rows by selected component, in chunks of kGroupRows positions.
+struct GroupArgs {
+  int K, n_rows, n_blocks, n_chunks_max;
+  const int32_t* kidx;
+  const int32_t* lrank;
+  const int32_t* blk_cnt;
+  int32_t* blk_base;     // [n_blocks, K] first sorted position of block b's rows of component c
+  int32_t* chunk_comp;   // [n_chunks_max] component of each chunk, -1 past the last one
+  int32_t* chunk_begin;  // [K + 1] first chunk of each component
+  int32_t* perm;         // [n_chunks_max * kGroupRows] sorted position -> row (pre-filled with -1)
+};
+
+// Reduction of the per-chunk encoder-head weight-gradient slabs into the stacked head gradient.
+struct HeadReduceArgs {
+  const float* slab;          // [n_chunks, ldS, ldc]
+  const int32_t* chunk_begin; // [K + 1]
+  int K, D, ldK, ldD, ldS, n_in, ldc;
+  float* grads;
+  int w_off, b_off, ld;
 };
 
 struct LatentBwdArgs {
-  const float* encout;
-  int ldE, K, D, ldK, ldD, n_rows, n_chunks;
+  const float* sel;
+  int ldS, K, D, ldK, ldD, n_rows, n_chunks;
   const float* ysoft;
   const int32_t* kidx;
   const float* eps_buf;
@@ -66,7 +92,7 @@ struct LatentBwdArgs {
   const float* gkl_mu;     // [B, ldD]
   const float* gkl_lv;     // [B, ldD]
   float tau;
-  float* dencout;          // [B, ldE]
+  float* dsel;             // [B, ldS] gradient in the compact head layout (pads zero)
 };
 
 // dst[dst_off + i*dst_si + j*dst_sj] = sum_s src[src_off + s*slab_stride + i*src_ld + j]
@@ -132,7 +158,10 @@ size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes, int ldx, int 
 int loss_set_lds_limit(size_t lds_bytes);
 int launch_loss(const LossArgs& a, bool grad, int kmax, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s);
 int launch_expand(const suave_plan* p, const int32_t* enc_src_dev, const suave_batch_t& b, float* x, hipStream_t s);
-int launch_latent_fwd(const LatentFwdArgs& a, hipStream_t s);
+int launch_assign(const LatentFwdArgs& a, hipStream_t s);
+int launch_group(const GroupArgs& a, hipStream_t s);
+int launch_reparam(const LatentFwdArgs& a, hipStream_t s);
+int launch_head_reduce(const HeadReduceArgs& a, hipStream_t s);
 int launch_latent_bwd(const LatentBwdArgs& a, hipStream_t s);
 int launch_posterior_stats(const float* encout, int ldE, int K, int D, int n_rows, float inv_temp, float* enc_out_user,
                            float* post_mean, float* post_logvar, float* probs, hipStream_t s);

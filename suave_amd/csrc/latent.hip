@@ -6,6 +6,8 @@
 // :1573-1598 (assignment + reparam), :2924-2942, :2944-2964
 // (_mixture_posterior_statistics); torch F.gumbel_softmax.
 #include "kernels.h"
+#include <algorithm>
+
 #include "detmath.h"
 
 namespace suave {
@@ -44,86 +46,136 @@ __global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_
 }
 
 
-// supervised: y_soft = softmax((logits + g)/tau), k = argmax, z = mu_k + eps * exp(lv_k / 2)
-__global__ __launch_bounds__(256) void k_latent_fwd(LatentFwdArgs a) {
-  __shared__ int k_s[64];
-  const int tid = threadIdx.x;
+// supervised, step 1: y_soft = softmax((logits + g)/tau), k = argmax; one row per thread.  Also the first
+// pass of the stable counting sort by component: the row's rank among the rows of its 256-row block that
+// chose the same component, and the block's per-component counts.
+__global__ __launch_bounds__(256) void k_assign(LatentFwdArgs a) {
+  __shared__ int wcnt[4][SUAVE_MAX_COMPONENTS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Philox rng(a.seed);
-  for (int r0 = blockIdx.x * 64; r0 < a.n_rows; r0 += gridDim.x * 64) {
-    const int nrows = min(64, a.n_rows - r0);
-    if (tid < nrows) {
-      const int r = r0 + tid;
-      const uint32_t rid = a.row_index ? (uint32_t)a.row_index[r] : (uint32_t)(a.row_begin + r);
-      const float* lg = a.encout + (size_t)r * a.ldE;
-      float t[SUAVE_MAX_COMPONENTS];
-      float best = -INFINITY;
-      int kb = 0;
+  const int r = blockIdx.x * 256 + tid;
+  const bool valid = r < a.n_rows;
+  int kb = -1;
+  if (valid) {
+    const uint32_t rid = a.row_index ? (uint32_t)a.row_index[r] : (uint32_t)(a.row_begin + r);
+    const float* lg = a.sel + (size_t)r * a.ldS;
+    float t[SUAVE_MAX_COMPONENTS];
+    float best = -INFINITY;
+    kb = 0;
 #pragma unroll 1
-      for (int j = 0; j < a.K; ++j) {
-        float e;
-        if (a.exp_noise) {
-          e = a.exp_noise[(size_t)r * a.K + j];
-        } else {
-          const uint4 w = rng(rid, (uint32_t)(j >> 2), kStreamGumbel, (uint32_t)a.step);
-          const uint32_t word = (j & 3) == 0 ? w.x : (j & 3) == 1 ? w.y : (j & 3) == 2 ? w.z : w.w;
-          e = -__logf(u01(word));
-        }
-        // Gumbel noise g = -log(e); the assignment path is deterministic binary32
-        const float tj = detm::dvd(detm::sub(lg[j], detm::log(e)), a.tau);
-        t[j] = tj;
-        if (tj > best) { best = tj; kb = j; }
+    for (int j = 0; j < a.K; ++j) {
+      float e;
+      if (a.exp_noise) {
+        e = a.exp_noise[(size_t)r * a.K + j];
+      } else {
+        const uint4 w = rng(rid, (uint32_t)(j >> 2), kStreamGumbel, (uint32_t)a.step);
+        const uint32_t word = (j & 3) == 0 ? w.x : (j & 3) == 1 ? w.y : (j & 3) == 2 ? w.z : w.w;
+        e = -__logf(u01(word));
       }
-      float sum = 0.f;
-#pragma unroll 1
-      for (int j = 0; j < a.K; ++j) { t[j] = __expf(t[j] - best); sum += t[j]; }
-      const float inv = 1.0f / sum;
-#pragma unroll 1
-      for (int j = 0; j < a.K; ++j) a.ysoft[(size_t)r * a.ldK + j] = t[j] * inv;
-      a.kidx[r] = kb;
-      if (a.comp_out) a.comp_out[r] = kb;
-      k_s[tid] = kb;
+      // Gumbel noise g = -log(e); the assignment path is deterministic binary32
+      const float tj = detm::dvd(detm::sub(lg[j], detm::log(e)), a.tau);
+      t[j] = tj;
+      if (tj > best) { best = tj; kb = j; }
     }
-    __syncthreads();
-    const int dq = (a.D + 3) / 4;
-    for (int idx = tid; idx < nrows * dq; idx += 256) {
-      const int lr = idx / dq, q = idx % dq;
-      const int r = r0 + lr, k = k_s[lr];
+    float sum = 0.f;
+#pragma unroll 1
+    for (int j = 0; j < a.K; ++j) { t[j] = __expf(t[j] - best); sum += t[j]; }
+    const float inv = 1.0f / sum;
+#pragma unroll 1
+    for (int j = 0; j < a.K; ++j) a.ysoft[(size_t)r * a.ldK + j] = t[j] * inv;
+    a.kidx[r] = kb;
+    if (a.comp_out) a.comp_out[r] = kb;
+  }
+  int rank = 0;
+#pragma unroll 1
+  for (int c = 0; c < a.K; ++c) {
+    const unsigned long long m = __ballot(kb == c);
+    if (kb == c) rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[wave][c] = __popcll(m);
+  }
+  __syncthreads();
+  if (valid) {
+    for (int w = 0; w < wave; ++w) rank += wcnt[w][kb];
+    a.lrank[r] = rank;
+  }
+  if (tid < a.K) a.blk_cnt[(size_t)blockIdx.x * a.K + tid] = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+}
+
+// Counting sort, pass 2 (one block): per-component totals -> chunk table (every component's rows start on
+// a chunk boundary) and the first sorted position of each (block, component) run.
+__global__ __launch_bounds__(256) void k_group_scan(GroupArgs a) {
+  __shared__ int tot[SUAVE_MAX_COMPONENTS], seg[SUAVE_MAX_COMPONENTS];
+  const int tid = threadIdx.x;
+  if (tid < a.K) {
+    int t = 0;
+    for (int b = 0; b < a.n_blocks; ++b) {
+      const int n = a.blk_cnt[(size_t)b * a.K + tid];
+      a.blk_base[(size_t)b * a.K + tid] = t;
+      t += n;
+    }
+    tot[tid] = t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int ch = 0;
+    for (int c = 0; c < a.K; ++c) {
+      a.chunk_begin[c] = ch;
+      seg[c] = ch * kGroupRows;
+      const int n = (tot[c] + kGroupRows - 1) / kGroupRows;
+      for (int i = 0; i < n && ch < a.n_chunks_max; ++i) a.chunk_comp[ch++] = c;
+    }
+    a.chunk_begin[a.K] = ch;
+    for (; ch < a.n_chunks_max; ++ch) a.chunk_comp[ch] = -1;
+  }
+  __syncthreads();
+  for (int i = tid; i < a.n_blocks * a.K; i += 256) a.blk_base[i] += seg[i % a.K];
+}
+
+// Counting sort, pass 3: sorted position of every row.
+__global__ __launch_bounds__(256) void k_group_scatter(GroupArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < a.n_rows) a.perm[a.blk_base[(size_t)blockIdx.x * a.K + a.kidx[r]] + a.lrank[r]] = r;
+}
+
+// supervised, step 2: z = mu_k + eps * exp(lv_k / 2) from the selected component's head outputs
+__global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
+  const Philox rng(a.seed);
+  const int dq = (a.D + 3) / 4;
+  const int64_t total = (int64_t)a.n_rows * dq;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int r = (int)(idx / dq), q = (int)(idx % dq);
+    float ev[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.eps_in == nullptr) {
       const uint32_t rid = a.row_index ? (uint32_t)a.row_index[r] : (uint32_t)(a.row_begin + r);
-      float ev[4];
-      if (a.eps_in == nullptr) {
-        const uint4 w = rng(rid, (uint32_t)q, kStreamEps, (uint32_t)a.step);
-        const float2 n0 = normal2(w.x, w.y), n1 = normal2(w.z, w.w);
-        ev[0] = n0.x; ev[1] = n0.y; ev[2] = n1.x; ev[3] = n1.y;
-      }
-      const float* mu = a.encout + (size_t)r * a.ldE + a.K + k * a.D;
-      const float* lv = mu + a.K * a.D;
+      const uint4 w = rng(rid, (uint32_t)q, kStreamEps, (uint32_t)a.step);
+      const float2 n0 = normal2(w.x, w.y), n1 = normal2(w.z, w.w);
+      ev[0] = n0.x; ev[1] = n0.y; ev[2] = n1.x; ev[3] = n1.y;
+    }
+    const float* mu = a.sel + (size_t)r * a.ldS + a.ldK;
+    const float* lv = mu + a.ldD;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int d = q * 4 + e;
-        if (d >= a.D) break;
-        const float eps = a.eps_in ? a.eps_in[(size_t)r * a.D + d] : ev[e];
-        const float lvc = fminf(fmaxf(lv[d], kLogvarMin), kLogvarMax);
-        const float zz = mu[d] + eps * __expf(0.5f * lvc);
-        a.z[(size_t)r * a.ldD + d] = zz;
-        a.eps_buf[(size_t)r * a.ldD + d] = eps;
-        if (a.latent_out) a.latent_out[(size_t)r * a.D + d] = zz;
-      }
+    for (int e = 0; e < 4; ++e) {
+      const int d = q * 4 + e;
+      if (d >= a.D) break;
+      const float eps = a.eps_in ? a.eps_in[(size_t)r * a.D + d] : ev[e];
+      const float lvc = fminf(fmaxf(lv[d], kLogvarMin), kLogvarMax);
+      const float zz = mu[d] + eps * __expf(0.5f * lvc);
+      a.z[(size_t)r * a.ldD + d] = zz;
+      a.eps_buf[(size_t)r * a.ldD + d] = eps;
+      if (a.latent_out) a.latent_out[(size_t)r * a.D + d] = zz;
     }
-    __syncthreads();
   }
 }
 
 
-// Straight-through Gumbel path + scatter of the selected component's gradients
-// (SURVEY Appendix A): all other entries of d(enc_out) are zero.
+// Straight-through Gumbel path + the selected component's mu / logvar gradients in the compact head
+// layout: every other entry of d(enc_out) is zero and is never materialised.
 __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
-  __shared__ int k_s[64];
   const int tid = threadIdx.x;
   for (int r0 = blockIdx.x * 64; r0 < a.n_rows; r0 += gridDim.x * 64) {
     const int nrows = min(64, a.n_rows - r0);
     if (tid < nrows) {
       const int r = r0 + tid;
-      k_s[tid] = a.kidx[r];
       const float* ys = a.ysoft + (size_t)r * a.ldK;
       float ds[SUAVE_MAX_COMPONENTS];
       float inner = 0.f;
@@ -136,36 +188,57 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
       }
       const float inv_tau = 1.0f / a.tau;
 #pragma unroll 1
-      for (int j = 0; j < a.K; ++j)
-        a.dencout[(size_t)r * a.ldE + j] = ys[j] * (ds[j] - inner) * inv_tau + a.gkl_logit[(size_t)r * a.ldK + j];
+      for (int j = 0; j < a.ldK; ++j)
+        a.dsel[(size_t)r * a.ldS + j] =
+            j < a.K ? ys[j] * (ds[j] - inner) * inv_tau + a.gkl_logit[(size_t)r * a.ldK + j] : 0.f;
     }
-    __syncthreads();
-    const int kd = a.K * a.D;
-    const int width = a.ldE - a.K;  // mu | logvar | pad
+    const int width = 2 * a.ldD;
     for (int idx = tid; idx < nrows * width; idx += 256) {
       const int lr = idx / width, c = idx % width;
-      const int r = r0 + lr, k = k_s[lr];
+      const int r = r0 + lr;
+      const bool is_lv = c >= a.ldD;
+      const int d = is_lv ? c - a.ldD : c;
       float v = 0.f;
-      if (c < 2 * kd) {
-        const bool is_lv = c >= kd;
-        const int cc = is_lv ? c - kd : c;
-        const int j = cc / a.D, d = cc % a.D;
-        if (j == k) {
-          const float g = a.dz[(size_t)r * a.ldD + d];
-          if (!is_lv) {
-            v = g + a.gkl_mu[(size_t)r * a.ldD + d];
-          } else {
-            const float raw = a.encout[(size_t)r * a.ldE + a.K + c];
-            if (raw >= kLogvarMin && raw <= kLogvarMax) {  // clamp passes gradient inside its range only
-              const float eps = a.eps_buf[(size_t)r * a.ldD + d];
-              v = g * eps * 0.5f * __expf(0.5f * raw) + a.gkl_lv[(size_t)r * a.ldD + d];
-            }
+      if (d < a.D) {
+        const float g = a.dz[(size_t)r * a.ldD + d];
+        if (!is_lv) {
+          v = g + a.gkl_mu[(size_t)r * a.ldD + d];
+        } else {
+          const float raw = a.sel[(size_t)r * a.ldS + a.ldK + c];
+          if (raw >= kLogvarMin && raw <= kLogvarMax) {  // clamp passes gradient inside its range only
+            const float eps = a.eps_buf[(size_t)r * a.ldD + d];
+            v = g * eps * 0.5f * __expf(0.5f * raw) + a.gkl_lv[(size_t)r * a.ldD + d];
           }
         }
       }
-      a.dencout[(size_t)r * a.ldE + a.K + c] = v;
+      a.dsel[(size_t)r * a.ldS + a.ldK + c] = v;
     }
-    __syncthreads();
+  }
+}
+
+// dW_head[row(q, c)][j] = sum over the chunks of component c (all chunks for the logits rows), fixed order.
+__global__ __launch_bounds__(256) void k_head_reduce(HeadReduceArgs a) {
+  const int n_head = a.K + 2 * a.K * a.D;
+  const int64_t total = (int64_t)n_head * (a.n_in + 1);
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int R = (int)(e / (a.n_in + 1)), j = (int)(e % (a.n_in + 1));
+    int q, s0, s1;
+    if (R < a.K) {
+      q = R; s0 = 0; s1 = a.chunk_begin[a.K];
+    } else {
+      const int t = R - a.K;
+      const bool is_lv = t >= a.K * a.D;
+      const int u = is_lv ? t - a.K * a.D : t;
+      const int c = u / a.D, d = u % a.D;
+      q = a.ldK + (is_lv ? a.ldD : 0) + d;
+      s0 = a.chunk_begin[c]; s1 = a.chunk_begin[c + 1];
+    }
+    const float* src = a.slab + (size_t)q * a.ldc + j;
+    const size_t stride = (size_t)a.ldS * a.ldc;
+    float t = 0.f;
+    for (int s = s0; s < s1; ++s) t += src[(size_t)s * stride];
+    if (j < a.n_in) a.grads[a.w_off + (size_t)R * a.ld + j] = t;
+    else a.grads[a.b_off + R] = t;
   }
 }
 
@@ -468,11 +541,37 @@ int launch_expand(const suave_plan* p, const int32_t* enc_src_dev, const suave_b
   return 0;
 }
 
-int launch_latent_fwd(const LatentFwdArgs& a, hipStream_t s) {
+int launch_assign(const LatentFwdArgs& a, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
-  const int grid = std::min((a.n_rows + 63) / 64, 2048);
   ProfScope prof_scope(kProfLatent, s);
-  hipLaunchKernelGGL(k_latent_fwd, dim3(grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_assign, dim3((a.n_rows + 255) / 256), dim3(256), 0, s, a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_group(const GroupArgs& a, hipStream_t s) {
+  if (a.n_rows <= 0) return 0;
+  ProfScope prof_scope(kProfLatent, s);
+  SUAVE_CHECK_HIP(hipMemsetAsync(a.perm, 0xFF, sizeof(int32_t) * (size_t)a.n_chunks_max * kGroupRows, s));
+  hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_group_scatter, dim3(a.n_blocks), dim3(256), 0, s, a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_reparam(const LatentFwdArgs& a, hipStream_t s) {
+  if (a.n_rows <= 0) return 0;
+  const int64_t total = (int64_t)a.n_rows * ((a.D + 3) / 4);
+  ProfScope prof_scope(kProfLatent, s);
+  hipLaunchKernelGGL(k_reparam, dim3((int)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_head_reduce(const HeadReduceArgs& a, hipStream_t s) {
+  const int64_t total = (int64_t)(a.K + 2 * a.K * a.D) * (a.n_in + 1);
+  ProfScope prof_scope(kProfReduce, s);
+  hipLaunchKernelGGL(k_head_reduce, dim3((int)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -387,8 +387,9 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
       const int rr = r0 + (v4 ? lr : 0);
       const int kk = k_s[lr];
       const int D = a.D;
-      const float* mu = a.encout + (size_t)rr * a.ldE + K + kk * D;
-      const float* lv = mu + K * D;
+      // compact head buffer: [logits (ldK) | mu of the selected component (ldD) | raw logvar (ldD)]
+      const float* mu = a.encout + (size_t)rr * a.ldE + a.ldK;
+      const float* lv = mu + a.ldD;
       const float* pm = a.params + a.prior_mu_off + kk * D;
       const float* plv = a.params + a.prior_logvar_off + kk * D;
       float gk = 0.f;
