@@ -231,8 +231,8 @@ int fwd_layer(const suave_plan* p, const float* params, const suave_layer_t& l, 
 }
 
 // data gradient: dA = (dC * W) [* relu/dropout mask of H]
-int bwd_data(const suave_plan* p, const float* params, const suave_layer_t& l, const float* dC, int lddc, float* dA,
-             int ldda, int rows, const float* H, float drop_p, hipStream_t s) {
+GemmArgs bwd_data_args(const float* params, const suave_layer_t& l, const float* dC, int lddc, float* dA, int ldda, int rows,
+                       const float* H, float drop_p) {
   GemmArgs g = gemm_base();
   g.A = dC; g.B = params + l.w_off; g.C = dA;
   g.M = rows; g.N = l.n_in; g.K = l.n_out;
@@ -241,12 +241,12 @@ int bwd_data(const suave_plan* p, const float* params, const suave_layer_t& l, c
   g.epi = H ? kEpiMaskBwd : kEpiBias;
   g.H = H;
   g.drop_p = drop_p;
-  return launch_gemm(g, p->n_cu, s);
+  return g;
 }
 
 // weight gradient into a slab + its reduction segments (weight, bias)
-int bwd_weight(const suave_plan* p, const suave_layer_t& l, const float* dC, int lddc, const float* A, int lda,
-               int rows, float* slab_base, size_t* slab_off, ReduceArgs* red, int* max_elems, hipStream_t s) {
+int bwd_weight_args(const suave_plan* p, const suave_layer_t& l, const float* dC, int lddc, const float* A, int lda,
+                    int rows, float* slab_base, size_t* slab_off, ReduceArgs* red, int* max_elems, GemmArgs* out) {
   const int ldc = round_up(l.n_in + 1, 4);
   const int splits = tn_splits(p, l.n_out, l.n_in, rows);
   GemmArgs g = gemm_base();
@@ -258,8 +258,6 @@ int bwd_weight(const suave_plan* p, const suave_layer_t& l, const float* dC, int
   g.splits = splits;
   g.slab_stride = (int64_t)l.n_out * ldc;
   g.ones_col = l.n_in;
-  int rc = launch_gemm(g, p->n_cu, s);
-  if (rc) return rc;
   SUAVE_REQUIRE(red->n_segs + 2 <= kMaxReduceSegs, "too many reduction segments");
   ReduceSeg w{};
   w.src_off = (int64_t)*slab_off; w.slab_stride = g.slab_stride; w.n_slabs = splits;
@@ -271,7 +269,29 @@ int bwd_weight(const suave_plan* p, const suave_layer_t& l, const float* dC, int
   red->segs[red->n_segs++] = bseg;
   *max_elems = std::max(*max_elems, l.n_out * l.n_in);
   *slab_off += (size_t)splits * l.n_out * ldc;
+  *out = g;
   return 0;
+}
+
+int bwd_data(const suave_plan* p, const float* params, const suave_layer_t& l, const float* dC, int lddc, float* dA,
+             int ldda, int rows, const float* H, float drop_p, hipStream_t s) {
+  return launch_gemm(bwd_data_args(params, l, dC, lddc, dA, ldda, rows, H, drop_p), p->n_cu, s);
+}
+
+int bwd_weight(const suave_plan* p, const suave_layer_t& l, const float* dC, int lddc, const float* A, int lda,
+               int rows, float* slab_base, size_t* slab_off, ReduceArgs* red, int* max_elems, hipStream_t s) {
+  GemmArgs g;
+  if (int rc = bwd_weight_args(p, l, dC, lddc, A, lda, rows, slab_base, slab_off, red, max_elems, &g)) return rc;
+  return launch_gemm(g, p->n_cu, s);
+}
+
+// both backward GEMMs of layer l in one launch: dW (slab) from (dC, A_in) and dA_in from (dC, W)
+int bwd_layer(const suave_plan* p, const float* params, const suave_layer_t& l, const float* dC, int lddc,
+              const float* A_in, int lda_in, float* dA_in, int ldda, int rows, const float* H_in, float drop_p,
+              float* slab_base, size_t* slab_off, ReduceArgs* red, int* max_elems, hipStream_t s) {
+  GemmArgs w;
+  if (int rc = bwd_weight_args(p, l, dC, lddc, A_in, lda_in, rows, slab_base, slab_off, red, max_elems, &w)) return rc;
+  return launch_gemm_pair(bwd_data_args(params, l, dC, lddc, dA_in, ldda, rows, H_in, drop_p), w, p->n_cu, s);
 }
 
 __global__ void k_sum_chunks(const float* part, int n_chunks, int n_rows, float* out) {
@@ -583,24 +603,23 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   int max_elems = 256;
 
   if (grad) {
-    // ---- decoder backward ----
-    const float* hlast = nh ? w.hd[nh - 1] : w.z;
-    const int ldh = nh ? p->ldH[nh - 1] : p->ldD;
-    if (int rc = bwd_weight(p, m.y_proj, w.y, p->ldY, hlast, ldh, B, w.slab, &slab_off, &red, &max_elems, s)) return rc;
-    const float* dcur = w.y;
-    int lddcur = p->ldY;
-    const suave_layer_t* lcur = &m.y_proj;
-    for (int i = nh - 1; i >= 0; --i) {
-      if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dhd[i], p->ldH[i], B, w.hd[i], drop_p, s)) return rc;
-      const float* ain = i > 0 ? w.hd[i - 1] : w.z;
-      const int ldain = i > 0 ? p->ldH[i - 1] : p->ldD;
-      if (int rc = bwd_weight(p, m.dec[i], w.dhd[i], p->ldH[i], ain, ldain, B, w.slab, &slab_off, &red, &max_elems, s))
-        return rc;
-      dcur = w.dhd[i];
-      lddcur = p->ldH[i];
-      lcur = &m.dec[i];
+    // ---- decoder backward: per layer, dW and d(input) in one launch ----
+    {
+      const float* dcur = w.y;
+      int lddcur = p->ldY;
+      const suave_layer_t* lcur = &m.y_proj;
+      for (int i = nh - 1; i >= -1; --i) {
+        const float* ain = i >= 0 ? w.hd[i] : w.z;          // input activation of layer lcur
+        const int ldain = i >= 0 ? p->ldH[i] : p->ldD;
+        float* dain = i >= 0 ? w.dhd[i] : w.dz;
+        if (int rc = bwd_layer(p, params, *lcur, dcur, lddcur, ain, ldain, dain, ldain, B, i >= 0 ? w.hd[i] : nullptr,
+                               i >= 0 ? drop_p : 0.f, w.slab, &slab_off, &red, &max_elems, s))
+          return rc;
+        dcur = dain;
+        lddcur = ldain;
+        if (i >= 0) lcur = &m.dec[i];
+      }
     }
-    if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dz, p->ldD, B, nullptr, 0.f, s)) return rc;
     // ---- latent backward ----
     {
       LatentBwdArgs a{};
@@ -620,29 +639,33 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
       g.a_kmajor = 1; g.b_kmajor = 1; g.epi = kEpiSlab; g.splits = w.n_chunks_max;
       g.slab_stride = (int64_t)ldS * ldc; g.ones_col = l.n_in; g.grouped = 2;
       head_geometry(g);
-      if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
+      GemmArgs d = gemm_base();  // d h = dsel * W[rows of the row's component], relu/dropout mask of h
+      if (nh > 0) {
+        d.A = w.dsel; d.B = params + m.enc_head.w_off; d.C = w.dhe[nh - 1];
+        d.M = Vg; d.N = m.enc_head.n_in; d.K = ldS; d.lda = ldS; d.ldb = m.enc_head.ld; d.ldc = p->ldH[nh - 1];
+        d.b_kmajor = 1; d.epi = kEpiMaskBwd; d.H = w.he[nh - 1]; d.drop_p = drop_p; d.grouped = 1; d.q0 = 0;
+        head_geometry(d);
+        if (int rc = launch_gemm_pair(d, g, p->n_cu, s)) return rc;
+      } else {
+        if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
+      }
       HeadReduceArgs h{};
       h.slab = w.gslab; h.chunk_begin = w.chunk_begin; h.K = K; h.D = D; h.ldK = p->ldK; h.ldD = p->ldD; h.ldS = ldS;
       h.n_in = l.n_in; h.ldc = ldc; h.grads = grads; h.w_off = l.w_off; h.b_off = l.b_off; h.ld = l.ld;
       if (int rc = launch_head_reduce(h, s)) return rc;
     }
-    if (nh > 0) {
-      GemmArgs g = gemm_base();  // d h = dsel * W[rows of the row's component], relu/dropout mask of h
-      g.A = w.dsel; g.B = params + m.enc_head.w_off; g.C = w.dhe[nh - 1];
-      g.M = Vg; g.N = m.enc_head.n_in; g.K = ldS; g.lda = ldS; g.ldb = m.enc_head.ld; g.ldc = p->ldH[nh - 1];
-      g.b_kmajor = 1; g.epi = kEpiMaskBwd; g.H = w.he[nh - 1]; g.drop_p = drop_p; g.grouped = 1; g.q0 = 0;
-      head_geometry(g);
-      if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
-    }
     // ---- encoder trunk backward ----
     for (int i = nh - 1; i >= 0; --i) {
       const float* ain = i > 0 ? w.he[i - 1] : w.x;
       const int ldain = i > 0 ? p->ldH[i - 1] : p->ldI;
-      if (int rc = bwd_weight(p, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, B, w.slab, &slab_off, &red, &max_elems, s))
-        return rc;
-      if (i > 0)
-        if (int rc = bwd_data(p, params, m.enc[i], w.dhe[i], p->ldH[i], w.dhe[i - 1], p->ldH[i - 1], B, w.he[i - 1], drop_p, s))
+      if (i > 0) {
+        if (int rc = bwd_layer(p, params, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, w.dhe[i - 1], ldain, B, w.he[i - 1],
+                               drop_p, w.slab, &slab_off, &red, &max_elems, s))
           return rc;
+      } else {
+        if (int rc = bwd_weight(p, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, B, w.slab, &slab_off, &red, &max_elems, s))
+          return rc;
+      }
     }
     // ---- prior gradients: (prior_terms^T * [onehot(k) | 1]) via the split GEMM ----
     {

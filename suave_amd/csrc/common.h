@@ -186,6 +186,7 @@ __host__ __device__ __forceinline__ int head_row(int q, int c, int K, int D, int
 }
 
 int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream);
+int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t stream);
 
 // ----- optional per-kernel-class timing with HIP events (suave_profile_*) -----
 enum ProfClass : int { kProfGemm = 0, kProfLoss, kProfLatent, kProfExpand, kProfReduce, kProfAdam, kProfSample, kProfOther, kProfCount };

@@ -39,15 +39,17 @@ __device__ __forceinline__ bool drop_keep(uint32_t hrow, uint32_t col, uint32_t 
   return hash32(hrow ^ (col * 0x85EBCA77u)) >= thr;
 }
 
+template <int WAVES_M, int WAVES_N>
+constexpr int gemm_smem_floats() { return 2 * BK * ((WAVES_M * 64 + PAD) + (WAVES_N * 64 + PAD)); }
+
+// One block's work: tile `bid` of split `bz`.
 template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int GRP, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, const int bz, float* smem, int* perm_s) {
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   constexpr int LDAS = BM + PAD, LDBS = BN + PAD;
   constexpr int NA = BM * BK / 4 / 256;  // float4 loads per thread for the A tile
   constexpr int NB = BN * BK / 4 / 256;
   static_assert(kGroupRows % BM == 0, "a row tile never straddles two component chunks");
-  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDAS + LDBS)];
-  __shared__ int perm_s[GRP == 2 ? kGroupRows : 1];
   float* As = smem;
   float* Bs = smem + 2 * BK * LDAS;
 
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   // XCD-aware tile order: blocks id, id+8, ... run on one XCD and share its L2,
   // so give them the column tiles of the same row tile (they re-read one A tile).
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-  int id = blockIdx.x, tile_m, tile_n;
+  int id = bid, tile_m, tile_n;
   {
     const int full = (tiles_m / 8) * 8;
     const int n_full = full * tiles_n;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   if (a.splits > 1 || GRP == 2) {
     int chunk = (a.K + a.splits - 1) / a.splits;
     chunk = (chunk + BK - 1) / BK * BK;
-    k_begin = blockIdx.z * chunk;
+    k_begin = bz * chunk;
     k_end = min(a.K, k_begin + chunk);
   }
   const int nk = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   // Grouped forms: the component of this tile / chunk; unused chunks have no work (block-uniform exit).
   int comp = 0;
   if (GRP == 1) comp = a.chunk_comp[m0 / kGroupRows];
-  if (GRP == 2) comp = a.chunk_comp[blockIdx.z];
+  if (GRP == 2) comp = a.chunk_comp[bz];
   if (GRP != 0 && comp < 0) return;
   if (GRP == 2) {
     perm_s[tid] = a.perm[k_begin + tid];  // kGroupRows == blockDim.x
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   if (t < nk) compute(0);
 
   // ---- epilogue -------------------------------------------------------------
-  float* Cout = a.C + (EPI == kEpiSlab ? (size_t)blockIdx.z * a.slab_stride : 0);
+  float* Cout = a.C + (EPI == kEpiSlab ? (size_t)bz * a.slab_stride : 0);
   if (do_bias && m0 + tid < a.M) Cout[(size_t)(m0 + tid) * a.ldc + a.ones_col] = bias_acc;
   const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const uint32_t thr = a.drop_p > 0.f ? static_cast<uint32_t>(fminf(a.drop_p * 4294967296.0f, 4294967040.0f)) : 0u;
@@ -333,11 +335,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   }
 }
 
+template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int GRP, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<WAVES_M, WAVES_N>()];
+  __shared__ int perm_s[GRP == 2 ? kGroupRows : 1];
+  gemm_body<WAVES_M, WAVES_N, A_KM, B_KM, GRP, EPI>(a, blockIdx.x, blockIdx.z, smem, perm_s);
+}
+
+// The two backward GEMMs of one layer in one launch: they read the same dC and do not depend on each
+// other.  The weight-gradient blocks (few and long: one per CU) are dispatched first, the data-gradient
+// blocks fill the rest of each CU.
+template <int DM, int DN, int D_GRP, int D_EPI, int WM, int WN, int W_GRP>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(GemmArgs d, GemmArgs w, int w_blocks, int w_tiles) {
+  constexpr int kSmem = gemm_smem_floats<DM, DN>() > gemm_smem_floats<WM, WN>() ? gemm_smem_floats<DM, DN>()
+                                                                                : gemm_smem_floats<WM, WN>();
+  __shared__ __attribute__((aligned(16))) float smem[kSmem];
+  __shared__ int perm_s[W_GRP == 2 ? kGroupRows : 1];
+  const int b = blockIdx.x;
+  if (b < w_blocks) gemm_body<WM, WN, true, true, W_GRP, kEpiSlab>(w, b % w_tiles, b / w_tiles, smem, perm_s);
+  else gemm_body<DM, DN, false, true, D_GRP, D_EPI>(d, b - w_blocks, 0, smem, perm_s);
+}
+
 }  // namespace
 
-int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
-  (void)n_cu;
-  if (a.M <= 0 || a.N <= 0) return 0;
+namespace {
+int check_gemm(const GemmArgs& a) {
   SUAVE_REQUIRE(a.lda % 4 == 0 && a.ldb % 4 == 0, "gemm: leading dimensions must be multiples of 4 floats");
   SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0,
                 "gemm: operands must be 16-byte aligned");
@@ -353,12 +375,24 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   SUAVE_REQUIRE(a.ldc >= a.N + (a.ones_col >= 0 ? 1 : 0), "gemm: ldc too small");
   SUAVE_REQUIRE(a.ones_col < 0 || a.ones_col == a.N, "gemm: the bias column sits right after the N real columns");
   SUAVE_REQUIRE(a.epi != kEpiSlab || a.splits >= 1, "gemm: bad split count");
+  return 0;
+}
+inline bool gemm_narrow(const GemmArgs& a) { return a.N <= 64; }
+inline int gemm_tiles(const GemmArgs& a) {
+  return gemm_narrow(a) ? ((a.M + 255) / 256) * ((a.N + 63) / 64) : ((a.M + 127) / 128) * ((a.N + 127) / 128);
+}
+}  // namespace
+
+int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
+  (void)n_cu;
+  if (a.M <= 0 || a.N <= 0) return 0;
+  if (int rc = check_gemm(a)) return rc;
   const int splits = a.epi == kEpiSlab ? a.splits : 1;
   GemmArgs args = a;
   args.splits = splits;
   ProfScope prof_scope(kProfGemm, stream);
-  const bool narrow = a.N <= 64;
-  const int tiles = narrow ? ((a.M + 255) / 256) * ((a.N + 63) / 64) : ((a.M + 127) / 128) * ((a.N + 127) / 128);
+  const bool narrow = gemm_narrow(a);
+  const int tiles = gemm_tiles(a);
   const dim3 grid(tiles, 1, splits), block(256);
 #define SUAVE_GEMM_LAUNCH(AKM, BKM, GRP, EPI)                                                              \
   do {                                                                                                     \
@@ -378,6 +412,42 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   else if (a.a_kmajor && a.b_kmajor && e == kEpiSlab) SUAVE_GEMM_LAUNCH(true, true, 0, kEpiSlab);
   else SUAVE_REQUIRE(false, "gemm: unsupported operand layout / epilogue combination");
 #undef SUAVE_GEMM_LAUNCH
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// d: data-gradient GEMM (A k-contiguous, B k-major, kEpiMaskBwd or kEpiBias); w: weight-gradient GEMM of the
+// same layer (both k-major, kEpiSlab).  Combinations without a fused instantiation run as two launches.
+int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t stream) {
+  const bool fusable = d.M > 0 && d.N > 0 && w.M > 0 && w.N > 0 && !d.a_kmajor && d.b_kmajor && w.a_kmajor && w.b_kmajor &&
+                       w.epi == kEpiSlab && (d.epi == kEpiMaskBwd || d.epi == kEpiBias) &&
+                       ((d.grouped == 0 && w.grouped == 0) || (d.grouped == 1 && w.grouped == 2 && d.epi == kEpiMaskBwd));
+  if (!fusable) {
+    if (int rc = launch_gemm(w, n_cu, stream)) return rc;
+    return launch_gemm(d, n_cu, stream);
+  }
+  if (int rc = check_gemm(d)) return rc;
+  if (int rc = check_gemm(w)) return rc;
+  GemmArgs da = d, wa = w;
+  da.splits = 1;
+  const int w_tiles = gemm_tiles(w), w_blocks = w_tiles * w.splits, d_tiles = gemm_tiles(d);
+  const bool dn = gemm_narrow(d), wn = gemm_narrow(w);
+  ProfScope prof_scope(kProfGemm, stream);
+  const dim3 grid(w_blocks + d_tiles), block(256);
+#define SUAVE_PAIR(DM, DN, DG, DE, WM, WN, WG) \
+  hipLaunchKernelGGL((gemm_pair_kernel<DM, DN, DG, DE, WM, WN, WG>), grid, block, 0, stream, da, wa, w_blocks, w_tiles)
+#define SUAVE_PAIR_SHAPES(DG, DE, WG)                  \
+  do {                                                 \
+    if (!dn && !wn) SUAVE_PAIR(2, 2, DG, DE, 2, 2, WG); \
+    else if (!dn && wn) SUAVE_PAIR(2, 2, DG, DE, 4, 1, WG); \
+    else if (dn && !wn) SUAVE_PAIR(4, 1, DG, DE, 2, 2, WG); \
+    else SUAVE_PAIR(4, 1, DG, DE, 4, 1, WG);            \
+  } while (0)
+  if (d.grouped == 1) SUAVE_PAIR_SHAPES(1, kEpiMaskBwd, 2);
+  else if (d.epi == kEpiMaskBwd) SUAVE_PAIR_SHAPES(0, kEpiMaskBwd, 0);
+  else SUAVE_PAIR_SHAPES(0, kEpiBias, 0);
+#undef SUAVE_PAIR_SHAPES
+#undef SUAVE_PAIR
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -105,15 +105,30 @@ __global__ __launch_bounds__(256) void k_assign(LatentFwdArgs a) {
 // a chunk boundary) and the first sorted position of each (block, component) run.
 __global__ __launch_bounds__(256) void k_group_scan(GroupArgs a) {
   __shared__ int tot[SUAVE_MAX_COMPONENTS], seg[SUAVE_MAX_COMPONENTS];
-  const int tid = threadIdx.x;
-  if (tid < a.K) {
-    int t = 0;
-    for (int b = 0; b < a.n_blocks; ++b) {
-      const int n = a.blk_cnt[(size_t)b * a.K + tid];
-      a.blk_base[(size_t)b * a.K + tid] = t;
-      t += n;
+  __shared__ int wtot[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // exclusive prefix over the blocks, one component at a time, 256 blocks per round
+  for (int c = 0; c < a.K; ++c) {
+    int carry = 0;
+    for (int b0 = 0; b0 < a.n_blocks; b0 += 256) {
+      const int b = b0 + tid;
+      const int v = b < a.n_blocks ? a.blk_cnt[(size_t)b * a.K + c] : 0;
+      int incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+      }
+      if (lane == 63) wtot[wave] = incl;
+      __syncthreads();
+      int woff = 0;
+      for (int w = 0; w < wave; ++w) woff += wtot[w];
+      const int total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+      if (b < a.n_blocks) a.blk_base[(size_t)b * a.K + c] = carry + woff + incl - v;
+      carry += total;
+      __syncthreads();
     }
-    tot[tid] = t;
+    if (tid == 0) tot[c] = carry;
   }
   __syncthreads();
   if (tid == 0) {
@@ -235,8 +250,16 @@ __global__ __launch_bounds__(256) void k_head_reduce(HeadReduceArgs a) {
     }
     const float* src = a.slab + (size_t)q * a.ldc + j;
     const size_t stride = (size_t)a.ldS * a.ldc;
-    float t = 0.f;
-    for (int s = s0; s < s1; ++s) t += src[(size_t)s * stride];
+    float t = 0.f;  // fixed summation order; 8 independent loads in flight
+    int s = s0;
+    for (; s + 8 <= s1; s += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; s < s1; ++s) t += src[(size_t)s * stride];
     if (j < a.n_in) a.grads[a.w_off + (size_t)R * a.ld + j] = t;
     else a.grads[a.b_off + R] = t;
   }
