@@ -180,7 +180,7 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
     slab += (size_t)tn_splits(p, l->n_out, l->n_in, rows) * l->n_out * ldc;
   }
   const int lg = loss_grid(p, rows);
-  slab += (size_t)lg * m.head_len;
+  slab += (size_t)lg * m.head_len + 4;
   {
     const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components;
     slab += (size_t)tn_splits(p, Mt, Nt, rows) * Mt * round_up(Nt + 1, 4);
@@ -365,7 +365,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
   const int ldT = round_up(K * D + D, 4);
   size_t slab_off = 0;
   float* head_slab = w.slab;
-  slab_off += (size_t)lgrid * m.head_len;
+  slab_off += ((size_t)lgrid * m.head_len + 3) & ~size_t(3);  // GEMM slabs start 16-byte aligned
   {
     LossArgs a{};
     a.cols = p->cols_dev; a.chunks = p->chunks_dev; a.params = params; a.y = w.y; a.batch = *batch;
@@ -568,7 +568,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   const int ldT = round_up(2 * m.latent_dim + m.n_components, 4);
   size_t slab_off = 0;
   float* head_slab = w.slab;
-  slab_off += (size_t)lgrid * m.head_len;
+  slab_off += ((size_t)lgrid * m.head_len + 3) & ~size_t(3);  // GEMM slabs start 16-byte aligned
   {
     LossArgs a{};
     a.cols = p->cols_dev; a.chunks = p->chunks_dev; a.params = params; a.y = w.y; a.batch = *batch;
@@ -810,11 +810,14 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
   p->max_classes = max_classes;
   // chunking of the schema for the loss kernel (LDS budget)
   {
-    const int kChunkY = 384;
+    // chunks of about equal y width, at most ~96 floats of y per tile row (LDS budget: two 8-wave blocks per CU)
+    const int kChunkY = 96;
+    const int n_target = std::max(1, (m.total_y + kChunkY - 1) / kChunkY);
+    const int y_target = (m.total_y + n_target - 1) / n_target;
     ColChunk cur{0, 0, 0, 0};
     int hw_max = 0, hw_start = m.head_off, max_y = 0;
     for (int c = 0; c < m.n_cols; ++c) {
-      if (cur.col_end > cur.col_begin && cur.y_len + cols[c].y_dim > kChunkY) {
+      if (cur.col_end > cur.col_begin && cur.y_len + cols[c].y_dim > y_target) {
         p->chunks_host.push_back(cur);
         hw_max = std::max(hw_max, cols[c].w_off - hw_start);
         hw_start = cols[c].w_off;

@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 OUT=../libsuave_hip.so
 OBJ=../../build/obj
 mkdir -p "$OBJ"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $SUAVE_EXTRA_FLAGS"
 pids=()
 for f in gemm loss latent optim sample api; do
   [ -f $f.hip ] || continue

@@ -13,6 +13,8 @@
 // MFMA tiles, K step 16, LDS tiles stored k-major ([k][i]) so that the MFMA
 // operand fetch (lane l: i = l&31, k = l>>5) is a conflict-free ds_read_b32,
 // double-buffered with the next tile's global loads in flight during the MFMAs.
+#include <cstring>
+
 #include "common.h"
 
 namespace suave {
@@ -33,11 +35,9 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   return x;
 }
 
-// Stateless dropout decision keyed by (seed, step, stream, table row, column): row part, then column part.
+// Stateless dropout decision keyed by (seed, step, stream, table row, column): this is the row part; the
+// epilogue mixes in the column pair and spends 16 hash bits per element.
 __device__ __forceinline__ uint32_t drop_row_hash(uint32_t key, uint32_t row_id) { return hash32(row_id * 0x9E3779B1u + key); }
-__device__ __forceinline__ bool drop_keep(uint32_t hrow, uint32_t col, uint32_t thr) {
-  return hash32(hrow ^ (col * 0x85EBCA77u)) >= thr;
-}
 
 template <int WAVES_M, int WAVES_N>
 constexpr int gemm_smem_floats() { return 2 * BK * ((WAVES_M * 64 + PAD) + (WAVES_N * 64 + PAD)); }
@@ -275,61 +275,101 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   if (t < nk) compute(0);
 
   // ---- epilogue -------------------------------------------------------------
+  // The accumulators (lane = column, 4 consecutive rows per register group) go through a per-wave LDS
+  // patch of 8 rows x 64 columns and come back as float4 along the row, so that C is written (and the
+  // activation mask read) with 16-byte accesses: a wave store covers 4 rows x 256 contiguous bytes.
   float* Cout = a.C + (EPI == kEpiSlab ? (size_t)bz * a.slab_stride : 0);
   if (do_bias && m0 + tid < a.M) Cout[(size_t)(m0 + tid) * a.ldc + a.ones_col] = bias_acc;
   const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-  const uint32_t thr = a.drop_p > 0.f ? static_cast<uint32_t>(fminf(a.drop_p * 4294967296.0f, 4294967040.0f)) : 0u;
+  // keep decision: 16 bits of a per-(row, column pair) hash against round(p * 65536)
+  const uint32_t thr16 = a.drop_p > 0.f ? min(65535u, static_cast<uint32_t>(a.drop_p * 65536.0f + 0.5f)) : 0u;
   const uint32_t key = hash32(static_cast<uint32_t>(a.seed) ^ hash32(static_cast<uint32_t>(a.seed >> 32) + a.stream_id)) ^
                        hash32(static_cast<uint32_t>(a.step) * 0x9E3779B1u + 0x632BE5ABu);
   const bool hashed_drop = EPI == kEpiReluDrop && a.drop_p > 0.f && a.keep == nullptr;
-  float bias[2] = {0.f, 0.f};
+  constexpr int LDP = 68;
+  __syncthreads();  // every wave is done with the operand tiles
+  float* patch = smem + wave * (8 * LDP);
+  const int c4 = (lane & 15) * 4;
+  const int col = n0 + wn * 64 + c4;  // first of this lane's 4 columns
+  const int ncol = a.N - col;         // valid columns among them (may be <= 0 or >= 4)
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
   if ((EPI == kEpiBias || EPI == kEpiReluDrop) && a.bias != nullptr) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + wn * 64 + ni * 32 + l31;
-      if (col < a.N) {
-        const int bi = GRP == 1 ? head_row(a.q0 + col, comp, a.hK, a.hD, a.hldK, a.hldD) : col;
-        if (bi >= 0) bias[ni] = a.bias[bi];
+    for (int e = 0; e < 4; ++e) {
+      if (e < ncol) {
+        const int bi = GRP == 1 ? head_row(a.q0 + col + e, comp, a.hK, a.hD, a.hldK, a.hldD) : col + e;
+        if (bi >= 0) bias4[e] = a.bias[bi];
       }
     }
   }
+  if (act) {
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int row_base = m0 + wm * 64 + mi * 32 + 4 * kh;
-    if (row_base - 4 * kh >= a.M) continue;
+    for (int mi = 0; mi < 2; ++mi) {
+      const int row_tile = m0 + wm * 64 + mi * 32;
+      if (row_tile >= a.M) continue;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row_base + (r & 3) + 8 * (r >> 2);
-      if (row >= a.M) continue;
-      int orow = row;
-      if (GRP == 1) {
-        orow = a.perm[row];
-        if (orow < 0) continue;
-      }
-      uint32_t hrow = 0;
-      if (hashed_drop) {
-        const uint32_t rid = a.row_ids ? static_cast<uint32_t>(a.row_ids[row]) : static_cast<uint32_t>(a.row_begin + row);
-        hrow = drop_row_hash(key, rid);
-      }
+      for (int g = 0; g < 4; ++g) {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int col = n0 + wn * 64 + ni * 32 + l31;
-        if (col >= a.N) continue;
-        float v = acc[mi][ni][r];
-        const size_t off = (size_t)orow * a.ldc + col;
-        if (EPI == kEpiBias) {
-          v += bias[ni];
-        } else if (EPI == kEpiReluDrop) {
-          v = fmaxf(v + bias[ni], 0.f);
-          if (a.drop_p > 0.f) {
-            const bool keep = a.keep != nullptr ? a.keep[(size_t)row * a.N + col] != 0
-                                                : drop_keep(hrow, static_cast<uint32_t>(col), thr);
-            v = keep ? v * inv_keep : 0.f;
-          }
-        } else if (EPI == kEpiMaskBwd) {
-          v = a.H[off] > 0.f ? v * inv_keep : 0.f;
+        for (int j = 0; j < 4; ++j) {
+          patch[(4 * kh + j) * LDP + l31] = acc[mi][0][g * 4 + j];
+          patch[(4 * kh + j) * LDP + 32 + l31] = acc[mi][1][g * 4 + j];
         }
-        Cout[off] = v;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int lrow = (lane >> 4) + 4 * h;
+          const float4 v4 = *reinterpret_cast<const float4*>(patch + lrow * LDP + c4);
+          const int row = row_tile + 8 * g + lrow;
+          if (row >= a.M || ncol <= 0) continue;
+          int orow = row;
+          if (GRP == 1) {
+            orow = a.perm[row];
+            if (orow < 0) continue;
+          }
+          float v[4] = {v4.x, v4.y, v4.z, v4.w};
+          const size_t off = (size_t)orow * a.ldc + col;
+          if (EPI == kEpiBias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+          } else if (EPI == kEpiReluDrop) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
+            if (a.drop_p > 0.f) {
+              if (hashed_drop) {
+                const uint32_t rid = a.row_ids ? static_cast<uint32_t>(a.row_ids[row]) : static_cast<uint32_t>(a.row_begin + row);
+                const uint32_t hrow = drop_row_hash(key, rid);
+                const uint32_t h0 = hash32(hrow ^ (static_cast<uint32_t>(col >> 1) * 0x85EBCA77u));
+                const uint32_t h1 = hash32(hrow ^ (static_cast<uint32_t>((col >> 1) + 1) * 0x85EBCA77u));
+                v[0] = (h0 & 0xFFFFu) >= thr16 ? v[0] * inv_keep : 0.f;
+                v[1] = (h0 >> 16) >= thr16 ? v[1] * inv_keep : 0.f;
+                v[2] = (h1 & 0xFFFFu) >= thr16 ? v[2] * inv_keep : 0.f;
+                v[3] = (h1 >> 16) >= thr16 ? v[3] * inv_keep : 0.f;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (e < ncol) v[e] = a.keep[(size_t)row * a.N + col + e] != 0 ? v[e] * inv_keep : 0.f;
+              }
+            }
+          } else if (EPI == kEpiMaskBwd) {
+            if (ncol >= 4) {
+              const float4 hv = *reinterpret_cast<const float4*>(a.H + off);
+              v[0] = hv.x > 0.f ? v[0] * inv_keep : 0.f;
+              v[1] = hv.y > 0.f ? v[1] * inv_keep : 0.f;
+              v[2] = hv.z > 0.f ? v[2] * inv_keep : 0.f;
+              v[3] = hv.w > 0.f ? v[3] * inv_keep : 0.f;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (e < ncol) v[e] = a.H[off + e] > 0.f ? v[e] * inv_keep : 0.f;
+            }
+          }
+          if (ncol >= 4) {
+            *reinterpret_cast<float4*>(Cout + off) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {  // ragged right edge: never touch the columns past N (the slab's bias column lives there)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (e < ncol) Cout[off + e] = v[e];
+          }
+        }
       }
     }
   }
@@ -361,7 +401,9 @@ __global__ __launch_bounds__(256) void gemm_pair_kernel(GemmArgs d, GemmArgs w, 
 namespace {
 int check_gemm(const GemmArgs& a) {
   SUAVE_REQUIRE(a.lda % 4 == 0 && a.ldb % 4 == 0, "gemm: leading dimensions must be multiples of 4 floats");
-  SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0,
+  SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 && a.ldc % 4 == 0 && a.slab_stride % 4 == 0 &&
+                    (a.epi != kEpiMaskBwd || (reinterpret_cast<uintptr_t>(a.H) & 15) == 0),
                 "gemm: operands must be 16-byte aligned");
   if (a.grouped == 0) {
     SUAVE_REQUIRE(a.a_kmajor ? a.lda >= a.M : a.lda >= a.K, "gemm: lda too small");
@@ -453,3 +495,19 @@ int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t
 }
 
 }  // namespace suave
+
+// Debugging / tuning aid (not part of include/suave_hip.h): one plain GEMM launch on device pointers.
+extern "C" int suave_debug_gemm(const float* A, const float* B, float* C, const float* bias, const float* H, int M, int N,
+                                int K, int lda, int ldb, int ldc, int a_kmajor, int b_kmajor, int epi, int splits,
+                                float drop_p, void* stream) {
+  suave::GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.H = H;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor; g.epi = epi; g.splits = splits > 0 ? splits : 1;
+  g.slab_stride = (int64_t)M * ldc;
+  g.ones_col = -1;
+  g.drop_p = drop_p;
+  g.seed = 1234; g.step = 1;
+  return suave::launch_gemm(g, 256, static_cast<hipStream_t>(stream));
+}

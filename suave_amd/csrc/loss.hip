@@ -26,6 +26,10 @@ namespace suave {
 namespace {
 
 constexpr int kMissing = 0x7FC0DEAD;  // cell sentinel: masked / unobserved
+// 8 wavefronts share one 64-row tile (each walks every 8th column): two blocks per CU put 4 waves on every
+// SIMD, which is what hides the LDS / transcendental latency of the per-column chains.
+constexpr int kLossWaves = 8;
+constexpr int kLossThreads = kLossWaves * 64;
 
 // Sum over the 64 lanes with DPP row operations; result is wave-uniform.
 __device__ __forceinline__ float wave_sum_dpp(float v) {
@@ -53,22 +57,34 @@ __device__ __forceinline__ void acc_add_lanes(float* slot, float v) {
 
 }  // namespace
 
+#ifdef SUAVE_LOSS_TIMING
+__device__ unsigned long long g_loss_dbg[8];
+#define LOSS_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define LOSS_ACC(i, v) dbg_acc[i] += (v)
+#else
+#define LOSS_T(var)
+#define LOSS_ACC(i, v)
+#endif
+
 template <bool GRAD, int KMAX>
-__global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
+__global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
+#ifdef SUAVE_LOSS_TIMING
+  unsigned long long dbg_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int K = a.K;
   float* ytile = lds;                         // [64][ldy]
   float* hw_acc = ytile + 64 * a.ldy;         // [hw_max]
-  float* gs = hw_acc + a.hw_max;              // [4][max_classes][64]
-  int* k_s = reinterpret_cast<int*>(gs + 4 * a.max_classes * 64);  // [64]
+  float* wsm = hw_acc + a.hw_max;             // [hw_max] this chunk's head weights
+  int* k_s = reinterpret_cast<int*>(wsm + a.hw_max);               // [64]
   float* up_s = reinterpret_cast<float*>(k_s + 64);                // [64]
   float* red_s = up_s + 64;                   // [16]
   long long* trow_s = reinterpret_cast<long long*>(red_s + 16);    // [64] table row of each tile row
-  float* wsm = reinterpret_cast<float*>(trow_s + 64);              // [hw_max] this chunk's head weights
-  int* xsrc_s = reinterpret_cast<int*>(wsm + a.hw_max);            // [ldx] cell source of each chunk column
-  int* xs = xsrc_s + a.ldx;                   // [64][ldx] cell: float bits / code, kMissing when masked
-  float* ds_w = reinterpret_cast<float*>(xs); // [4][64][K]  (aliases xs: used after the column phase)
-  float* recon_w = ds_w + 4 * 64 * K;         // [4][64]
+  int* xsrc_s = reinterpret_cast<int*>(trow_s + 64);               // [ldx] cell source of each chunk column
+  float* gs = reinterpret_cast<float*>(xsrc_s + a.ldx);            // [waves][max_classes][64]
+  int* xs = reinterpret_cast<int*>(gs + kLossWaves * a.max_classes * 64);  // [64][ldx] cell bits, kMissing when masked
+  float* ds_w = gs;                           // [waves][64][K]  (aliases gs + xs: used after the column phase)
+  float* recon_w = ds_w + kLossWaves * 64 * K;  // [waves][64]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,35 +100,45 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
     const int hw_next = (chunk_id + 1 < (int)gridDim.y) ? a.cols[a.chunks[chunk_id + 1].col_begin].w_off
                                                         : a.head_off + a.head_len;
     const int hw_len = min(a.hw_max, hw_next - hw_begin);
-    for (int i = tid; i < hw_len; i += 256) wsm[i] = a.params[hw_begin + i];
-    for (int i = tid; i < ncc; i += 256) xsrc_s[i] = a.xsrc[ch.col_begin + i];
+    for (int i = tid; i < hw_len; i += kLossThreads) wsm[i] = a.params[hw_begin + i];
+    for (int i = tid; i < ncc; i += kLossThreads) xsrc_s[i] = a.xsrc[ch.col_begin + i];
     if (GRAD)
-      for (int i = tid; i < a.hw_max; i += 256) hw_acc[i] = 0.f;
+      for (int i = tid; i < a.hw_max; i += kLossThreads) hw_acc[i] = 0.f;
   }
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int r0 = tile * 64;
     const int nrows = min(64, a.n_rows - r0);
     __syncthreads();
+    LOSS_T(t0);
     // ---- stage the y tile (coalesced) ----
     {
       const int ybase = ch.y_begin & ~3;              // aligned start column
       const int lead = ch.y_begin - ybase;
       const int nq = (lead + ch.y_len + 3) / 4;
-      for (int lr = wave; lr < 64; lr += 4) {
-        float* dst = ytile + lr * a.ldy;
-        if (lr < nrows) {
-          const float* src = a.y + (size_t)(r0 + lr) * a.ldY + ybase;
-          for (int q = lane; q < nq; q += 64) {
-            const float4 v = *reinterpret_cast<const float4*>(src + q * 4);
-            const int c0 = q * 4 - lead;
-            if (c0 >= 0 && c0 < ch.y_len) dst[c0] = v.x;
-            if (c0 + 1 >= 0 && c0 + 1 < ch.y_len) dst[c0 + 1] = v.y;
-            if (c0 + 2 >= 0 && c0 + 2 < ch.y_len) dst[c0 + 2] = v.z;
-            if (c0 + 3 >= 0 && c0 + 3 < ch.y_len) dst[c0 + 3] = v.w;
+      // wave = row, lane = float4 of the row; 4 rows of loads are issued before the first LDS store
+      for (int lr0 = wave; lr0 < 64; lr0 += 4 * kLossWaves) {
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+          const int q = q0 + lane;
+          float4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int lr = lr0 + kLossWaves * u;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past the table: finite zeros
+            if (q < nq && lr < nrows) v[u] = *reinterpret_cast<const float4*>(a.y + (size_t)(r0 + lr) * a.ldY + ybase + q * 4);
           }
-        } else {  // rows past the table: finite zeros
-          for (int cc = lane; cc < ch.y_len; cc += 64) dst[cc] = 0.f;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int lr = lr0 + kLossWaves * u;
+            if (q < nq && lr < 64) {
+              float* dst = ytile + lr * a.ldy;
+              const int c0 = q * 4 - lead;
+              if (c0 >= 0 && c0 < ch.y_len) dst[c0] = v[u].x;
+              if (c0 + 1 >= 0 && c0 + 1 < ch.y_len) dst[c0 + 1] = v[u].y;
+              if (c0 + 2 >= 0 && c0 + 2 < ch.y_len) dst[c0 + 2] = v[u].z;
+              if (c0 + 3 >= 0 && c0 + 3 < ch.y_len) dst[c0 + 3] = v[u].w;
+            }
+          }
         }
       }
       (void)yq;
@@ -133,17 +159,18 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
       }
     }
     __syncthreads();
+    LOSS_T(t1);
     // stage the tile's cells (mask folded in): wave = row, lane = column, 4 rows of loads in flight
     for (int j0 = 0; j0 < ncc; j0 += 64) {
       const int cc = j0 + lane;
       const bool cok = cc < ncc;
       const int src = cok ? xsrc_s[cc] : 0;
-      for (int lr0 = wave; lr0 < nrows; lr0 += 16) {
+      for (int lr0 = wave; lr0 < nrows; lr0 += 4 * kLossWaves) {
         int v[4];
         unsigned char mk[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int lr = lr0 + 4 * u;
+          const int lr = lr0 + kLossWaves * u;
           v[u] = 0;
           mk[u] = 0;
           if (cok && lr < nrows) {
@@ -155,12 +182,13 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int lr = lr0 + 4 * u;
+          const int lr = lr0 + kLossWaves * u;
           if (cok && lr < nrows) xs[lr * a.ldx + cc] = mk[u] ? v[u] : kMissing;
         }
       }
     }
     __syncthreads();
+    LOSS_T(t2);
 
     // ---- column phase: lane = row, wave-uniform column ----
     const bool valid = lane < nrows;
@@ -178,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
     float* yrow = ytile + lane * a.ldy;
     float* gsw = gs + wave * a.max_classes * 64 + lane;
 
-    for (int c = ch.col_begin + wave; c < ch.col_end; c += 4) {
+    for (int c = ch.col_begin + wave; c < ch.col_end; c += kLossWaves) {
       const suave_col_t col = a.cols[c];
       const int cell = valid ? xrow[c] : kMissing;
       const bool obs = cell != kMissing;
@@ -349,7 +377,9 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
     }
 
     // ---- cross-wave reduction of the per-row terms (ds_w / recon_w alias the cell tile) ----
+    LOSS_T(t3);
     __syncthreads();
+    LOSS_T(t3b);
     recon_w[wave * 64 + lane] = recon;
     if (GRAD) {
 #pragma unroll
@@ -358,7 +388,9 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
     }
     __syncthreads();
     if (tid < 64) {
-      const float rsum = recon_w[tid] + recon_w[64 + tid] + recon_w[128 + tid] + recon_w[192 + tid];
+      float rsum = 0.f;
+#pragma unroll
+      for (int w = 0; w < kLossWaves; ++w) rsum += recon_w[w * 64 + tid];
       if (tid < nrows) a.recon_part[(size_t)chunk_id * a.n_rows + r0 + tid] = rsum;
       const float tot = wave_sum_dpp(tid < nrows ? rsum : 0.f);
       if (tid == 0) sum_recon += (double)tot;
@@ -366,14 +398,17 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
     if (GRAD && a.ds_part) {
       if (tid < nrows) {
         float* dst = a.ds_part + ((size_t)chunk_id * a.n_rows + r0 + tid) * a.ldK;
-        for (int j = 0; j < K; ++j)
-          dst[j] = ds_w[(0 * 64 + tid) * K + j] + ds_w[(1 * 64 + tid) * K + j] + ds_w[(2 * 64 + tid) * K + j] +
-                   ds_w[(3 * 64 + tid) * K + j];
+        for (int j = 0; j < K; ++j) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < kLossWaves; ++w) t += ds_w[(w * 64 + tid) * K + j];
+          dst[j] = t;
+        }
       }
     }
     // ---- write dY back (coalesced) ----
     if (GRAD) {
-      for (int lr = wave; lr < nrows; lr += 4) {
+      for (int lr = wave; lr < nrows; lr += kLossWaves) {
         float* dst = a.y + (size_t)(r0 + lr) * a.ldY + ch.y_begin;
         const float* src = ytile + lr * a.ldy;
         for (int cc = lane; cc < ch.y_len; cc += 64) dst[cc] = src[cc];
@@ -382,6 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
 
     // ---- KL phase (chunk 0 only): 4 lanes per row ----
     if (a.do_kl && chunk_id == 0) {
+     if (tid < 256) {  // waves 0-3: 4 lanes per row
       const int lr = tid >> 2, qd = tid & 3;
       const bool v4 = lr < nrows;
       const int rr = r0 + (v4 ? lr : 0);
@@ -439,13 +475,21 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
       const float t_c = wave_sum_dpp((v4 && qd == 0) ? ck : 0.f);
       const float t_g = wave_sum_dpp((v4 && qd == 0) ? gk : 0.f);
       if (lane == 0) { red_s[wave * 2] = t_c; red_s[wave * 2 + 1] = t_g; }
+     }
       __syncthreads();
       if (tid == 0) {
         sum_cat += (double)red_s[0] + (double)red_s[2] + (double)red_s[4] + (double)red_s[6];
         sum_gauss += (double)red_s[1] + (double)red_s[3] + (double)red_s[5] + (double)red_s[7];
       }
     }
+    LOSS_T(t5);
+    LOSS_ACC(0, t1 - t0); LOSS_ACC(1, t2 - t1); LOSS_ACC(2, t3 - t2); LOSS_ACC(3, t3b - t3); LOSS_ACC(4, t5 - t3b);
+    LOSS_ACC(5, 1);
   }
+#ifdef SUAVE_LOSS_TIMING
+  if (lane == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_loss_dbg[i], dbg_acc[i]);
+#endif
 
   __syncthreads();
   if (GRAD && a.head_slab) {
@@ -454,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
                                                       : a.head_off + a.head_len;
     const int n = min(len, next - hw_begin);
     float* dst = a.head_slab + (size_t)blockIdx.x * a.head_len + (hw_begin - a.head_off);
-    for (int i = tid; i < n; i += 256) dst[i] = hw_acc[i];
+    for (int i = tid; i < n; i += kLossThreads) dst[i] = hw_acc[i];
   }
   if (tid == 0 && a.sums_slab) {
     double* s = a.sums_slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
@@ -467,17 +511,17 @@ __global__ __launch_bounds__(256, 2) void k_loss(LossArgs a) {
 
 size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes, int ldx, int ldm) {
   (void)ldm;
-  const size_t cells = std::max((size_t)64 * ldx, (size_t)4 * 64 * K + 4 * 64);
-  size_t floats = (size_t)64 * ldy + 2 * (size_t)hw_max + (size_t)4 * max_classes * 64 + 64 + 64 + 16 + 2 * 64 + ldx + cells;
+  const size_t cells = std::max((size_t)kLossWaves * max_classes * 64 + (size_t)64 * ldx, (size_t)kLossWaves * 64 * K + kLossWaves * 64);
+  size_t floats = (size_t)64 * ldy + 2 * (size_t)hw_max + 64 + 64 + 16 + 2 * 64 + ldx + cells;
   return floats * sizeof(float);
 }
 
 template <int KMAX>
 static int launch_loss_k(const LossArgs& a, bool grad, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s) {
   if (grad)
-    hipLaunchKernelGGL((k_loss<true, KMAX>), dim3(grid_x, n_chunks), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL((k_loss<true, KMAX>), dim3(grid_x, n_chunks), dim3(kLossThreads), lds_bytes, s, a);
   else
-    hipLaunchKernelGGL((k_loss<false, KMAX>), dim3(grid_x, n_chunks), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL((k_loss<false, KMAX>), dim3(grid_x, n_chunks), dim3(kLossThreads), lds_bytes, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -507,5 +551,14 @@ int loss_set_lds_limit(size_t lds_bytes) {
   rc |= set_lds_one<false, 32>(lds_bytes);
   return rc;
 }
+
+#ifdef SUAVE_LOSS_TIMING
+extern "C" int suave_debug_loss_timing(unsigned long long* out, int reset) {
+  unsigned long long z[8] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loss_dbg), sizeof(z)) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_loss_dbg), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
+#endif
 
 }  // namespace suave
