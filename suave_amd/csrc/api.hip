@@ -76,6 +76,7 @@ struct Workspace {
   int32_t* kidx;
   float *recon_part, *ds_part, *catkl, *gausskl, *gkl_logit, *gkl_mu, *gkl_lv, *prior_terms, *recon;
   float* onehot;
+  int32_t* cells;  // [rows, n_cols] packed cells of the batch rows, mask folded in
   // selected-component encoder head (supervised branch)
   float *sel, *dsel, *gslab;
   int32_t *perm, *lrank, *blk_cnt, *blk_base, *chunk_comp, *chunk_begin;
@@ -108,8 +109,12 @@ int tn_splits(const suave_plan* p, int n_out, int n_in1, int64_t rows) {
 }
 
 int loss_grid(const suave_plan* p, int64_t rows) {
+  // about three resident 8-wave blocks per CU over all chunks; each block walks several tiles so that the
+  // register prefetch of the next tile overlaps the column phase of the current one
   const int64_t tiles = (rows + 63) / 64;
-  return (int)std::max<int64_t>(1, std::min<int64_t>(tiles, 2 * (int64_t)p->n_cu));
+  const int64_t nch = std::max<size_t>(1, p->chunks_host.size());
+  const int64_t per_chunk = (3 * (int64_t)p->n_cu + nch - 1) / nch;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(tiles, per_chunk));
 }
 
 struct LayerRef {
@@ -157,6 +162,7 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
                                    : round_up(m.n_components * m.latent_dim + m.latent_dim, 4);
   w->prior_terms = c.take<float>(R * ldT);
   w->onehot = c.take<float>(R * p->ldK);
+  w->cells = c.take<int32_t>(R * m.n_cols);
   {
     const int ldS = p->ldK + 2 * p->ldD;
     const bool sup = m.behaviour == 0;
@@ -188,7 +194,7 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
   if (m.behaviour == 1) slab += (size_t)lg * (m.n_components * m.latent_dim + m.latent_dim);
   w->slab_floats = slab;
   w->slab = c.take<float>(slab);
-  w->sums_slab = c.take<double>((size_t)lg * nch * 4);
+  w->sums_slab = c.take<double>(((size_t)lg * nch + 1024) * 4);
   w->total_bytes = (c.off + 255) & ~size_t(255);
 }
 
@@ -328,7 +334,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
   const suave_noise_t* nz = noise ? noise : &nz_default;
   const float tau_c = tau > 0.f ? std::max(tau, 1e-6f) : 0.f;
 
-  if (int rc = launch_expand(p, p->enc_src_dev, *batch, w.x, s)) return rc;
+  if (int rc = launch_expand(p, *batch, w.x, w.cells, s)) return rc;
   const float* act = w.x;
   int ld_act = p->ldI;
   for (int i = 0; i < nh; ++i) {
@@ -375,7 +381,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     a.ldT = ldT; a.max_classes = p->max_classes; a.recon_part = w.recon_part; a.ds_part = nullptr; a.do_kl = 0;
     a.head_slab = grad ? head_slab : nullptr; a.sums_slab = nullptr;
     a.head_off = m.head_off; a.head_len = m.head_len; a.hw_max = p->hw_max;
-    a.xsrc = p->xsrc_dev; a.ldx = p->loss_ldx; a.ldm = p->loss_ldm;
+    a.xsrc = p->xsrc_dev; a.ldx = p->loss_ldx; a.ldm = p->loss_ldm; a.cells = w.cells; a.n_cols = m.n_cols;
     if (int rc = launch_loss(a, grad, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
   }
   ReduceArgs red{};
@@ -498,7 +504,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   const suave_noise_t* nz = noise ? noise : &nz_default;
 
   // ---- encoder ----
-  if (int rc = launch_expand(p, p->enc_src_dev, *batch, w.x, s)) return rc;
+  if (int rc = launch_expand(p, *batch, w.x, w.cells, s)) return rc;
   const float* act = w.x;
   int ld_act = p->ldI;
   for (int i = 0; i < nh; ++i) {
@@ -549,6 +555,13 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     head_geometry(g);
     if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
   }
+  const int n_chunks = (int)p->chunks_host.size();
+  const int lgrid = loss_grid(p, B);
+  const int ldT = round_up(2 * m.latent_dim + m.n_components, 4);
+  la.params = params; la.prior_logits_off = m.prior_logits_off; la.prior_mu_off = m.prior_mu_off;
+  la.prior_logvar_off = m.prior_logvar_off; la.bk = beta_scale / (float)global_rows; la.grad = grad ? 1 : 0; la.ldT = ldT;
+  la.catkl = w.catkl; la.gausskl = w.gausskl; la.gkl_logit = w.gkl_logit; la.gkl_mu = w.gkl_mu; la.gkl_lv = w.gkl_lv;
+  la.prior_terms = w.prior_terms; la.sums_slab = w.sums_slab + (size_t)lgrid * n_chunks * 4;
   if (int rc = launch_reparam(la, s)) return rc;
   // ---- decoder trunk ----
   act = w.z;
@@ -562,10 +575,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   }
   if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, batch, nz, 0, 1, s))
     return rc;
-  // ---- fused likelihood + KL (+ gradients) ----
-  const int n_chunks = (int)p->chunks_host.size();
-  const int lgrid = loss_grid(p, B);
-  const int ldT = round_up(2 * m.latent_dim + m.n_components, 4);
+  // ---- fused likelihood (+ gradients) ----
   size_t slab_off = 0;
   float* head_slab = w.slab;
   slab_off += ((size_t)lgrid * m.head_len + 3) & ~size_t(3);  // GEMM slabs start 16-byte aligned
@@ -577,12 +587,12 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     a.bk = beta_scale / (float)global_rows;
     a.K = m.n_components; a.D = m.latent_dim; a.ldY = p->ldY; a.ldy = p->max_chunk_y | 1; a.ldK = p->ldK;
     a.ldD = p->ldD; a.ldE = p->ldE; a.ldT = ldT; a.max_classes = p->max_classes;
-    a.recon_part = w.recon_part; a.ds_part = w.ds_part; a.do_kl = 1; a.encout = w.sel; a.ldE = ldS;
+    a.recon_part = w.recon_part; a.ds_part = w.ds_part; a.do_kl = 0;
     a.prior_logits_off = m.prior_logits_off; a.prior_mu_off = m.prior_mu_off; a.prior_logvar_off = m.prior_logvar_off;
     a.catkl = w.catkl; a.gausskl = w.gausskl; a.gkl_logit = w.gkl_logit; a.gkl_mu = w.gkl_mu; a.gkl_lv = w.gkl_lv;
     a.prior_terms = w.prior_terms; a.head_slab = grad ? head_slab : nullptr; a.sums_slab = w.sums_slab;
     a.head_off = m.head_off; a.head_len = m.head_len; a.hw_max = p->hw_max;
-    a.xsrc = p->xsrc_dev; a.ldx = p->loss_ldx; a.ldm = p->loss_ldm;
+    a.xsrc = p->xsrc_dev; a.ldx = p->loss_ldx; a.ldm = p->loss_ldm; a.cells = w.cells; a.n_cols = m.n_cols;
     if (int rc = launch_loss(a, grad, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
   }
   const float* recon_final = w.recon_part;
@@ -597,7 +607,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   red.slab = w.slab;
   red.dst = grads;
   red.sums_slab = w.sums_slab;
-  red.n_sum_slabs = lgrid * n_chunks;
+  red.n_sum_slabs = lgrid * n_chunks + reparam_grid(B);
   red.sums_out = out ? out->sums : nullptr;
   red.n_rows = (double)B;
   int max_elems = 256;
@@ -848,14 +858,16 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("plan_create: no HIP device");
   p->device = dev;
   p->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  std::vector<int32_t> enc_src(p->ldI, -1);
+  std::vector<int32_t> enc_src(p->ldI, 0);  // kind 0 = pad
   for (int c = 0; c < m.n_cols; ++c) {
     const suave_col_t& col = cols[c];
     const int width = col.type >= SUAVE_TYPE_CAT ? col.n_classes : 1;
     if (col.enc_off < 0 || col.enc_off + width > m.enc_in || col.enc_mask < 0 || col.enc_mask >= m.enc_in)
       return fail("plan_create: encoder input offsets out of range");
-    for (int k = 0; k < width; ++k) enc_src[col.enc_off + k] = (c << 16) | k;
-    enc_src[col.enc_mask] = (1 << 30) | (c << 16);
+    const uint32_t kind = col.type <= SUAVE_TYPE_COUNT ? 2u : (col.type == SUAVE_TYPE_CAT ? 3u : 4u);
+    for (int k = 0; k < width; ++k)
+      enc_src[col.enc_off + k] = (int32_t)((kind << 29) | ((uint32_t)k << 14) | (uint32_t)col.x_index);
+    enc_src[col.enc_mask] = (int32_t)((1u << 29) | (uint32_t)c);
   }
   auto dfail = [&](const char* msg) {
     set_error(msg);
@@ -864,7 +876,7 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
   };
   if (hipMalloc(&p->cols_dev, sizeof(suave_col_t) * m.n_cols) != hipSuccess) return dfail("plan_create: hipMalloc failed");
   if (hipMalloc(&p->chunks_dev, sizeof(ColChunk) * p->chunks_host.size()) != hipSuccess) return dfail("plan_create: hipMalloc failed");
-  if (hipMalloc(&p->enc_src_dev, sizeof(int32_t) * p->ldI) != hipSuccess) return dfail("plan_create: hipMalloc failed");
+  if (hipMalloc(&p->enc_map_dev, sizeof(int32_t) * p->ldI) != hipSuccess) return dfail("plan_create: hipMalloc failed");
   if (hipMalloc(&p->cls_off_dev, sizeof(int32_t) * m.n_cols) != hipSuccess) return dfail("plan_create: hipMalloc failed");
   if (hipMalloc(&p->xsrc_dev, sizeof(int32_t) * m.n_cols) != hipSuccess) return dfail("plan_create: hipMalloc failed");
   {
@@ -885,7 +897,7 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
   }
   if (hipMemcpy(p->cols_dev, cols, sizeof(suave_col_t) * m.n_cols, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(p->chunks_dev, p->chunks_host.data(), sizeof(ColChunk) * p->chunks_host.size(), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(p->enc_src_dev, enc_src.data(), sizeof(int32_t) * p->ldI, hipMemcpyHostToDevice) != hipSuccess)
+      hipMemcpy(p->enc_map_dev, enc_src.data(), sizeof(int32_t) * p->ldI, hipMemcpyHostToDevice) != hipSuccess)
     return dfail("plan_create: hipMemcpy failed");
   if (p->loss_lds_bytes > 48 * 1024)
     if (loss_set_lds_limit(p->loss_lds_bytes)) { suave_plan_destroy(p); return 2; }
@@ -897,7 +909,7 @@ extern "C" int suave_plan_destroy(suave_plan* p) {
   if (!p) return 0;
   if (p->cols_dev) (void)hipFree(p->cols_dev);
   if (p->chunks_dev) (void)hipFree(p->chunks_dev);
-  if (p->enc_src_dev) (void)hipFree(p->enc_src_dev);
+  if (p->enc_map_dev) (void)hipFree(p->enc_map_dev);
   if (p->cls_off_dev) (void)hipFree(p->cls_off_dev);
   if (p->xsrc_dev) (void)hipFree(p->xsrc_dev);
   delete p;
@@ -942,7 +954,7 @@ extern "C" int suave_encode(const suave_plan* p, const float* params, const suav
   Workspace w;
   carve(p, B, workspace, &w);
   SUAVE_REQUIRE(workspace_bytes >= w.total_bytes, "workspace too small (see suave_workspace_bytes)");
-  if (int rc = launch_expand(p, p->enc_src_dev, *batch, w.x, s)) return rc;
+  if (int rc = launch_expand(p, *batch, w.x, nullptr, s)) return rc;
   const float* act = w.x;
   int ld_act = p->ldI;
   for (int i = 0; i < m.n_hidden; ++i) {

@@ -53,7 +53,7 @@ struct suave_plan {
   suave::ColChunk* chunks_dev = nullptr;
   int device = 0;
   int n_cu = 256;
-  int32_t* enc_src_dev = nullptr;
+  int32_t* enc_map_dev = nullptr;  // encoder input feature -> packed-cell source (k_expand)
   int32_t* cls_off_dev = nullptr;
   int32_t* xsrc_dev = nullptr;
   int loss_ldx = 1, loss_ldm = 4;

@@ -4,6 +4,8 @@
 
 namespace suave {
 
+constexpr int kCellMissing = 0x7FC0DEAD;  // cell sentinel: masked / unobserved
+
 struct LossArgs {
   const suave_col_t* cols;
   const ColChunk* chunks;
@@ -33,6 +35,8 @@ struct LossArgs {
   double* sums_slab;   // [gridDim.x * gridDim.y, 4]
   int head_off, head_len, hw_max;
   const int32_t* xsrc;  // [n_cols] x_index | (1 << 30 for cat / ordinal)
+  const int32_t* cells; // [data rows, n_cols] packed cells from k_expand
+  int n_cols;
   int ldx, ldm;         // LDS row strides of the staged cells (ints) and masks (bytes)
 };
 
@@ -57,6 +61,19 @@ struct LatentFwdArgs {
   // rows sorted by component (stable): rank of the row inside its 256-row block, per-block counts
   int32_t* lrank;       // [B]
   int32_t* blk_cnt;     // [ceil(B/256), K]
+  // KL terms (k_reparam): losses.py:51-57, :87-97 with the prior of the selected component (model.py:1607-1613)
+  const float* params;
+  int prior_logits_off, prior_mu_off, prior_logvar_off;
+  float bk;             // d loss / d KL_row = beta / global rows
+  int grad;             // write the gradient buffers below
+  int ldT;
+  float* catkl;         // [B]
+  float* gausskl;       // [B]
+  float* gkl_logit;     // [B, ldK]
+  float* gkl_mu;        // [B, ldD]
+  float* gkl_lv;        // [B, ldD]
+  float* prior_terms;   // [B, ldT]: d/d prior_mu_k | d/d prior_logvar_k | d/d prior_logits
+  double* sums_slab;    // [gridDim.x, 4]: (0, sum cat KL, sum gauss KL, 0) per block
 };
 
 // Stable counting sort of the batch rows by selected component, in chunks of kGroupRows positions.
@@ -157,9 +174,10 @@ int launch_colsum(const float* src, int ld, int n_rows, int n_cols, float* slab,
 size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes, int ldx, int ldm);
 int loss_set_lds_limit(size_t lds_bytes);
 int launch_loss(const LossArgs& a, bool grad, int kmax, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s);
-int launch_expand(const suave_plan* p, const int32_t* enc_src_dev, const suave_batch_t& b, float* x, hipStream_t s);
+int launch_expand(const suave_plan* p, const suave_batch_t& b, float* x, int32_t* cells, hipStream_t s);
 int launch_assign(const LatentFwdArgs& a, hipStream_t s);
 int launch_group(const GroupArgs& a, hipStream_t s);
+int reparam_grid(int n_rows);
 int launch_reparam(const LatentFwdArgs& a, hipStream_t s);
 int launch_head_reduce(const HeadReduceArgs& a, hipStream_t s);
 int launch_latent_bwd(const LatentBwdArgs& a, hipStream_t s);

@@ -12,35 +12,88 @@
 
 namespace suave {
 
-// enc_src entry: bits 0..15 class index, bits 16..29 column, bit 30 = mask entry; -1 = pad
-__global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_src, const suave_col_t* __restrict__ cols,
-                                                suave_batch_t b, int ldI, float* __restrict__ x) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int r = blockIdx.x * 4 + wave; r < b.n_rows; r += gridDim.x * 4) {
-    const int64_t tr = b.row_index ? (int64_t)b.row_index[r] : b.row_begin + r;
-    const float* xn = b.xnum + tr * b.ld_num;
-    const int16_t* cd = b.codes + tr * b.ld_disc;
-    const uint8_t* mk = b.mask + tr * b.ld_mask;
-    for (int i = lane; i < ldI; i += 64) {
-      const int32_t e = enc_src[i];
-      float v = 0.f;
-      if (e >= 0) {
-        const int c = (e >> 16) & 0x3FFF;
-        if (e & (1 << 30)) {
-          v = mk[c] ? 1.f : 0.f;
-        } else {
-          const suave_col_t col = cols[c];
-          const int cls = e & 0xFFFF;
-          if (col.type <= SUAVE_TYPE_COUNT) {
-            v = xn[col.x_index];
-          } else {
-            const int code = cd[col.x_index];
-            if (col.type == SUAVE_TYPE_CAT) v = (code == cls) ? 1.f : 0.f;
-            else v = (code >= 0 && cls <= code) ? 1.f : 0.f;  // thermometer, model.py:2890-2891
+// enc_map entry (built in suave_plan_create): bits 31..29 kind, 28..14 class index, 13..0 source index
+//   kind 0 pad, 1 mask of column idx, 2 numeric cell xnum[idx], 3 one-hot of codes[idx], 4 thermometer of codes[idx]
+// A block stages the packed cells of its rows in LDS with coalesced row reads, then writes
+//   x     [B, ldI]    the encoder input (model.py:2784-2922 layout, quirks Q6/Q7), and
+//   cells [B, n_cols] one int per cell for the likelihood kernel: float bits / class code, kCellMissing when masked.
+__global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_map, const int32_t* __restrict__ xsrc,
+                                                suave_batch_t b, int n_num, int n_disc, int n_cols, int ldI,
+                                                int rows_per_block, float* __restrict__ x, int32_t* __restrict__ cells) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ldn = n_num, ldd = (n_disc + 1) & ~1, ldm = (n_cols + 3) & ~3;
+  float* xn_s = reinterpret_cast<float*>(stage);                                   // [R][ldn]
+  int16_t* cd_s = reinterpret_cast<int16_t*>(xn_s + (size_t)rows_per_block * ldn);  // [R][ldd]
+  uint8_t* mk_s = reinterpret_cast<uint8_t*>(cd_s + (size_t)rows_per_block * ldd);  // [R][ldm]
+  for (int r0 = blockIdx.x * rows_per_block; r0 < b.n_rows; r0 += gridDim.x * rows_per_block) {
+    const int nrows = min(rows_per_block, b.n_rows - r0);
+    __syncthreads();
+    // each wave stages a contiguous quarter of the block's rows: one load of their table row ids, then
+    // 8 rows of cell loads in flight at a time (lane = element)
+    const int rows_w = (rows_per_block + 3) / 4;
+    const int lw0 = wave * rows_w;
+    int64_t my_tr = -1;
+    if (lane < rows_w && lw0 + lane < nrows) my_tr = b.row_index ? (int64_t)b.row_index[r0 + lw0 + lane] : b.row_begin + r0 + lw0 + lane;
+    const int n_max = max(n_num, max(n_disc, n_cols));
+    for (int j0 = 0; j0 < rows_w; j0 += 8) {
+      int64_t tr[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tr[u] = __shfl(my_tr, (j0 + u) & 63, 64);
+      for (int i0 = 0; i0 < n_max; i0 += 64) {
+        const int i = i0 + lane;
+        float xv[8];
+        int16_t cv[8];
+        uint8_t mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool ok = j0 + u < rows_w && tr[u] >= 0;
+          xv[u] = (ok && i < n_num) ? b.xnum[tr[u] * b.ld_num + i] : 0.f;
+          cv[u] = (ok && i < n_disc) ? b.codes[tr[u] * b.ld_disc + i] : (int16_t)0;
+          mv[u] = (ok && i < n_cols) ? b.mask[tr[u] * b.ld_mask + i] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int lr = lw0 + j0 + u;
+          if (j0 + u < rows_w && tr[u] >= 0) {
+            if (i < n_num) xn_s[lr * ldn + i] = xv[u];
+            if (i < n_disc) cd_s[lr * ldd + i] = cv[u];
+            if (i < n_cols) mk_s[lr * ldm + i] = mv[u];
           }
         }
       }
-      x[(size_t)r * ldI + i] = v;
+    }
+    __syncthreads();
+    // lane = input feature (its map entry stays in a register), wave walks the rows: no index division
+    for (int i0 = 0; i0 < ldI; i0 += 64) {
+      const int i = i0 + lane;
+      const uint32_t e = i < ldI ? (uint32_t)enc_map[i] : 0u;
+      const int kind = e >> 29, cls = (e >> 14) & 0x7FFF, src = e & 0x3FFF;
+      if (i < ldI) {
+        for (int lr = wave; lr < nrows; lr += 4) {
+          float v = 0.f;
+          if (kind == 2) v = xn_s[lr * ldn + src];
+          else if (kind == 1) v = mk_s[lr * ldm + src] ? 1.f : 0.f;
+          else if (kind >= 3) {
+            const int code = cd_s[lr * ldd + src];
+            v = kind == 3 ? (code == cls ? 1.f : 0.f) : ((code >= 0 && cls <= code) ? 1.f : 0.f);  // model.py:2890-2891
+          }
+          x[(size_t)(r0 + lr) * ldI + i] = v;
+        }
+      }
+    }
+    if (cells) {
+      for (int c0 = 0; c0 < n_cols; c0 += 64) {
+        const int c = c0 + lane;
+        if (c >= n_cols) continue;
+        const int sx = xsrc[c];
+        const bool disc = (sx & (1 << 30)) != 0;
+        const int src = sx & 0xFFFFFF;
+        for (int lr = wave; lr < nrows; lr += 4) {
+          const int v = disc ? (int)cd_s[lr * ldd + src] : __float_as_int(xn_s[lr * ldn + src]);
+          cells[(size_t)(r0 + lr) * n_cols + c] = mk_s[lr * ldm + c] ? v : kCellMissing;
+        }
+      }
     }
   }
 }
@@ -152,33 +205,139 @@ __global__ __launch_bounds__(256) void k_group_scatter(GroupArgs a) {
   if (r < a.n_rows) a.perm[a.blk_base[(size_t)blockIdx.x * a.K + a.kidx[r]] + a.lrank[r]] = r;
 }
 
-// supervised, step 2: z = mu_k + eps * exp(lv_k / 2) from the selected component's head outputs
+// supervised, step 2 (4 lanes per row): z = mu_k + eps * exp(lv_k / 2) from the selected component's head
+// outputs, and both KL terms with their gradients -- everything that only needs the compact head row.
 __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
+  extern __shared__ float prior_s[];  // [K*D] prior mu | [K*D] prior logvar | [K*D] +-1 / max(exp(logvar), 1e-6)
+  __shared__ float red_s[8];
   const Philox rng(a.seed);
-  const int dq = (a.D + 3) / 4;
-  const int64_t total = (int64_t)a.n_rows * dq;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int r = (int)(idx / dq), q = (int)(idx % dq);
-    float ev[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.eps_in == nullptr) {
-      const uint32_t rid = a.row_index ? (uint32_t)a.row_index[r] : (uint32_t)(a.row_begin + r);
-      const uint4 w = rng(rid, (uint32_t)q, kStreamEps, (uint32_t)a.step);
-      const float2 n0 = normal2(w.x, w.y), n1 = normal2(w.z, w.w);
-      ev[0] = n0.x; ev[1] = n0.y; ev[2] = n1.x; ev[3] = n1.y;
-    }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K, D = a.D;
+  const int dq = (D + 3) / 4;
+  float* pm_s = prior_s;
+  float* plv_s = prior_s + K * D;
+  float* ivp_s = prior_s + 2 * K * D;
+  for (int i = tid; i < K * D; i += 256) {
+    pm_s[i] = a.params[a.prior_mu_off + i];
+    const float l = a.params[a.prior_logvar_off + i];
+    plv_s[i] = l;
+    const float vp_raw = __expf(l);  // sign of the stored reciprocal: negative when the 1e-6 floor is active
+    ivp_s[i] = vp_raw >= 1e-6f ? 1.0f / vp_raw : -1e6f;
+  }
+  __syncthreads();
+  const bool vec = (D & 3) == 0;
+  double sum_cat = 0.0, sum_gauss = 0.0;
+  for (int r0 = blockIdx.x * 64; r0 < a.n_rows; r0 += gridDim.x * 64) {
+    const int lr = tid >> 2, qd = tid & 3;
+    const bool v4 = r0 + lr < a.n_rows;
+    const int r = v4 ? r0 + lr : r0;
+    const int kk = a.kidx[r];
     const float* mu = a.sel + (size_t)r * a.ldS + a.ldK;
     const float* lv = mu + a.ldD;
+    const uint32_t rid = a.row_index ? (uint32_t)a.row_index[r] : (uint32_t)(a.row_begin + r);
+    float gk = 0.f;
+    if (v4) {
+      for (int q = qd; q < dq; q += 4) {
+        float ev[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.eps_in == nullptr) {
+          const uint4 w = rng(rid, (uint32_t)q, kStreamEps, (uint32_t)a.step);
+          const float2 n0 = normal2(w.x, w.y), n1 = normal2(w.z, w.w);
+          ev[0] = n0.x; ev[1] = n0.y; ev[2] = n1.x; ev[3] = n1.y;
+        } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int d = q * 4 + e;
-      if (d >= a.D) break;
-      const float eps = a.eps_in ? a.eps_in[(size_t)r * a.D + d] : ev[e];
-      const float lvc = fminf(fmaxf(lv[d], kLogvarMin), kLogvarMax);
-      const float zz = mu[d] + eps * __expf(0.5f * lvc);
-      a.z[(size_t)r * a.ldD + d] = zz;
-      a.eps_buf[(size_t)r * a.ldD + d] = eps;
-      if (a.latent_out) a.latent_out[(size_t)r * a.D + d] = zz;
+          for (int e = 0; e < 4; ++e)
+            if (q * 4 + e < D) ev[e] = a.eps_in[(size_t)r * D + q * 4 + e];
+        }
+        const float4 mu4 = *reinterpret_cast<const float4*>(mu + q * 4);
+        const float4 lv4 = *reinterpret_cast<const float4*>(lv + q * 4);
+        const float mv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, lvv[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
+        float zz[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {0.f, 0.f, 0.f, 0.f}, gl[4] = {0.f, 0.f, 0.f, 0.f}, pl2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int d = q * 4 + e;
+          if (d >= D) break;
+          const float lvc = fminf(fmaxf(lvv[e], kLogvarMin), kLogvarMax);
+          zz[e] = mv[e] + ev[e] * __expf(0.5f * lvc);
+          const float plvd = plv_s[kk * D + d], ivp_sg = ivp_s[kk * D + d];
+          const float ivp = fabsf(ivp_sg);
+          const float diff = mv[e] - pm_s[kk * D + d];
+          const float elv = __expf(lvc);
+          const float quad = (elv + diff * diff) * ivp;
+          gk += 0.5f * (plvd - lvc + quad - 1.0f);
+          gm[e] = a.bk * diff * ivp;
+          gl[e] = a.bk * 0.5f * (elv * ivp - 1.0f);
+          pl2[e] = a.bk * 0.5f * (1.0f - (ivp_sg > 0.f ? quad : 0.f));  // max(exp(lv_p), 1e-6) passes gradient above its floor only
+        }
+        if (vec) {
+          *reinterpret_cast<float4*>(a.z + (size_t)r * a.ldD + q * 4) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+          *reinterpret_cast<float4*>(a.eps_buf + (size_t)r * a.ldD + q * 4) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+          if (a.grad) {
+            *reinterpret_cast<float4*>(a.gkl_mu + (size_t)r * a.ldD + q * 4) = make_float4(gm[0], gm[1], gm[2], gm[3]);
+            *reinterpret_cast<float4*>(a.gkl_lv + (size_t)r * a.ldD + q * 4) = make_float4(gl[0], gl[1], gl[2], gl[3]);
+            *reinterpret_cast<float4*>(a.prior_terms + (size_t)r * a.ldT + q * 4) = make_float4(-gm[0], -gm[1], -gm[2], -gm[3]);
+            *reinterpret_cast<float4*>(a.prior_terms + (size_t)r * a.ldT + D + q * 4) = make_float4(pl2[0], pl2[1], pl2[2], pl2[3]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int d = q * 4 + e;
+            if (d >= D) break;
+            a.z[(size_t)r * a.ldD + d] = zz[e];
+            a.eps_buf[(size_t)r * a.ldD + d] = ev[e];
+            if (a.grad) {
+              a.gkl_mu[(size_t)r * a.ldD + d] = gm[e];
+              a.gkl_lv[(size_t)r * a.ldD + d] = gl[e];
+              a.prior_terms[(size_t)r * a.ldT + d] = -gm[e];
+              a.prior_terms[(size_t)r * a.ldT + D + d] = pl2[e];
+            }
+          }
+        }
+        if (a.latent_out) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (q * 4 + e < D) a.latent_out[(size_t)r * D + q * 4 + e] = zz[e];
+        }
+      }
     }
+    gk += __shfl_xor(gk, 1, 64);
+    gk += __shfl_xor(gk, 2, 64);
+    float ck = 0.f;
+    if (v4 && qd == 0) {
+      const float* lg = a.sel + (size_t)r * a.ldS;
+      const float* pl = a.params + a.prior_logits_off;
+      float mq = -INFINITY, mp = -INFINITY;
+      for (int j = 0; j < K; ++j) { mq = fmaxf(mq, lg[j]); mp = fmaxf(mp, pl[j]); }
+      float sq = 0.f, sp = 0.f;
+      for (int j = 0; j < K; ++j) { sq += __expf(lg[j] - mq); sp += __expf(pl[j] - mp); }
+      const float lq = mq + __logf(sq), lp = mp + __logf(sp);
+      for (int j = 0; j < K; ++j) {
+        const float logq = lg[j] - lq, logp = pl[j] - lp;
+        ck += __expf(logq) * (logq - logp);
+      }
+      if (a.grad) {
+        for (int j = 0; j < K; ++j) {
+          const float logq = lg[j] - lq, logp = pl[j] - lp;
+          const float q = __expf(logq);
+          a.gkl_logit[(size_t)r * a.ldK + j] = a.bk * q * ((logq - logp) - ck);
+          a.prior_terms[(size_t)r * a.ldT + 2 * D + j] = a.bk * (__expf(logp) - q);
+        }
+      }
+      a.catkl[r] = ck;
+      a.gausskl[r] = gk;
+    }
+    const float t_c = wave_sum((v4 && qd == 0) ? ck : 0.f);
+    const float t_g = wave_sum((v4 && qd == 0) ? gk : 0.f);
+    __syncthreads();
+    if (lane == 0) { red_s[wave * 2] = t_c; red_s[wave * 2 + 1] = t_g; }
+    __syncthreads();
+    if (tid == 0) {
+      sum_cat += (double)red_s[0] + (double)red_s[2] + (double)red_s[4] + (double)red_s[6];
+      sum_gauss += (double)red_s[1] + (double)red_s[3] + (double)red_s[5] + (double)red_s[7];
+    }
+  }
+  if (tid == 0 && a.sums_slab) {
+    double* s = a.sums_slab + (size_t)blockIdx.x * 4;
+    s[0] = 0.0; s[1] = sum_cat; s[2] = sum_gauss; s[3] = 0.0;
   }
 }
 
@@ -186,47 +345,68 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
 // Straight-through Gumbel path + the selected component's mu / logvar gradients in the compact head
 // layout: every other entry of d(enc_out) is zero and is never materialised.
 __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
+  __shared__ float ds_s[64 * SUAVE_MAX_COMPONENTS];
+  __shared__ float ys_s[64 * SUAVE_MAX_COMPONENTS];
+  __shared__ float inner_s[64];
   const int tid = threadIdx.x;
+  const int K = a.K;
   for (int r0 = blockIdx.x * 64; r0 < a.n_rows; r0 += gridDim.x * 64) {
     const int nrows = min(64, a.n_rows - r0);
-    if (tid < nrows) {
-      const int r = r0 + tid;
-      const float* ys = a.ysoft + (size_t)r * a.ldK;
-      float ds[SUAVE_MAX_COMPONENTS];
-      float inner = 0.f;
-#pragma unroll 1
-      for (int j = 0; j < a.K; ++j) {
-        float v = 0.f;
-        for (int c = 0; c < a.n_chunks; ++c) v += a.ds_part[((size_t)c * a.n_rows + r) * a.ldK + j];
-        ds[j] = v;
-        inner += ys[j] * v;
-      }
-      const float inv_tau = 1.0f / a.tau;
-#pragma unroll 1
-      for (int j = 0; j < a.ldK; ++j)
-        a.dsel[(size_t)r * a.ldS + j] =
-            j < a.K ? ys[j] * (ds[j] - inner) * inv_tau + a.gkl_logit[(size_t)r * a.ldK + j] : 0.f;
-    }
-    const int width = 2 * a.ldD;
-    for (int idx = tid; idx < nrows * width; idx += 256) {
-      const int lr = idx / width, c = idx % width;
+    __syncthreads();
+    for (int idx = tid; idx < nrows * K; idx += 256) {
+      const int lr = idx / K, j = idx - lr * K;
       const int r = r0 + lr;
-      const bool is_lv = c >= a.ldD;
-      const int d = is_lv ? c - a.ldD : c;
       float v = 0.f;
-      if (d < a.D) {
-        const float g = a.dz[(size_t)r * a.ldD + d];
+      for (int c = 0; c < a.n_chunks; ++c) v += a.ds_part[((size_t)c * a.n_rows + r) * a.ldK + j];
+      ds_s[lr * SUAVE_MAX_COMPONENTS + j] = v;
+      ys_s[lr * SUAVE_MAX_COMPONENTS + j] = a.ysoft[(size_t)r * a.ldK + j];
+    }
+    __syncthreads();
+    if (tid < nrows) {
+      float inner = 0.f;
+      for (int j = 0; j < K; ++j) inner += ys_s[tid * SUAVE_MAX_COMPONENTS + j] * ds_s[tid * SUAVE_MAX_COMPONENTS + j];
+      inner_s[tid] = inner;
+    }
+    __syncthreads();
+    const float inv_tau = 1.0f / a.tau;
+    // one float4 of one row per step (ldK and ldD are multiples of 4, so a float4 never straddles regions)
+    const int nq = a.ldS >> 2;
+    for (int idx = tid; idx < nrows * nq; idx += 256) {
+      const int lr = idx / nq, q = (idx - lr * nq) * 4;
+      const int r = r0 + lr;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (q < a.ldK) {
+        const float4 gl = *reinterpret_cast<const float4*>(a.gkl_logit + (size_t)r * a.ldK + q);
+        const float g4[4] = {gl.x, gl.y, gl.z, gl.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (q + e < K)
+            v[e] = ys_s[lr * SUAVE_MAX_COMPONENTS + q + e] * (ds_s[lr * SUAVE_MAX_COMPONENTS + q + e] - inner_s[lr]) * inv_tau + g4[e];
+      } else {
+        const int c = q - a.ldK;
+        const bool is_lv = c >= a.ldD;
+        const int d = is_lv ? c - a.ldD : c;
+        const float4 g4 = *reinterpret_cast<const float4*>(a.dz + (size_t)r * a.ldD + d);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
         if (!is_lv) {
-          v = g + a.gkl_mu[(size_t)r * a.ldD + d];
+          const float4 m4 = *reinterpret_cast<const float4*>(a.gkl_mu + (size_t)r * a.ldD + d);
+          const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (d + e < a.D) v[e] = g[e] + mm[e];
         } else {
-          const float raw = a.sel[(size_t)r * a.ldS + a.ldK + c];
-          if (raw >= kLogvarMin && raw <= kLogvarMax) {  // clamp passes gradient inside its range only
-            const float eps = a.eps_buf[(size_t)r * a.ldD + d];
-            v = g * eps * 0.5f * __expf(0.5f * raw) + a.gkl_lv[(size_t)r * a.ldD + d];
-          }
+          const float4 raw4 = *reinterpret_cast<const float4*>(a.sel + (size_t)r * a.ldS + q);
+          const float4 eps4 = *reinterpret_cast<const float4*>(a.eps_buf + (size_t)r * a.ldD + d);
+          const float4 l4 = *reinterpret_cast<const float4*>(a.gkl_lv + (size_t)r * a.ldD + d);
+          const float raw[4] = {raw4.x, raw4.y, raw4.z, raw4.w}, eps[4] = {eps4.x, eps4.y, eps4.z, eps4.w};
+          const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)  // clamp passes gradient inside its range only
+            if (d + e < a.D && raw[e] >= kLogvarMin && raw[e] <= kLogvarMax)
+              v[e] = g[e] * eps[e] * 0.5f * __expf(0.5f * raw[e]) + ll[e];
         }
       }
-      a.dsel[(size_t)r * a.ldS + a.ldK + c] = v;
+      *reinterpret_cast<float4*>(a.dsel + (size_t)r * a.ldS + q) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
 }
@@ -555,11 +735,16 @@ int launch_colsum(const float* src, int ld, int n_rows, int n_cols, float* slab,
   return 0;
 }
 
-int launch_expand(const suave_plan* p, const int32_t* enc_src_dev, const suave_batch_t& b, float* x, hipStream_t s) {
+int launch_expand(const suave_plan* p, const suave_batch_t& b, float* x, int32_t* cells, hipStream_t s) {
   if (b.n_rows <= 0) return 0;
   ProfScope prof_scope(kProfExpand, s);
-  const int grid = std::min((b.n_rows + 3) / 4, 4096);
-  hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), 0, s, enc_src_dev, p->cols_dev, b, p->ldI, x);
+  const suave_model_t& m = p->model;
+  const int row_bytes = m.n_num * 4 + ((m.n_disc + 1) & ~1) * 2 + ((m.n_cols + 3) & ~3);
+  int rows_per_block = std::max(4, std::min(64, (48 * 1024) / std::max(row_bytes, 1)) & ~3);
+  SUAVE_REQUIRE((size_t)rows_per_block * row_bytes <= 48 * 1024, "expand: schema too wide for the staging buffer");
+  const int grid = std::min((b.n_rows + rows_per_block - 1) / rows_per_block, 4096);
+  hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), (size_t)rows_per_block * row_bytes, s, p->enc_map_dev, p->xsrc_dev, b,
+                     m.n_num, m.n_disc, m.n_cols, p->ldI, rows_per_block, x, cells);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -582,11 +767,12 @@ int launch_group(const GroupArgs& a, hipStream_t s) {
   return 0;
 }
 
+int reparam_grid(int n_rows) { return std::max(1, std::min((n_rows + 63) / 64, 1024)); }
+
 int launch_reparam(const LatentFwdArgs& a, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
-  const int64_t total = (int64_t)a.n_rows * ((a.D + 3) / 4);
   ProfScope prof_scope(kProfLatent, s);
-  hipLaunchKernelGGL(k_reparam, dim3((int)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_reparam, dim3(reparam_grid(a.n_rows)), dim3(256), sizeof(float) * 3 * a.K * a.D, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -25,7 +25,7 @@ namespace suave {
 
 namespace {
 
-constexpr int kMissing = 0x7FC0DEAD;  // cell sentinel: masked / unobserved
+constexpr int kMissing = kCellMissing;
 // 8 wavefronts share one 64-row tile (each walks every 8th column): two blocks per CU put 4 waves on every
 // SIMD, which is what hides the LDS / transcendental latency of the per-column chains.
 constexpr int kLossWaves = 8;
@@ -92,8 +92,7 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
   const ColChunk ch = a.chunks[chunk_id];
   const int hw_begin = a.cols[ch.col_begin].w_off;
   const int n_tiles = (a.n_rows + 63) / 64;
-  const int yq = (ch.y_len + 3) / 4;  // float4 per row of the chunk (ldY % 4 == 0, y_begin % 4 handled below)
-  double sum_recon = 0.0, sum_cat = 0.0, sum_gauss = 0.0;
+  double sum_recon = 0.0;
 
   const int ncc = ch.col_end - ch.col_begin;
   {
@@ -101,94 +100,86 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
                                                         : a.head_off + a.head_len;
     const int hw_len = min(a.hw_max, hw_next - hw_begin);
     for (int i = tid; i < hw_len; i += kLossThreads) wsm[i] = a.params[hw_begin + i];
-    for (int i = tid; i < ncc; i += kLossThreads) xsrc_s[i] = a.xsrc[ch.col_begin + i];
     if (GRAD)
       for (int i = tid; i < a.hw_max; i += kLossThreads) hw_acc[i] = 0.f;
   }
+
+  // Tile staging is software-pipelined: the y slice, the cells and the per-row scalars of the NEXT tile are
+  // loaded into registers before the column phase of the current one and stored to LDS after it, so the
+  // HBM round trip hides behind the arithmetic.  Each thread owns up to 4 float4 of y and 4 cells per tile
+  // (their (row, column) coordinates are fixed for the whole kernel); wider chunks stage the rest directly.
+  constexpr int kPre = 4;
+  const int ybase = ch.y_begin & ~3;  // aligned start column
+  const int lead = ch.y_begin - ybase;
+  const int nq = (lead + ch.y_len + 3) / 4;
+  int y_lr[kPre], y_q[kPre], c_lr[kPre], c_cc[kPre];
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const int idx = tid + u * kLossThreads;
+    y_lr[u] = idx / nq; y_q[u] = idx - y_lr[u] * nq;
+    c_lr[u] = idx / ncc; c_cc[u] = idx - c_lr[u] * ncc;
+  }
+  float4 y_pre[kPre];
+  int c_pre[kPre];
+  int k_pre = 0;
+  float up_pre = 0.f;
+  auto prefetch = [&](int tile) {
+    const int r0 = tile * 64;
+    const int nrows = min(64, a.n_rows - r0);
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+      y_pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past the table: finite zeros
+      if (y_lr[u] < nrows) y_pre[u] = *reinterpret_cast<const float4*>(a.y + (size_t)(r0 + y_lr[u]) * a.ldY + ybase + y_q[u] * 4);
+      c_pre[u] = kMissing;
+      if (c_lr[u] < nrows) c_pre[u] = a.cells[(size_t)((r0 + c_lr[u]) / a.vdiv) * a.n_cols + ch.col_begin + c_cc[u]];
+    }
+    if (tid < 64) {
+      k_pre = 0;
+      up_pre = 0.f;
+      if (tid < nrows) {
+        const int r = r0 + tid;
+        k_pre = a.kidx ? a.kidx[r] : (r % a.vdiv);
+        up_pre = a.c_up * (a.row_weight ? a.row_weight[r] : 1.0f);
+      }
+    }
+  };
+  auto put_y = [&](int lr, int q, const float4& v) {
+    float* dst = ytile + lr * a.ldy;
+    const int c0 = q * 4 - lead;
+    if (c0 >= 0 && c0 < ch.y_len) dst[c0] = v.x;
+    if (c0 + 1 >= 0 && c0 + 1 < ch.y_len) dst[c0 + 1] = v.y;
+    if (c0 + 2 >= 0 && c0 + 2 < ch.y_len) dst[c0 + 2] = v.z;
+    if (c0 + 3 >= 0 && c0 + 3 < ch.y_len) dst[c0 + 3] = v.w;
+  };
+  if ((int)blockIdx.x < n_tiles) prefetch(blockIdx.x);
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int r0 = tile * 64;
     const int nrows = min(64, a.n_rows - r0);
     __syncthreads();
     LOSS_T(t0);
-    // ---- stage the y tile (coalesced) ----
-    {
-      const int ybase = ch.y_begin & ~3;              // aligned start column
-      const int lead = ch.y_begin - ybase;
-      const int nq = (lead + ch.y_len + 3) / 4;
-      // wave = row, lane = float4 of the row; 4 rows of loads are issued before the first LDS store
-      for (int lr0 = wave; lr0 < 64; lr0 += 4 * kLossWaves) {
-        for (int q0 = 0; q0 < nq; q0 += 64) {
-          const int q = q0 + lane;
-          float4 v[4];
+    // ---- registers -> LDS ----
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int lr = lr0 + kLossWaves * u;
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past the table: finite zeros
-            if (q < nq && lr < nrows) v[u] = *reinterpret_cast<const float4*>(a.y + (size_t)(r0 + lr) * a.ldY + ybase + q * 4);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int lr = lr0 + kLossWaves * u;
-            if (q < nq && lr < 64) {
-              float* dst = ytile + lr * a.ldy;
-              const int c0 = q * 4 - lead;
-              if (c0 >= 0 && c0 < ch.y_len) dst[c0] = v[u].x;
-              if (c0 + 1 >= 0 && c0 + 1 < ch.y_len) dst[c0 + 1] = v[u].y;
-              if (c0 + 2 >= 0 && c0 + 2 < ch.y_len) dst[c0 + 2] = v[u].z;
-              if (c0 + 3 >= 0 && c0 + 3 < ch.y_len) dst[c0 + 3] = v[u].w;
-            }
-          }
-        }
-      }
-      (void)yq;
-      if (tid < 64) {
-        const int r = r0 + tid;
-        int k = 0;
-        float up = 0.f;
-        long long trow = 0;
-        if (tid < nrows) {
-          k = a.kidx ? a.kidx[r] : (r % a.vdiv);
-          up = a.c_up * (a.row_weight ? a.row_weight[r] : 1.0f);
-          const int64_t drow = (int64_t)(r / a.vdiv);
-          trow = a.batch.row_index ? (long long)a.batch.row_index[drow] : (long long)(a.batch.row_begin + drow);
-        }
-        k_s[tid] = k;
-        up_s[tid] = up;
-        trow_s[tid] = trow;
-      }
+    for (int u = 0; u < kPre; ++u) {
+      if (y_lr[u] < 64) put_y(y_lr[u], y_q[u], y_pre[u]);
+      if (c_lr[u] < 64) xs[c_lr[u] * a.ldx + c_cc[u]] = c_pre[u];
     }
-    __syncthreads();
+    if (tid < 64) { k_s[tid] = k_pre; up_s[tid] = up_pre; }
+    // wide chunks: what the per-thread registers do not cover is staged directly
+    for (int idx = tid + kPre * kLossThreads; idx < 64 * nq; idx += kLossThreads) {
+      const int lr = idx / nq, q = idx - lr * nq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lr < nrows) v = *reinterpret_cast<const float4*>(a.y + (size_t)(r0 + lr) * a.ldY + ybase + q * 4);
+      put_y(lr, q, v);
+    }
+    for (int idx = tid + kPre * kLossThreads; idx < 64 * ncc; idx += kLossThreads) {
+      const int lr = idx / ncc, cc = idx - lr * ncc;
+      xs[lr * a.ldx + cc] = lr < nrows ? a.cells[(size_t)((r0 + lr) / a.vdiv) * a.n_cols + ch.col_begin + cc] : kMissing;
+    }
     LOSS_T(t1);
-    // stage the tile's cells (mask folded in): wave = row, lane = column, 4 rows of loads in flight
-    for (int j0 = 0; j0 < ncc; j0 += 64) {
-      const int cc = j0 + lane;
-      const bool cok = cc < ncc;
-      const int src = cok ? xsrc_s[cc] : 0;
-      for (int lr0 = wave; lr0 < nrows; lr0 += 4 * kLossWaves) {
-        int v[4];
-        unsigned char mk[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int lr = lr0 + kLossWaves * u;
-          v[u] = 0;
-          mk[u] = 0;
-          if (cok && lr < nrows) {
-            const long long trow = trow_s[lr];
-            if (src & (1 << 30)) v[u] = (int)a.batch.codes[trow * a.batch.ld_disc + (src & 0xFFFFFF)];
-            else v[u] = __float_as_int(a.batch.xnum[trow * a.batch.ld_num + src]);
-            mk[u] = a.batch.mask[trow * a.batch.ld_mask + ch.col_begin + cc];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int lr = lr0 + kLossWaves * u;
-          if (cok && lr < nrows) xs[lr * a.ldx + cc] = mk[u] ? v[u] : kMissing;
-        }
-      }
-    }
     __syncthreads();
     LOSS_T(t2);
+    if (tile + (int)gridDim.x < n_tiles) prefetch(tile + gridDim.x);
 
     // ---- column phase: lane = row, wave-uniform column ----
     const bool valid = lane < nrows;
@@ -415,73 +406,6 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
       }
     }
 
-    // ---- KL phase (chunk 0 only): 4 lanes per row ----
-    if (a.do_kl && chunk_id == 0) {
-     if (tid < 256) {  // waves 0-3: 4 lanes per row
-      const int lr = tid >> 2, qd = tid & 3;
-      const bool v4 = lr < nrows;
-      const int rr = r0 + (v4 ? lr : 0);
-      const int kk = k_s[lr];
-      const int D = a.D;
-      // compact head buffer: [logits (ldK) | mu of the selected component (ldD) | raw logvar (ldD)]
-      const float* mu = a.encout + (size_t)rr * a.ldE + a.ldK;
-      const float* lv = mu + a.ldD;
-      const float* pm = a.params + a.prior_mu_off + kk * D;
-      const float* plv = a.params + a.prior_logvar_off + kk * D;
-      float gk = 0.f;
-      if (v4) {
-        for (int d = qd; d < D; d += 4) {
-          const float lvc = fminf(fmaxf(lv[d], kLogvarMin), kLogvarMax);
-          const float vp_raw = __expf(plv[d]);
-          const float vp = fmaxf(vp_raw, 1e-6f);
-          const float diff = mu[d] - pm[d];
-          const float elv = __expf(lvc);
-          gk += 0.5f * (plv[d] - lvc + (elv + diff * diff) / vp - 1.0f);
-          if (GRAD) {
-            a.gkl_mu[(size_t)rr * a.ldD + d] = a.bk * diff / vp;
-            a.gkl_lv[(size_t)rr * a.ldD + d] = a.bk * 0.5f * (elv / vp - 1.0f);
-            a.prior_terms[(size_t)rr * a.ldT + d] = -a.bk * diff / vp;
-            a.prior_terms[(size_t)rr * a.ldT + D + d] =
-                a.bk * 0.5f * (1.0f - (vp_raw >= 1e-6f ? (elv + diff * diff) / vp : 0.f));
-          }
-        }
-      }
-      gk += __shfl_xor(gk, 1, 64);
-      gk += __shfl_xor(gk, 2, 64);
-      float ck = 0.f;
-      if (v4 && qd == 0) {
-        const float* lg = a.encout + (size_t)rr * a.ldE;
-        const float* pl = a.params + a.prior_logits_off;
-        float mq = -INFINITY, mp = -INFINITY;
-        for (int j = 0; j < K; ++j) { mq = fmaxf(mq, lg[j]); mp = fmaxf(mp, pl[j]); }
-        float sq = 0.f, sp = 0.f;
-        for (int j = 0; j < K; ++j) { sq += __expf(lg[j] - mq); sp += __expf(pl[j] - mp); }
-        const float lq = mq + __logf(sq), lp = mp + __logf(sp);
-        for (int j = 0; j < K; ++j) {
-          const float logq = lg[j] - lq, logp = pl[j] - lp;
-          ck += __expf(logq) * (logq - logp);
-        }
-        if (GRAD) {
-          for (int j = 0; j < K; ++j) {
-            const float logq = lg[j] - lq, logp = pl[j] - lp;
-            const float q = __expf(logq);
-            a.gkl_logit[(size_t)rr * a.ldK + j] = a.bk * q * ((logq - logp) - ck);
-            a.prior_terms[(size_t)rr * a.ldT + 2 * D + j] = a.bk * (__expf(logp) - q);
-          }
-        }
-        a.catkl[rr] = ck;
-        a.gausskl[rr] = gk;
-      }
-      const float t_c = wave_sum_dpp((v4 && qd == 0) ? ck : 0.f);
-      const float t_g = wave_sum_dpp((v4 && qd == 0) ? gk : 0.f);
-      if (lane == 0) { red_s[wave * 2] = t_c; red_s[wave * 2 + 1] = t_g; }
-     }
-      __syncthreads();
-      if (tid == 0) {
-        sum_cat += (double)red_s[0] + (double)red_s[2] + (double)red_s[4] + (double)red_s[6];
-        sum_gauss += (double)red_s[1] + (double)red_s[3] + (double)red_s[5] + (double)red_s[7];
-      }
-    }
     LOSS_T(t5);
     LOSS_ACC(0, t1 - t0); LOSS_ACC(1, t2 - t1); LOSS_ACC(2, t3 - t2); LOSS_ACC(3, t3b - t3); LOSS_ACC(4, t5 - t3b);
     LOSS_ACC(5, 1);
@@ -503,8 +427,8 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
   if (tid == 0 && a.sums_slab) {
     double* s = a.sums_slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
     s[0] = sum_recon;
-    s[1] = sum_cat;
-    s[2] = sum_gauss;
+    s[1] = 0.0;
+    s[2] = 0.0;
     s[3] = 0.0;
   }
 }

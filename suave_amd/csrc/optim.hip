@@ -10,37 +10,62 @@ namespace suave {
 
 __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   const int seg_id = blockIdx.y;
-  if (seg_id == a.n_segs) {  // scalar sums (double), one block
-    if (blockIdx.x == 0 && threadIdx.x < 3 && a.sums_slab && a.sums_out) {
-      double t = 0.0;
-      for (int s = 0; s < a.n_sum_slabs; ++s) t += a.sums_slab[(size_t)s * 4 + threadIdx.x];
-      a.sums_out[threadIdx.x] += t;
-      if (threadIdx.x == 0) a.sums_out[3] += a.n_rows;
+  if (seg_id == a.n_segs) {  // scalar sums (double), one block: strided partials, then a fixed-order tree
+    if (blockIdx.x == 0 && a.sums_slab && a.sums_out) {
+      __shared__ double part[3][256];
+      const int t = threadIdx.x;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int s = t; s < a.n_sum_slabs; s += 256) {
+        s0 += a.sums_slab[(size_t)s * 4 + 0];
+        s1 += a.sums_slab[(size_t)s * 4 + 1];
+        s2 += a.sums_slab[(size_t)s * 4 + 2];
+      }
+      part[0][t] = s0; part[1][t] = s1; part[2][t] = s2;
+      __syncthreads();
+      for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) { part[0][t] += part[0][t + w]; part[1][t] += part[1][t + w]; part[2][t] += part[2][t + w]; }
+        __syncthreads();
+      }
+      if (t < 3) a.sums_out[t] += part[t][0];
+      if (t == 0) a.sums_out[3] += a.n_rows;
     }
     return;
   }
+  // wave = quarter of the slab range, lane = element: 4 x 16 loads in flight per element, the four partial
+  // sums are combined in a fixed order (deterministic).
+  __shared__ float part[4][64];
   const ReduceSeg sg = a.segs[seg_id];
   const int64_t total = (int64_t)sg.rows * sg.cols;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int i = (int)(e / sg.cols), j = (int)(e % sg.cols);
+  const int sub = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per = (sg.n_slabs + 3) / 4;
+  const int s_begin = min(sub * per, sg.n_slabs), s_end = min(sg.n_slabs, s_begin + per);
+  for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < total; e0 += (int64_t)gridDim.x * 64) {
+    const int64_t e = e0 + lane;
+    const bool valid = e < total;
+    const int i = valid ? (int)(e / sg.cols) : 0, j = valid ? (int)(e % sg.cols) : 0;
     const float* src = a.slab + sg.src_off + (int64_t)i * sg.src_ld + j;
-    // fixed summation order; 16 independent loads in flight per thread
     float t = 0.f;
-    int s = 0;
-    for (; s + 16 <= sg.n_slabs; s += 16) {
-      float v[16];
+    if (valid) {
+      int s = s_begin;
+      for (; s + 16 <= s_end; s += 16) {
+        float v[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = src[(int64_t)(s + q) * sg.slab_stride];
+        for (int q = 0; q < 16; ++q) v[q] = src[(int64_t)(s + q) * sg.slab_stride];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) t += v[q];
+        for (int q = 0; q < 16; ++q) t += v[q];
+      }
+      for (; s < s_end; ++s) t += src[(int64_t)s * sg.slab_stride];
     }
-    for (; s < sg.n_slabs; ++s) t += src[(int64_t)s * sg.slab_stride];
-    a.dst[sg.dst_off + (int64_t)i * sg.dst_si + (int64_t)j * sg.dst_sj] = t;
+    part[sub][lane] = t;
+    __syncthreads();
+    if (sub == 0 && valid)
+      a.dst[sg.dst_off + (int64_t)i * sg.dst_si + (int64_t)j * sg.dst_sj] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    __syncthreads();
   }
 }
 
 int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s) {
-  int gx = std::max(1, std::min((max_elems + 255) / 256, 256));
+  int gx = std::max(1, std::min((max_elems + 63) / 64, 1024));
   ProfScope prof_scope(kProfReduce, s);
   hipLaunchKernelGGL(k_reduce, dim3(gx, a.n_segs + 1), dim3(256), 0, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
