@@ -108,14 +108,15 @@ int tn_splits(const suave_plan* p, int n_out, int n_in1, int64_t rows) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(s, 512));
 }
 
+// blocks per column chunk of the likelihood kernel: about 16 independent wave workers per CU over all chunks
 int loss_grid(const suave_plan* p, int64_t rows) {
-  // about three resident 8-wave blocks per CU over all chunks; each block walks several tiles so that the
-  // register prefetch of the next tile overlaps the column phase of the current one
   const int64_t tiles = (rows + 63) / 64;
   const int64_t nch = std::max<size_t>(1, p->chunks_host.size());
-  const int64_t per_chunk = (3 * (int64_t)p->n_cu + nch - 1) / nch;
-  return (int)std::max<int64_t>(1, std::min<int64_t>(tiles, per_chunk));
+  const int wpb = loss_workers_per_block();
+  const int64_t workers = std::min<int64_t>(tiles, (16 * (int64_t)p->n_cu + nch - 1) / nch);
+  return (int)std::max<int64_t>(1, (workers + wpb - 1) / wpb);
 }
+int loss_workers(const suave_plan* p, int64_t rows) { return loss_grid(p, rows) * loss_workers_per_block(); }
 
 struct LayerRef {
   const suave_layer_t* l;
@@ -162,7 +163,7 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
                                    : round_up(m.n_components * m.latent_dim + m.latent_dim, 4);
   w->prior_terms = c.take<float>(R * ldT);
   w->onehot = c.take<float>(R * p->ldK);
-  w->cells = c.take<int32_t>(R * m.n_cols);
+  w->cells = c.take<int32_t>(((R + 63) / 64) * 64 * m.n_cols);
   {
     const int ldS = p->ldK + 2 * p->ldD;
     const bool sup = m.behaviour == 0;
@@ -185,7 +186,7 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
     const int ldc = round_up(l->n_in + 1, 4);
     slab += (size_t)tn_splits(p, l->n_out, l->n_in, rows) * l->n_out * ldc;
   }
-  const int lg = loss_grid(p, rows);
+  const int lg = loss_workers(p, rows);
   slab += (size_t)lg * m.head_len + 4;
   {
     const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components;
@@ -368,10 +369,11 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     return rc;
   const int n_chunks = (int)p->chunks_host.size();
   const int lgrid = loss_grid(p, V);
+  const int lworkers = loss_workers(p, V);
   const int ldT = round_up(K * D + D, 4);
   size_t slab_off = 0;
   float* head_slab = w.slab;
-  slab_off += ((size_t)lgrid * m.head_len + 3) & ~size_t(3);  // GEMM slabs start 16-byte aligned
+  slab_off += ((size_t)lworkers * m.head_len + 3) & ~size_t(3);  // GEMM slabs start 16-byte aligned
   {
     LossArgs a{};
     a.cols = p->cols_dev; a.chunks = p->chunks_dev; a.params = params; a.y = w.y; a.batch = *batch;
@@ -455,7 +457,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
       slab_off += (size_t)nb * ncol;
     }
     ReduceSeg sh{};
-    sh.src_off = 0; sh.slab_stride = m.head_len; sh.n_slabs = lgrid; sh.rows = 1; sh.cols = m.head_len;
+    sh.src_off = 0; sh.slab_stride = m.head_len; sh.n_slabs = lworkers; sh.rows = 1; sh.cols = m.head_len;
     sh.src_ld = m.head_len; sh.dst_off = m.head_off; sh.dst_si = 0; sh.dst_sj = 1;
     red.segs[red.n_segs++] = sh;
     max_elems = std::max(max_elems, m.head_len);
@@ -557,11 +559,12 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   }
   const int n_chunks = (int)p->chunks_host.size();
   const int lgrid = loss_grid(p, B);
+  const int lworkers = loss_workers(p, B);
   const int ldT = round_up(2 * m.latent_dim + m.n_components, 4);
   la.params = params; la.prior_logits_off = m.prior_logits_off; la.prior_mu_off = m.prior_mu_off;
   la.prior_logvar_off = m.prior_logvar_off; la.bk = beta_scale / (float)global_rows; la.grad = grad ? 1 : 0; la.ldT = ldT;
   la.catkl = w.catkl; la.gausskl = w.gausskl; la.gkl_logit = w.gkl_logit; la.gkl_mu = w.gkl_mu; la.gkl_lv = w.gkl_lv;
-  la.prior_terms = w.prior_terms; la.sums_slab = w.sums_slab + (size_t)lgrid * n_chunks * 4;
+  la.prior_terms = w.prior_terms; la.sums_slab = w.sums_slab + (size_t)lworkers * n_chunks * 4;
   if (int rc = launch_reparam(la, s)) return rc;
   // ---- decoder trunk ----
   act = w.z;
@@ -578,7 +581,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   // ---- fused likelihood (+ gradients) ----
   size_t slab_off = 0;
   float* head_slab = w.slab;
-  slab_off += ((size_t)lgrid * m.head_len + 3) & ~size_t(3);  // GEMM slabs start 16-byte aligned
+  slab_off += ((size_t)lworkers * m.head_len + 3) & ~size_t(3);  // GEMM slabs start 16-byte aligned
   {
     LossArgs a{};
     a.cols = p->cols_dev; a.chunks = p->chunks_dev; a.params = params; a.y = w.y; a.batch = *batch;
@@ -607,7 +610,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   red.slab = w.slab;
   red.dst = grads;
   red.sums_slab = w.sums_slab;
-  red.n_sum_slabs = lgrid * n_chunks + reparam_grid(B);
+  red.n_sum_slabs = lworkers * n_chunks + reparam_grid(B);
   red.sums_out = out ? out->sums : nullptr;
   red.n_rows = (double)B;
   int max_elems = 256;
@@ -709,7 +712,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     // ---- likelihood-head weights ----
     {
       ReduceSeg sh{};
-      sh.src_off = 0; sh.slab_stride = m.head_len; sh.n_slabs = lgrid; sh.rows = 1; sh.cols = m.head_len;
+      sh.src_off = 0; sh.slab_stride = m.head_len; sh.n_slabs = lworkers; sh.rows = 1; sh.cols = m.head_len;
       sh.src_ld = m.head_len; sh.dst_off = m.head_off; sh.dst_si = 0; sh.dst_sj = 1;
       red.segs[red.n_segs++] = sh;
       max_elems = std::max(max_elems, m.head_len);
@@ -820,8 +823,9 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
   p->max_classes = max_classes;
   // chunking of the schema for the loss kernel (LDS budget)
   {
-    // chunks of about equal y width, at most ~96 floats of y per tile row (LDS budget: two 8-wave blocks per CU)
-    const int kChunkY = 96;
+    // chunks of about equal y width, ~20 floats of y per tile row: a wave worker's private LDS slice stays near
+    // 10 KB (16 workers per CU) and its y tile fits the 8 float4 per lane of the register prefetch
+    const int kChunkY = 20;
     const int n_target = std::max(1, (m.total_y + kChunkY - 1) / kChunkY);
     const int y_target = (m.total_y + n_target - 1) / n_target;
     ColChunk cur{0, 0, 0, 0};

@@ -31,11 +31,11 @@ struct LossArgs {
   float* gkl_mu;       // [n_rows, ldD]
   float* gkl_lv;       // [n_rows, ldD]
   float* prior_terms;  // [n_rows, ldT]: d/d prior_mu_k | d/d prior_logvar_k | d/d prior_logits
-  float* head_slab;    // [gridDim.x, head_len]
-  double* sums_slab;   // [gridDim.x * gridDim.y, 4]
+  float* head_slab;    // [workers per chunk, head_len]  (worker = wavefront)
+  double* sums_slab;   // [chunks * workers per chunk, 4]
   int head_off, head_len, hw_max;
   const int32_t* xsrc;  // [n_cols] x_index | (1 << 30 for cat / ordinal)
-  const int32_t* cells; // [data rows, n_cols] packed cells from k_expand
+  const int32_t* cells; // [ceil(data rows / 64), n_cols, 64] packed cells from k_expand (tile-transposed)
   int n_cols;
   int ldx, ldm;         // LDS row strides of the staged cells (ints) and masks (bytes)
 };
@@ -173,6 +173,7 @@ int launch_colsum(const float* src, int ld, int n_rows, int n_cols, float* slab,
 
 size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes, int ldx, int ldm);
 int loss_set_lds_limit(size_t lds_bytes);
+int loss_workers_per_block();
 int launch_loss(const LossArgs& a, bool grad, int kmax, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s);
 int launch_expand(const suave_plan* p, const suave_batch_t& b, float* x, int32_t* cells, hipStream_t s);
 int launch_assign(const LatentFwdArgs& a, hipStream_t s);

@@ -16,7 +16,8 @@ namespace suave {
 //   kind 0 pad, 1 mask of column idx, 2 numeric cell xnum[idx], 3 one-hot of codes[idx], 4 thermometer of codes[idx]
 // A block stages the packed cells of its rows in LDS with coalesced row reads, then writes
 //   x     [B, ldI]    the encoder input (model.py:2784-2922 layout, quirks Q6/Q7), and
-//   cells [B, n_cols] one int per cell for the likelihood kernel: float bits / class code, kCellMissing when masked.
+//   cells [ceil(B/64), n_cols, 64] one int per cell for the likelihood kernel (tile-transposed): float bits /
+//         class code, kCellMissing when masked.
 __global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_map, const int32_t* __restrict__ xsrc,
                                                 suave_batch_t b, int n_num, int n_disc, int n_cols, int ldI,
                                                 int rows_per_block, float* __restrict__ x, int32_t* __restrict__ cells) {
@@ -83,15 +84,16 @@ __global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_
       }
     }
     if (cells) {
-      for (int c0 = 0; c0 < n_cols; c0 += 64) {
-        const int c = c0 + lane;
-        if (c >= n_cols) continue;
-        const int sx = xsrc[c];
-        const bool disc = (sx & (1 << 30)) != 0;
-        const int src = sx & 0xFFFFFF;
-        for (int lr = wave; lr < nrows; lr += 4) {
-          const int v = disc ? (int)cd_s[lr * ldd + src] : __float_as_int(xn_s[lr * ldn + src]);
-          cells[(size_t)(r0 + lr) * n_cols + c] = mk_s[lr * ldm + c] ? v : kCellMissing;
+      // tile-transposed layout [row / 64][column][row % 64]: lane = row, so the likelihood kernel's
+      // lane = row reads of one column are one coalesced 256-byte load
+      for (int lr = lane; lr < nrows; lr += 64) {
+        const int r = r0 + lr;
+        int32_t* dst = cells + ((size_t)(r >> 6) * n_cols) * 64 + (r & 63);
+        for (int c = wave; c < n_cols; c += 4) {
+          const int sx = xsrc[c];
+          const int src = sx & 0xFFFFFF;
+          const int v = (sx & (1 << 30)) ? (int)cd_s[lr * ldd + src] : __float_as_int(xn_s[lr * ldn + src]);
+          dst[(size_t)c * 64] = mk_s[lr * ldm + c] ? v : kCellMissing;
         }
       }
     }

@@ -26,9 +26,9 @@ namespace suave {
 namespace {
 
 constexpr int kMissing = kCellMissing;
-// 8 wavefronts share one 64-row tile (each walks every 8th column): two blocks per CU put 4 waves on every
-// SIMD, which is what hides the LDS / transcendental latency of the per-column chains.
-constexpr int kLossWaves = 8;
+// Every wavefront is an independent worker on (64-row tile, column chunk) tasks with private LDS: no block
+// barrier anywhere in the kernel, so a slow column type in one wave never stalls another.
+constexpr int kLossWaves = 4;
 constexpr int kLossThreads = kLossWaves * 64;
 
 // Sum over the 64 lanes with DPP row operations; result is wave-uniform.
@@ -58,7 +58,7 @@ __device__ __forceinline__ void acc_add_lanes(float* slot, float v) {
 }  // namespace
 
 #ifdef SUAVE_LOSS_TIMING
-__device__ unsigned long long g_loss_dbg[8];
+__device__ unsigned long long g_loss_dbg[16];
 #define LOSS_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define LOSS_ACC(i, v) dbg_acc[i] += (v)
 #else
@@ -69,78 +69,64 @@ __device__ unsigned long long g_loss_dbg[8];
 template <bool GRAD, int KMAX>
 __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
 #ifdef SUAVE_LOSS_TIMING
-  unsigned long long dbg_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_acc[16] = {0};
+  LOSS_T(tk0);
 #endif
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int K = a.K;
-  float* ytile = lds;                         // [64][ldy]
-  float* hw_acc = ytile + 64 * a.ldy;         // [hw_max]
-  float* wsm = hw_acc + a.hw_max;             // [hw_max] this chunk's head weights
-  int* k_s = reinterpret_cast<int*>(wsm + a.hw_max);               // [64]
-  float* up_s = reinterpret_cast<float*>(k_s + 64);                // [64]
-  float* red_s = up_s + 64;                   // [16]
-  long long* trow_s = reinterpret_cast<long long*>(red_s + 16);    // [64] table row of each tile row
-  int* xsrc_s = reinterpret_cast<int*>(trow_s + 64);               // [ldx] cell source of each chunk column
-  float* gs = reinterpret_cast<float*>(xsrc_s + a.ldx);            // [waves][max_classes][64]
-  int* xs = reinterpret_cast<int*>(gs + kLossWaves * a.max_classes * 64);  // [64][ldx] cell bits, kMissing when masked
-  float* ds_w = gs;                           // [waves][64][K]  (aliases gs + xs: used after the column phase)
-  float* recon_w = ds_w + kLossWaves * 64 * K;  // [waves][64]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_floats = 64 * a.ldy + 2 * a.hw_max + a.max_classes * 64;
+  float* ytile = lds + (size_t)wave * wave_floats;  // [64][ldy]  this wave's y slice, overwritten with dY
+  float* hw_acc = ytile + 64 * a.ldy;               // [hw_max]   head-weight gradients of this chunk
+  float* wsm = hw_acc + a.hw_max;                   // [hw_max]   this chunk's head weights
+  float* gsw = wsm + a.hw_max + lane;               // [max_classes][64] per-class scratch of the categorical head
   const int chunk_id = blockIdx.y;
   const ColChunk ch = a.chunks[chunk_id];
   const int hw_begin = a.cols[ch.col_begin].w_off;
   const int n_tiles = (a.n_rows + 63) / 64;
+  const int worker = blockIdx.x * kLossWaves + wave, n_workers = gridDim.x * kLossWaves;
   double sum_recon = 0.0;
+  const int hw_next = (chunk_id + 1 < (int)gridDim.y) ? a.cols[a.chunks[chunk_id + 1].col_begin].w_off
+                                                      : a.head_off + a.head_len;
+  const int hw_len = min(a.hw_max, hw_next - hw_begin);
+  for (int i = lane; i < hw_len; i += 64) wsm[i] = a.params[hw_begin + i];
+  if (GRAD)
+    for (int i = lane; i < a.hw_max; i += 64) hw_acc[i] = 0.f;
 
-  const int ncc = ch.col_end - ch.col_begin;
-  {
-    const int hw_next = (chunk_id + 1 < (int)gridDim.y) ? a.cols[a.chunks[chunk_id + 1].col_begin].w_off
-                                                        : a.head_off + a.head_len;
-    const int hw_len = min(a.hw_max, hw_next - hw_begin);
-    for (int i = tid; i < hw_len; i += kLossThreads) wsm[i] = a.params[hw_begin + i];
-    if (GRAD)
-      for (int i = tid; i < a.hw_max; i += kLossThreads) hw_acc[i] = 0.f;
-  }
-
-  // Tile staging is software-pipelined: the y slice, the cells and the per-row scalars of the NEXT tile are
-  // loaded into registers before the column phase of the current one and stored to LDS after it, so the
-  // HBM round trip hides behind the arithmetic.  Each thread owns up to 4 float4 of y and 4 cells per tile
-  // (their (row, column) coordinates are fixed for the whole kernel); wider chunks stage the rest directly.
-  constexpr int kPre = 4;
+  // Tile staging is software-pipelined: the y slice and the per-row scalars of the NEXT tile are loaded into
+  // registers before the column phase of the current one and stored to LDS after it, so the HBM round trip
+  // hides behind the arithmetic.  Each lane owns up to kPre float4 of the 64 x y_len slice (fixed (row,
+  // float4) coordinates for the whole kernel); wider chunks stage the rest directly.
+  constexpr int kPre = 6;
   const int ybase = ch.y_begin & ~3;  // aligned start column
   const int lead = ch.y_begin - ybase;
   const int nq = (lead + ch.y_len + 3) / 4;
-  int y_lr[kPre], y_q[kPre], c_lr[kPre], c_cc[kPre];
-#pragma unroll
-  for (int u = 0; u < kPre; ++u) {
-    const int idx = tid + u * kLossThreads;
-    y_lr[u] = idx / nq; y_q[u] = idx - y_lr[u] * nq;
-    c_lr[u] = idx / ncc; c_cc[u] = idx - c_lr[u] * ncc;
-  }
+  // slot u of a lane is flat index lane + 64 u of the [64][nq] float4 grid; only slot 0's coordinates are
+  // kept, the others follow by adding (64 / nq, 64 % nq) with carry (wave-uniform increments)
+  const int y_lr0 = lane / nq, y_q0 = lane - y_lr0 * nq;
+  const int step_lr = 64 / nq, step_q = 64 - step_lr * nq;
   float4 y_pre[kPre];
-  int c_pre[kPre];
   int k_pre = 0;
   float up_pre = 0.f;
   auto prefetch = [&](int tile) {
     const int r0 = tile * 64;
     const int nrows = min(64, a.n_rows - r0);
+    int lr = y_lr0, q = y_q0;
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
       y_pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past the table: finite zeros
-      if (y_lr[u] < nrows) y_pre[u] = *reinterpret_cast<const float4*>(a.y + (size_t)(r0 + y_lr[u]) * a.ldY + ybase + y_q[u] * 4);
-      c_pre[u] = kMissing;
-      if (c_lr[u] < nrows) c_pre[u] = a.cells[(size_t)((r0 + c_lr[u]) / a.vdiv) * a.n_cols + ch.col_begin + c_cc[u]];
+      if (lr < nrows) y_pre[u] = *reinterpret_cast<const float4*>(a.y + (size_t)(r0 + lr) * a.ldY + ybase + q * 4);
+      lr += step_lr; q += step_q;
+      if (q >= nq) { q -= nq; ++lr; }
     }
-    if (tid < 64) {
-      k_pre = 0;
-      up_pre = 0.f;
-      if (tid < nrows) {
-        const int r = r0 + tid;
-        k_pre = a.kidx ? a.kidx[r] : (r % a.vdiv);
-        up_pre = a.c_up * (a.row_weight ? a.row_weight[r] : 1.0f);
-      }
+    k_pre = 0;
+    up_pre = 0.f;
+    if (lane < nrows) {
+      const int r = r0 + lane;
+      k_pre = a.kidx ? a.kidx[r] : (r % a.vdiv);
+      up_pre = a.c_up * (a.row_weight ? a.row_weight[r] : 1.0f);
     }
   };
   auto put_y = [&](int lr, int q, const float4& v) {
@@ -151,43 +137,51 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
     if (c0 + 2 >= 0 && c0 + 2 < ch.y_len) dst[c0 + 2] = v.z;
     if (c0 + 3 >= 0 && c0 + 3 < ch.y_len) dst[c0 + 3] = v.w;
   };
-  if ((int)blockIdx.x < n_tiles) prefetch(blockIdx.x);
+  // dY of one float4 slot back to global: whole float4 when it lies inside the chunk, else its valid lanes
+  auto get_dy = [&](int r0, int nrows, int lr, int q) {
+    if (lr >= nrows) return;
+    const float* src = ytile + lr * a.ldy;
+    float* dst = a.y + (size_t)(r0 + lr) * a.ldY + ybase + q * 4;
+    const int c0 = q * 4 - lead;
+    if (c0 >= 0 && c0 + 3 < ch.y_len) {
+      *reinterpret_cast<float4*>(dst) = make_float4(src[c0], src[c0 + 1], src[c0 + 2], src[c0 + 3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c0 + e >= 0 && c0 + e < ch.y_len) dst[e] = src[c0 + e];
+    }
+  };
+  if (worker < n_tiles) prefetch(worker);
 
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (int tile = worker; tile < n_tiles; tile += n_workers) {
     const int r0 = tile * 64;
     const int nrows = min(64, a.n_rows - r0);
-    __syncthreads();
     LOSS_T(t0);
-    // ---- registers -> LDS ----
+    // ---- registers -> LDS (DS operations of one wave execute in order: no barrier needed) ----
+    {
+      int lr = y_lr0, q = y_q0;
 #pragma unroll
-    for (int u = 0; u < kPre; ++u) {
-      if (y_lr[u] < 64) put_y(y_lr[u], y_q[u], y_pre[u]);
-      if (c_lr[u] < 64) xs[c_lr[u] * a.ldx + c_cc[u]] = c_pre[u];
+      for (int u = 0; u < kPre; ++u) {
+        if (lr < 64) put_y(lr, q, y_pre[u]);
+        lr += step_lr; q += step_q;
+        if (q >= nq) { q -= nq; ++lr; }
+      }
     }
-    if (tid < 64) { k_s[tid] = k_pre; up_s[tid] = up_pre; }
-    // wide chunks: what the per-thread registers do not cover is staged directly
-    for (int idx = tid + kPre * kLossThreads; idx < 64 * nq; idx += kLossThreads) {
+    for (int idx = lane + kPre * 64; idx < 64 * nq; idx += 64) {  // wide chunks
       const int lr = idx / nq, q = idx - lr * nq;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (lr < nrows) v = *reinterpret_cast<const float4*>(a.y + (size_t)(r0 + lr) * a.ldY + ybase + q * 4);
       put_y(lr, q, v);
     }
-    for (int idx = tid + kPre * kLossThreads; idx < 64 * ncc; idx += kLossThreads) {
-      const int lr = idx / ncc, cc = idx - lr * ncc;
-      xs[lr * a.ldx + cc] = lr < nrows ? a.cells[(size_t)((r0 + lr) / a.vdiv) * a.n_cols + ch.col_begin + cc] : kMissing;
-    }
-    LOSS_T(t1);
-    __syncthreads();
-    LOSS_T(t2);
-    if (tile + (int)gridDim.x < n_tiles) prefetch(tile + gridDim.x);
+    const int k = k_pre;
+    const float up = up_pre;
+    if (tile + n_workers < n_tiles) prefetch(tile + n_workers);
 
     // ---- column phase: lane = row, wave-uniform column ----
     const bool valid = lane < nrows;
-    const int r = r0 + (valid ? lane : 0);
-    (void)r;
-    const int* xrow = xs + lane * a.ldx - ch.col_begin;
-    const int k = k_s[lane];
-    const float up = up_s[lane];
+    // packed cells in tile-transposed layout [row / 64][column][row % 64]: one coalesced load per column
+    const int drow = a.vdiv == 1 ? r0 + lane : (r0 + lane) / a.vdiv;
+    const int32_t* cell_ptr = a.cells + ((size_t)(drow >> 6) * a.n_cols) * 64 + (drow & 63);
     float recon = 0.f;
     float ds[KMAX];
     if (GRAD) {
@@ -195,11 +189,15 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
       for (int j = 0; j < KMAX; ++j) ds[j] = 0.f;
     }
     float* yrow = ytile + lane * a.ldy;
-    float* gsw = gs + wave * a.max_classes * 64 + lane;
+    int cell_next = valid ? cell_ptr[(size_t)ch.col_begin * 64] : kMissing;
 
-    for (int c = ch.col_begin + wave; c < ch.col_end; c += kLossWaves) {
+    LOSS_T(t1);
+    LOSS_ACC(0, t1 - t0);
+    for (int c = ch.col_begin; c < ch.col_end; ++c) {
+      LOSS_T(tc0);
       const suave_col_t col = a.cols[c];
-      const int cell = valid ? xrow[c] : kMissing;
+      const int cell = cell_next;
+      if (c + 1 < ch.col_end) cell_next = valid ? cell_ptr[(size_t)(c + 1) * 64] : kMissing;
       const bool obs = cell != kMissing;
       const float u = obs ? up : 0.f;
       float* yb = yrow + (col.y_off - ch.y_begin);
@@ -365,67 +363,65 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
           }
         }
       }
+      LOSS_T(tc1);
+      LOSS_ACC(1 + col.type, tc1 - tc0);
+      LOSS_ACC(8 + col.type, 1);
     }
+    LOSS_T(t2);
 
-    // ---- cross-wave reduction of the per-row terms (ds_w / recon_w alias the cell tile) ----
-    LOSS_T(t3);
-    __syncthreads();
-    LOSS_T(t3b);
-    recon_w[wave * 64 + lane] = recon;
-    if (GRAD) {
+    // ---- per-row outputs straight from the registers (lane = row) ----
+    if (valid) a.recon_part[(size_t)chunk_id * a.n_rows + r0 + lane] = recon;
+    {
+      const float tot = wave_sum_dpp(valid ? recon : 0.f);
+      sum_recon += (double)tot;
+    }
+#ifdef SUAVE_LOSS_TIMING
+    LOSS_T(t2a);
+    LOSS_ACC(15, t2a - t2);
+#endif
+    if (GRAD && a.ds_part && valid) {
+      float* dst = a.ds_part + ((size_t)chunk_id * a.n_rows + r0 + lane) * a.ldK;
 #pragma unroll
       for (int j = 0; j < KMAX; ++j)
-        if (j < K) ds_w[(wave * 64 + lane) * K + j] = ds[j];
+        if (j < K) dst[j] = ds[j];
     }
-    __syncthreads();
-    if (tid < 64) {
-      float rsum = 0.f;
-#pragma unroll
-      for (int w = 0; w < kLossWaves; ++w) rsum += recon_w[w * 64 + tid];
-      if (tid < nrows) a.recon_part[(size_t)chunk_id * a.n_rows + r0 + tid] = rsum;
-      const float tot = wave_sum_dpp(tid < nrows ? rsum : 0.f);
-      if (tid == 0) sum_recon += (double)tot;
-    }
-    if (GRAD && a.ds_part) {
-      if (tid < nrows) {
-        float* dst = a.ds_part + ((size_t)chunk_id * a.n_rows + r0 + tid) * a.ldK;
-        for (int j = 0; j < K; ++j) {
-          float t = 0.f;
-#pragma unroll
-          for (int w = 0; w < kLossWaves; ++w) t += ds_w[(w * 64 + tid) * K + j];
-          dst[j] = t;
-        }
-      }
-    }
-    // ---- write dY back (coalesced) ----
+#ifdef SUAVE_LOSS_TIMING
+    LOSS_T(t2b);
+    LOSS_ACC(12, t2b - t2);
+#endif
+    // ---- write dY back ----
     if (GRAD) {
-      for (int lr = wave; lr < nrows; lr += kLossWaves) {
-        float* dst = a.y + (size_t)(r0 + lr) * a.ldY + ch.y_begin;
-        const float* src = ytile + lr * a.ldy;
-        for (int cc = lane; cc < ch.y_len; cc += 64) dst[cc] = src[cc];
+      int lr = y_lr0, q = y_q0;
+#pragma unroll
+      for (int u = 0; u < kPre; ++u) {
+        if (lr < 64) get_dy(r0, nrows, lr, q);
+        lr += step_lr; q += step_q;
+        if (q >= nq) { q -= nq; ++lr; }
+      }
+      for (int idx = lane + kPre * 64; idx < 64 * nq; idx += 64) {
+        const int lr = idx / nq;
+        get_dy(r0, nrows, lr, idx - lr * nq);
       }
     }
-
-    LOSS_T(t5);
-    LOSS_ACC(0, t1 - t0); LOSS_ACC(1, t2 - t1); LOSS_ACC(2, t3 - t2); LOSS_ACC(3, t3b - t3); LOSS_ACC(4, t5 - t3b);
-    LOSS_ACC(5, 1);
+    LOSS_T(t3);
+    LOSS_ACC(6, t3 - t2);
+    LOSS_ACC(13, 1);
   }
 #ifdef SUAVE_LOSS_TIMING
-  if (lane == 0)
-    for (int i = 0; i < 6; ++i) atomicAdd(&g_loss_dbg[i], dbg_acc[i]);
-#endif
-
-  __syncthreads();
-  if (GRAD && a.head_slab) {
-    const int len = a.hw_max;  // this chunk's head range is [hw_begin, hw_begin + chunk length)
-    const int next = (chunk_id + 1 < (int)gridDim.y) ? a.cols[a.chunks[chunk_id + 1].col_begin].w_off
-                                                      : a.head_off + a.head_len;
-    const int n = min(len, next - hw_begin);
-    float* dst = a.head_slab + (size_t)blockIdx.x * a.head_len + (hw_begin - a.head_off);
-    for (int i = tid; i < n; i += kLossThreads) dst[i] = hw_acc[i];
+  {
+    LOSS_T(tk1);
+    dbg_acc[7] = tk1 - tk0;
+    dbg_acc[14] = 1;
+    if (lane == 0)
+      for (int i = 0; i < 16; ++i) atomicAdd(&g_loss_dbg[i], dbg_acc[i]);
   }
-  if (tid == 0 && a.sums_slab) {
-    double* s = a.sums_slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+#endif
+  if (GRAD && a.head_slab) {
+    float* dst = a.head_slab + (size_t)worker * a.head_len + (hw_begin - a.head_off);
+    for (int i = lane; i < hw_len; i += 64) dst[i] = hw_acc[i];
+  }
+  if (lane == 0 && a.sums_slab) {
+    double* s = a.sums_slab + ((size_t)blockIdx.y * n_workers + worker) * 4;
     s[0] = sum_recon;
     s[1] = 0.0;
     s[2] = 0.0;
@@ -434,11 +430,11 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
 }
 
 size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes, int ldx, int ldm) {
-  (void)ldm;
-  const size_t cells = std::max((size_t)kLossWaves * max_classes * 64 + (size_t)64 * ldx, (size_t)kLossWaves * 64 * K + kLossWaves * 64);
-  size_t floats = (size_t)64 * ldy + 2 * (size_t)hw_max + 64 + 64 + 16 + 2 * 64 + ldx + cells;
-  return floats * sizeof(float);
+  (void)K; (void)ldx; (void)ldm;
+  return (size_t)kLossWaves * ((size_t)64 * ldy + 2 * (size_t)hw_max + (size_t)max_classes * 64) * sizeof(float);
 }
+
+int loss_workers_per_block() { return kLossWaves; }
 
 template <int KMAX>
 static int launch_loss_k(const LossArgs& a, bool grad, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s) {
@@ -453,8 +449,9 @@ static int launch_loss_k(const LossArgs& a, bool grad, int grid_x, int n_chunks,
 int launch_loss(const LossArgs& a, bool grad, int kmax, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
   ProfScope prof_scope(kProfLoss, s);
-  if (kmax <= 8) return launch_loss_k<8>(a, grad, grid_x, n_chunks, lds_bytes, s);
-  if (kmax <= 16) return launch_loss_k<16>(a, grad, grid_x, n_chunks, lds_bytes, s);
+  if (a.K <= 8) return launch_loss_k<8>(a, grad, grid_x, n_chunks, lds_bytes, s);
+  if (a.K <= 12) return launch_loss_k<12>(a, grad, grid_x, n_chunks, lds_bytes, s);
+  if (a.K <= 16) return launch_loss_k<16>(a, grad, grid_x, n_chunks, lds_bytes, s);
   return launch_loss_k<32>(a, grad, grid_x, n_chunks, lds_bytes, s);
 }
 
@@ -469,6 +466,8 @@ int loss_set_lds_limit(size_t lds_bytes) {
   int rc = 0;
   rc |= set_lds_one<true, 8>(lds_bytes);
   rc |= set_lds_one<false, 8>(lds_bytes);
+  rc |= set_lds_one<true, 12>(lds_bytes);
+  rc |= set_lds_one<false, 12>(lds_bytes);
   rc |= set_lds_one<true, 16>(lds_bytes);
   rc |= set_lds_one<false, 16>(lds_bytes);
   rc |= set_lds_one<true, 32>(lds_bytes);
@@ -476,9 +475,10 @@ int loss_set_lds_limit(size_t lds_bytes) {
   return rc;
 }
 
+
 #ifdef SUAVE_LOSS_TIMING
 extern "C" int suave_debug_loss_timing(unsigned long long* out, int reset) {
-  unsigned long long z[8] = {0};
+  unsigned long long z[16] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loss_dbg), sizeof(z)) != hipSuccess) return 1;
   if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_loss_dbg), z, sizeof(z)) != hipSuccess) return 1;
   return 0;
