@@ -148,6 +148,102 @@ def cpu_baseline(spec, stats, dropout, budget_s=15.0, batch=4096):
             "sample": f"{len(times) - 1} ELBO steps (fwd+bwd+Adam) of the numpy oracle on {batch} S64 rows, median"}
 
 
+def generation_rates(eng, table, rows, gen_rows, device, rank, world, dist, fence, prof):
+    """sample() / impute() rows/sec (BASELINE.json config #5 on this rank's shard): device-side throughput with the
+    outputs left in HBM in the packed columnar layout (host DataFrame assembly is not part of the kernels' rate).
+    Rows are sharded over ranks with no collective; every generator is keyed by the global row index."""
+
+    import torch
+
+    from suave_amd import lib as slib
+
+    K, D = eng.layout.n_components, eng.layout.latent_dim
+    chunk = 1 << 18
+    # training-posterior cache of this rank's table (model.py:1669-1741), labels Bernoulli(0.3)
+    n_cache = min(rows, 1_000_000)
+    probs = torch.empty((n_cache, K), device=device)
+    mu = torch.empty((n_cache, K, D), device=device)
+    lv = torch.empty((n_cache, K, D), device=device)
+    for s0 in range(0, n_cache, chunk):
+        nb = min(chunk, n_cache - s0)
+        o = eng.encode(table, s0, nb)
+        probs[s0:s0 + nb] = o["probs"]
+        mu[s0:s0 + nb] = o["enc_out"][:, K:K + K * D].view(nb, K, D)
+        lv[s0:s0 + nb] = o["enc_out"][:, K + K * D:].view(nb, K, D)
+    g = torch.Generator(device=device)
+    g.manual_seed(99 + rank)
+    train_y = (torch.rand(n_cache, device=device, generator=g) < 0.3).to(torch.int64)
+    order = torch.argsort(train_y, stable=True)
+    n0 = int((train_y == 0).sum().item())
+    class_off = torch.tensor([0, n0, n_cache], device=device, dtype=torch.int64)
+    labels = (torch.rand(chunk, device=device, generator=g) < 0.3).to(torch.int32)
+    res = {}
+
+    def timed(fn, n_rows_done, name):
+        fn()  # warm-up pass (allocator, code objects)
+        fence()
+        if prof:
+            slib.load().suave_profile_enable(1)
+        t0 = time.perf_counter()
+        fn()
+        fence()
+        dt = time.perf_counter() - t0
+        ms = (C.c_double * 8)()
+        cnt = (C.c_int64 * 8)()
+        if prof:
+            slib.load().suave_profile_enable(0)
+            slib.check(slib.load().suave_profile_read(ms, cnt, 8), "suave_profile_read")
+        if dist is not None:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        res[name] = {"rows_per_s": world * n_rows_done / dt, "rows": world * n_rows_done, "seconds": dt}
+        if prof and cnt[6] > 0:
+            res[name]["sample_kernel_ms"] = ms[6]
+            res[name]["gemm_ms"] = ms[0]
+        return ms, cnt
+
+    base = rank * gen_rows
+
+    def run_sample():
+        for s0 in range(0, gen_rows, chunk):
+            nb = min(chunk, gen_rows - s0)
+            z, comp = eng.conditional_latents(labels[:nb], class_off, order, probs, mu, lv, seed=7, row_offset=base + s0)
+            eng.decode_sample(z, component=comp, seed=8, row_offset=base + s0)
+
+    ms, cnt = timed(run_sample, gen_rows, "sample_conditional")
+    if prof and cnt[6] > 0:
+        # k_sample_heads against HBM: reads y_full (4 B x Y) and writes the packed columnar output
+        L = eng.layout
+        bytes_row = 4 * L.total_y + 4 * L.n_num + 2 * L.n_disc
+        gbs = bytes_row * gen_rows / (ms[6] * 1e-3) / 1e9
+        res["roofline_sample_heads"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                        "frac": gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_row": bytes_row}
+    n_imp = min(rows, 1_000_000)
+
+    def run_impute():  # reference-exact single pass at the posterior-mean latent, hard assignment (model.py:3627-3651)
+        for s0 in range(0, n_imp, chunk):
+            nb = min(chunk, n_imp - s0)
+            o = eng.encode(table, s0, nb)
+            comp = o["probs"].argmax(dim=1).to(torch.int32)
+            z = o["enc_out"][:, K:K + K * D].view(nb, K, D)[torch.arange(nb, device=device), comp.long()].contiguous()
+            eng.decode_sample(z, component=comp, seed=9, row_offset=rank * n_imp + s0)
+
+    timed(run_impute, n_imp, "impute_single_pass")
+    Ldraws, mc_chunk = 32, 1 << 14
+
+    def run_impute_mc():  # posterior-predictive MC, 32 draws per row, every cell decoded (model.py:3304-3421 generalised)
+        for s0 in range(0, n_imp, mc_chunk):
+            nb = min(mc_chunk, n_imp - s0)
+            o = eng.encode(table, s0, nb)
+            z, comp = eng.posterior_draws(o["enc_out"], Ldraws, seed=10, row_offset=(rank * n_imp + s0) * Ldraws)
+            eng.decode_sample(z, component=comp, seed=11, row_offset=(rank * n_imp + s0) * Ldraws)
+
+    timed(run_impute_mc, n_imp, "impute_mc32")
+    res["impute_mc32"]["decoded_rows_per_s"] = res["impute_mc32"]["rows_per_s"] * Ldraws
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,6 +254,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--gen-rows", type=int, default=8_000_000, help="rows per GPU for the sample() measurement (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -237,6 +334,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     sums = eng.sums.cpu().numpy()
+    gen = generation_rates(eng, table, rows, args.gen_rows, device, rank, world, dist, fence, prof) if args.gen_rows > 0 else None
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -270,6 +368,16 @@ def main():
                                                   "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                                   "frac": loss_bytes * steps / (ms[1] * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                                   "traffic": None}
+        if gen is not None:
+            line["generation"] = gen
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if "roofline" in line and os.path.exists(pmc):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
+            with open(pmc) as fh:
+                t = json.load(fh)
+            line["roofline"]["traffic"] = t.get("gemm", {}).get("hbm_bytes_per_launch")
+            line["roofline"]["traffic_source"] = t.get("source")
+            if "roofline_likelihood_kl" in line:
+                line["roofline_likelihood_kl"]["traffic"] = t.get("likelihood_kl", {}).get("hbm_bytes_per_launch")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(spec, stats, args.dropout)
         print(json.dumps(line))
