@@ -57,6 +57,30 @@ def s64_schema(n_cols=64):
     return spec, stats
 
 
+def w1024_schema():
+    """400 real, 200 pos, 100 count, 224 cat (classes cycle 2..256), 100 ordinal
+    (classes cycle 3,5,7,10), interleaved by a seeded shuffle; Y = 15 605, encoder input 16 629."""
+
+    import numpy as _np
+
+    cat_c, ord_c = [2, 4, 8, 16, 32, 64, 128, 256], [3, 5, 7, 10]
+    kinds = [("real", None)] * 400 + [("pos", None)] * 200 + [("count", None)] * 100
+    kinds += [("cat", cat_c[i % 8]) for i in range(224)] + [("ordinal", ord_c[i % 4]) for i in range(100)]
+    order = _np.random.default_rng(4).permutation(len(kinds))
+    spec, stats = {}, {}
+    for j, i in enumerate(order):
+        t, c = kinds[i]
+        name = f"f{j}"
+        if c is not None:
+            spec[name] = {"type": t, "n_classes": c}
+            stats[name] = {}
+        else:
+            spec[name] = {"type": t}
+            stats[name] = ({"mean": 50.0, "std": 12.0} if t == "real" else
+                           {"mean_log": 1.2, "std_log": 0.45} if t == "pos" else {"offset": 1.0})
+    return spec, stats
+
+
 def synth_table_device(layout, n_rows, device, seed):
     """Synthetic S64 table generated directly in HBM (torch is plumbing here, not the measured path)."""
 
@@ -105,6 +129,12 @@ def gemm_flops_per_row(layout):
         mac += prev * h
         prev = h
     mac += prev * Y
+    # wide categorical heads run as GEMMs too (logits_layer on [y_col ; s], decoder.py:201-206)
+    from suave_amd.plan import WIDE_CAT_MIN_CLASSES
+    for n in layout.schema.feature_names:
+        sp = layout.schema[n]
+        if sp.type == "cat" and int(sp.n_classes) >= WIDE_CAT_MIN_CLASSES:
+            mac += (int(sp.n_classes) - 1) * (int(sp.n_classes) + K)
     return 6 * mac
 
 
@@ -249,7 +279,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=65536, help="rows per GPU per step")
+    ap.add_argument("--config", choices=["s64", "w1024"], default="s64",
+                    help="s64 = BASELINE config #2/#3 (headline); w1024 = config #4 (wide schema, latent 128)")
+    ap.add_argument("--batch", type=int, default=0, help="rows per GPU per step (default 65536 for s64, 8192 for w1024)")
     ap.add_argument("--rows", type=int, default=0, help="table rows per GPU (default 1M at N=1, 2M at N>1)")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -277,8 +309,14 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
-    spec, stats = s64_schema()
-    layout = ModelLayout(Schema(spec), K_COMP, LATENT, HIDDEN, args.dropout, "supervised", stats)
+    wide = args.config == "w1024"
+    spec, stats = w1024_schema() if wide else s64_schema()
+    latent, hidden = (128, (384, 256)) if wide else (LATENT, HIDDEN)
+    if not args.batch:
+        args.batch = 8192 if wide else 65536
+    if wide and not args.rows:
+        args.rows = 131072
+    layout = ModelLayout(Schema(spec), K_COMP, latent, hidden, args.dropout, "supervised", stats)
     eng = Engine(layout, device)
     eng.load_state(layout.init_params(seed=0))  # identical replicas on every rank
     rows = args.rows or (1_000_000 if world == 1 else 2_000_000)
@@ -334,7 +372,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     sums = eng.sums.cpu().numpy()
-    gen = generation_rates(eng, table, rows, args.gen_rows, device, rank, world, dist, fence, prof) if args.gen_rows > 0 else None
+    gen = (generation_rates(eng, table, rows, args.gen_rows, device, rank, world, dist, fence, prof)
+           if args.gen_rows > 0 and not wide else None)
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -343,8 +382,11 @@ def main():
             "metric": "ELBO train rows/sec", "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("S64: 1M rows x 64 mixed cols (13 real/13 pos/13 count/13 cat/12 ordinal, 10%% masked), "
-                                    "latent 32, K=10, hidden (256,128), dropout %.2f, fwd+bwd+Adam" % args.dropout)
+            "config": {"workload": ("W1024: %d rows x 1024 mixed cols (400 real/200 pos/100 count/224 cat up to 256 classes/"
+                                    "100 ordinal, 10%% masked), latent 128, K=10, hidden (384,256), dropout %.2f, "
+                                    "fwd+bwd+Adam" % (rows, args.dropout)) if wide else
+                       ("S64: 1M rows x 64 mixed cols (13 real/13 pos/13 count/13 cat/12 ordinal, 10%% masked), "
+                        "latent 32, K=10, hidden (256,128), dropout %.2f, fwd+bwd+Adam" % args.dropout)
                        if world == 1 else
                        ("S64 data-parallel: %dM rows x 64 cols row-sharded over %d GPUs, RCCL all-reduce of the flat "
                         "gradient per step" % (rows * world // 1_000_000, world)),
@@ -362,7 +404,8 @@ def main():
                                 "avg_launch_us": 1e3 * ms[0] / cnt[0],
                                 "algorithmic_flops_per_launch": gemm_flops / cnt[0]}
             line["kernel_ms_per_step"] = {PROF_CLASSES[i]: ms[i] / steps for i in range(8) if cnt[i] > 0}
-            loss_bytes = 3.0e3 * B  # ~3.0 KB/row fwd+bwd for the fused likelihood+KL kernel
+            # ~3.0 KB/row (S64) / ~196 KB/row (W1024) fwd+bwd for the fused likelihood+KL kernel(s)
+            loss_bytes = (196.0e3 if wide else 3.0e3) * B
             if cnt[1] > 0:
                 line["roofline_likelihood_kl"] = {"bound": "hbm", "achieved": loss_bytes * steps / (ms[1] * 1e-3) / 1e9,
                                                   "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -371,14 +414,14 @@ def main():
         if gen is not None:
             line["generation"] = gen
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if "roofline" in line and os.path.exists(pmc):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
+        if "roofline" in line and os.path.exists(pmc) and not wide and B == 65536:  # HBM bytes per launch from the committed rocprofv3 --pmc passes
             with open(pmc) as fh:
                 t = json.load(fh)
             line["roofline"]["traffic"] = t.get("gemm", {}).get("hbm_bytes_per_launch")
             line["roofline"]["traffic_source"] = t.get("source")
             if "roofline_likelihood_kl" in line:
                 line["roofline_likelihood_kl"]["traffic"] = t.get("likelihood_kl", {}).get("hbm_bytes_per_launch")
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not wide:
             line["cpu_baseline"] = cpu_baseline(spec, stats, args.dropout)
         print(json.dumps(line))
     if dist is not None:

@@ -49,13 +49,21 @@ extern "C" {
 
 #define SUAVE_MAX_HIDDEN 8
 #define SUAVE_MAX_COMPONENTS 32
+/* Categorical columns with at least this many classes are "wide": their logits_layer
+ * (decoder.py:201-206) runs as MFMA GEMMs instead of inside the fused likelihood kernel.
+ * Layout consequences: the y slices of the narrow columns are
+ * contiguous in schema order from 0; behind them (16-byte aligned) every wide column owns a
+ * slot [y (y_dim) | assignment s (K) | pad to 4] of the internal y buffer, and its weight
+ * matrix is stored [C-1, ld] with ld = y_dim + K rounded up to 4, 16-byte aligned, behind
+ * the narrow head weights. */
+#define SUAVE_WIDE_CAT_MIN_CLASSES 17
 
 /* One column of the schema, in schema order (suave/types.py:9-33; head
  * modules suave/modules/decoder.py:56-265). */
 typedef struct suave_col_t {
   int32_t type;      /* SUAVE_TYPE_* */
   int32_t n_classes; /* cat / ordinal, else 0 */
-  int32_t y_off;     /* first column of this feature's slice of y_full (decoder.py:306-314) */
+  int32_t y_off;     /* first column of this feature's slice of the internal y buffer (decoder.py:306-314) */
   int32_t y_dim;     /* width of that slice (types.py:267-287) */
   int32_t x_index;   /* column in xnum (numeric types) or in codes (cat / ordinal) */
   int32_t enc_off;   /* first column of the feature's values in the encoder input (model.py:2813-2905) */
@@ -94,6 +102,10 @@ typedef struct suave_model_t {
    * (prior.py:20-39), prior logits / logvar fixed at zero (model.py:538-542). */
   int32_t prior_logits_off, prior_mu_off, prior_logvar_off;
   int32_t pm_w_off, pm_b_off;
+  /* rows of y_projection / columns of the internal y buffer: total_y plus the alignment pads and
+   * assignment slots of the wide categorical columns (== total_y when the schema has none).  Pad
+   * rows of y_projection hold zeros. */
+  int32_t y_rows;
 } suave_model_t;
 
 /* A batch of rows of the packed table.  row_index == NULL selects rows
@@ -208,8 +220,8 @@ int suave_conditional_latents(const suave_plan* plan, const int64_t* class_offse
  * out_num float32 [n, ld_num] (real, pos, count as float), out_codes int16
  * [n, ld_disc].  noise_normal [n, n_cols], noise_uniform [n, n_cols],
  * noise_exp [n, total classes] inject draws (any may be NULL).  y_full_out
- * [n, total_y] optionally receives decoder.y_projection's output (the input of
- * the heads, decoder.py:344) -- NULL to skip. */
+ * [n, y_rows] optionally receives decoder.y_projection's output (the input of
+ * the heads, decoder.py:344) in the internal column layout -- NULL to skip. */
 int suave_decode_sample(const suave_plan* plan, const float* params, const float* z, const float* s,
                         const int32_t* component, int64_t n, const float* noise_normal,
                         const float* noise_uniform, const float* noise_exp, uint64_t seed,

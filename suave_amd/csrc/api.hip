@@ -81,6 +81,7 @@ struct Workspace {
   float *sel, *dsel, *gslab;
   int32_t *perm, *lrank, *blk_cnt, *blk_base, *chunk_comp, *chunk_begin;
   int n_blocks, n_chunks_max;
+  float* wideL;  // [rows, ldL] logits / logit gradients of the wide categorical columns
   float* slab;
   double* sums_slab;
   size_t slab_floats;
@@ -118,6 +119,14 @@ int loss_grid(const suave_plan* p, int64_t rows) {
 }
 int loss_workers(const suave_plan* p, int64_t rows) { return loss_grid(p, rows) * loss_workers_per_block(); }
 
+// split count of the grouped weight-gradient GEMM of the wide categorical columns
+int wide_splits(const suave_plan* p, int64_t rows) {
+  const int64_t tiles = std::max(1, p->wide_cum_total[2]);
+  int64_t s = (2 * (int64_t)p->n_cu + tiles - 1) / tiles;
+  s = std::min<int64_t>(s, std::max<int64_t>(1, rows / 256));
+  return (int)std::max<int64_t>(1, std::min<int64_t>(s, 64));
+}
+
 struct LayerRef {
   const suave_layer_t* l;
 };
@@ -151,8 +160,10 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
   }
   w->kidx = c.take<int32_t>(R);
   const size_t nch = p->chunks_host.size();
-  w->recon_part = c.take<float>(nch * R);
-  w->ds_part = c.take<float>(nch * R * p->ldK);
+  const bool any_wide = !p->wide_host.empty();
+  w->recon_part = c.take<float>((nch + 1) * R);
+  w->ds_part = c.take<float>((nch + 1) * R * p->ldK);
+  w->wideL = c.take<float>(any_wide ? R * p->ldL : 4);
   w->catkl = c.take<float>(R);
   w->gausskl = c.take<float>(R);
   w->recon = c.take<float>(R);
@@ -193,9 +204,10 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
     slab += (size_t)tn_splits(p, Mt, Nt, rows) * Mt * round_up(Nt + 1, 4);
   }
   if (m.behaviour == 1) slab += (size_t)lg * (m.n_components * m.latent_dim + m.latent_dim);
+  if (any_wide) slab += (size_t)wide_splits(p, rows) * p->wide_len + 4;
   w->slab_floats = slab;
   w->slab = c.take<float>(slab);
-  w->sums_slab = c.take<double>(((size_t)lg * nch + 1024) * 4);
+  w->sums_slab = c.take<double>(((size_t)lg * nch + 1024 + 4096) * 4);
   w->total_bytes = (c.off + 255) & ~size_t(255);
 }
 
@@ -301,6 +313,57 @@ int bwd_layer(const suave_plan* p, const float* params, const suave_layer_t& l, 
   return launch_gemm_pair(bwd_data_args(params, l, dC, lddc, dA_in, ldda, rows, H_in, drop_p), w, p->n_cu, s);
 }
 
+WideRowArgs wide_row_args(const suave_plan* p, const Workspace& w, int rows) {
+  WideRowArgs a{};
+  a.wide = p->wide_dev; a.n_wide = (int)p->wide_host.size(); a.n_rows = rows; a.vdiv = 1;
+  a.K = p->model.n_components; a.ldK = p->ldK; a.y = w.y; a.ldY = p->ldY; a.L = w.wideL; a.ldL = p->ldL;
+  a.cells = w.cells; a.n_cols = p->model.n_cols;
+  return a;
+}
+
+WideGemmArgs wide_gemm_args(const suave_plan* p, const float* params, const Workspace& w, int rows, int mode) {
+  WideGemmArgs g{};
+  g.cols = p->wide_dev; g.cum = p->wide_cum_dev[mode]; g.n_wide = (int)p->wide_host.size();
+  g.cum_total = p->wide_cum_total[mode]; g.params = params; g.y = w.y; g.ldY = p->ldY; g.L = w.wideL; g.ldL = p->ldL;
+  g.rows = rows; g.K = p->model.n_components; g.splits = 1; g.slab_stride = p->wide_len; g.wide_w0 = p->wide_w0;
+  return g;
+}
+
+// Forward part of the wide categorical columns: assignment slots, logits GEMM, log-softmax (+ d logits).
+int wide_forward(const suave_plan* p, const float* params, const Workspace& w, int rows, int vdiv, const int32_t* kidx,
+                 const float* s_dense, const float* row_weight, float c_up, bool grad, float* recon_out,
+                 double* sums_slab, hipStream_t s) {
+  WideRowArgs a = wide_row_args(p, w, rows);
+  a.vdiv = vdiv; a.kidx = kidx; a.s_dense = s_dense; a.row_weight = row_weight; a.c_up = c_up;
+  a.recon_out = recon_out; a.sums_slab = sums_slab;
+  if (int rc = launch_wide_fill(a, s)) return rc;
+  if (int rc = launch_gemm_wide(wide_gemm_args(p, params, w, rows, 0), 0, s)) return rc;
+  if (recon_out == nullptr) return 0;
+  return launch_wide_softmax(a, grad, s);
+}
+
+// Backward part: weight-gradient slabs (one reduction segment mirroring the weight region), data gradient into
+// the y slots, assignment gradient out of the slots.
+int wide_backward(const suave_plan* p, const float* params, const Workspace& w, int rows, float* ds_out, size_t* slab_off,
+                  ReduceArgs* red, int* max_elems, hipStream_t s) {
+  *slab_off = (*slab_off + 3) & ~size_t(3);
+  WideGemmArgs g = wide_gemm_args(p, params, w, rows, 2);
+  g.splits = wide_splits(p, rows);
+  g.slab = w.slab + *slab_off;
+  if (int rc = launch_gemm_wide(g, 2, s)) return rc;
+  SUAVE_REQUIRE(red->n_segs + 1 <= kMaxReduceSegs, "too many reduction segments");
+  ReduceSeg sg{};
+  sg.src_off = (int64_t)*slab_off; sg.slab_stride = p->wide_len; sg.n_slabs = g.splits; sg.rows = 1; sg.cols = p->wide_len;
+  sg.src_ld = p->wide_len; sg.dst_off = p->wide_w0; sg.dst_si = 0; sg.dst_sj = 1;
+  red->segs[red->n_segs++] = sg;
+  *max_elems = std::max(*max_elems, p->wide_len);
+  *slab_off += (size_t)g.splits * p->wide_len;
+  if (int rc = launch_gemm_wide(wide_gemm_args(p, params, w, rows, 1), 1, s)) return rc;
+  WideRowArgs a = wide_row_args(p, w, rows);
+  a.ds_out = ds_out;
+  return launch_wide_ds(a, s);
+}
+
 __global__ void k_sum_chunks(const float* part, int n_chunks, int n_rows, float* out) {
   for (int r = blockIdx.x * 256 + threadIdx.x; r < n_rows; r += gridDim.x * 256) {
     float t = 0.f;
@@ -384,12 +447,21 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     a.head_slab = grad ? head_slab : nullptr; a.sums_slab = nullptr;
     a.head_off = m.head_off; a.head_len = m.head_len; a.hw_max = p->hw_max;
     a.xsrc = p->xsrc_dev; a.ldx = p->loss_ldx; a.ldm = p->loss_ldm; a.cells = w.cells; a.n_cols = m.n_cols;
-    if (int rc = launch_loss(a, grad, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
+    if (n_chunks > 0)
+      if (int rc = launch_loss(a, grad, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
   }
+  const int n_wide = (int)p->wide_host.size();
+  const int n_parts = n_chunks + (n_wide ? 1 : 0);
+  if (n_wide)
+    if (int rc = wide_forward(p, params, w, V, K, nullptr, nullptr, wflat, -1.0f / (float)global_rows, grad,
+                              w.recon_part + (size_t)n_chunks * V, nullptr, s))
+      return rc;
   ReduceArgs red{};
   red.n_segs = 0; red.slab = w.slab; red.dst = grads;
   int max_elems = 256;
   if (grad) {
+    if (n_wide)
+      if (int rc = wide_backward(p, params, w, V, nullptr, &slab_off, &red, &max_elems, s)) return rc;
     const float* hlast = nh ? w.hd[nh - 1] : w.z;
     const int ldh = nh ? p->ldH[nh - 1] : p->ldD;
     if (int rc = bwd_weight(p, m.y_proj, w.y, p->ldY, hlast, ldh, V, w.slab, &slab_off, &red, &max_elems, s)) return rc;
@@ -412,7 +484,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
   {
     MixFinArgs a{};
     a.encout = w.encout; a.ldE = p->ldE; a.K = K; a.D = D; a.ldK = p->ldK; a.ldD = p->ldD; a.n_rows = B;
-    a.n_chunks = n_chunks; a.ldT = ldT; a.params = params; a.pm_w_off = m.pm_w_off; a.pm_b_off = m.pm_b_off;
+    a.n_chunks = n_parts; a.ldT = ldT; a.params = params; a.pm_w_off = m.pm_w_off; a.pm_b_off = m.pm_b_off;
     a.w = w.ysoft; a.eps_buf = w.eps; a.recon_part = w.recon_part; a.dz_all = w.dz; a.tau = tau_c;
     a.c_up = -1.0f / (float)global_rows; a.bk = beta_scale / (float)global_rows;
     a.recon = w.recon; a.catkl = w.catkl; a.gausskl = w.gausskl; a.dencout = w.dencout; a.prior_terms = w.prior_terms;
@@ -596,11 +668,19 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     a.prior_terms = w.prior_terms; a.head_slab = grad ? head_slab : nullptr; a.sums_slab = w.sums_slab;
     a.head_off = m.head_off; a.head_len = m.head_len; a.hw_max = p->hw_max;
     a.xsrc = p->xsrc_dev; a.ldx = p->loss_ldx; a.ldm = p->loss_ldm; a.cells = w.cells; a.n_cols = m.n_cols;
-    if (int rc = launch_loss(a, grad, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
+    if (n_chunks > 0)
+      if (int rc = launch_loss(a, grad, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
   }
+  const int n_wide = (int)p->wide_host.size();
+  const int n_parts = n_chunks + (n_wide ? 1 : 0);
+  if (n_wide)
+    if (int rc = wide_forward(p, params, w, B, 1, w.kidx, nullptr, nullptr, -1.0f / (float)global_rows, grad,
+                              w.recon_part + (size_t)n_chunks * B,
+                              w.sums_slab + ((size_t)lworkers * n_chunks + reparam_grid(B)) * 4, s))
+      return rc;
   const float* recon_final = w.recon_part;
-  if (n_chunks > 1) {
-    hipLaunchKernelGGL(k_sum_chunks, dim3(std::min((B + 255) / 256, 1024)), dim3(256), 0, s, w.recon_part, n_chunks, B,
+  if (n_parts > 1) {
+    hipLaunchKernelGGL(k_sum_chunks, dim3(std::min((B + 255) / 256, 1024)), dim3(256), 0, s, w.recon_part, n_parts, B,
                        w.recon);
     recon_final = w.recon;
   }
@@ -610,12 +690,15 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   red.slab = w.slab;
   red.dst = grads;
   red.sums_slab = w.sums_slab;
-  red.n_sum_slabs = lworkers * n_chunks + reparam_grid(B);
+  red.n_sum_slabs = lworkers * n_chunks + reparam_grid(B) + (n_wide ? wide_softmax_grid(B) : 0);
   red.sums_out = out ? out->sums : nullptr;
   red.n_rows = (double)B;
   int max_elems = 256;
 
   if (grad) {
+    if (n_wide)
+      if (int rc = wide_backward(p, params, w, B, w.ds_part + (size_t)n_chunks * B * p->ldK, &slab_off, &red, &max_elems, s))
+        return rc;
     // ---- decoder backward: per layer, dW and d(input) in one launch ----
     {
       const float* dcur = w.y;
@@ -637,7 +720,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     {
       LatentBwdArgs a{};
       a.sel = w.sel; a.ldS = ldS; a.K = K; a.D = D; a.ldK = p->ldK; a.ldD = p->ldD;
-      a.n_rows = B; a.n_chunks = n_chunks; a.ysoft = w.ysoft; a.kidx = w.kidx; a.eps_buf = w.eps; a.dz = w.dz;
+      a.n_rows = B; a.n_chunks = n_parts; a.ysoft = w.ysoft; a.kidx = w.kidx; a.eps_buf = w.eps; a.dz = w.dz;
       a.ds_part = w.ds_part; a.gkl_logit = w.gkl_logit; a.gkl_mu = w.gkl_mu; a.gkl_lv = w.gkl_lv; a.tau = tau_c;
       a.dsel = w.dsel;
       if (int rc = launch_latent_bwd(a, s)) return rc;
@@ -766,12 +849,12 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
   p->ldE = round_up(p->enc_out_width, 4);
   p->ldK = round_up(K, 4);
   p->ldD = round_up(D, 4);
-  p->ldY = round_up(m.total_y, 4);
+  p->ldY = round_up(m.y_rows, 4);
   for (int i = 0; i < m.n_hidden; ++i) p->ldH[i] = round_up(m.enc[i].n_out, 4);
   p->kmax = K <= 8 ? 8 : (K <= 16 ? 16 : 32);
   auto fail = [&](const char* msg) {
     set_error(msg);
-    delete p;
+    suave_plan_destroy(p);
     return 1;
   };
   // layer table consistency: every ld is the padded input width, offsets 16-byte aligned
@@ -792,20 +875,25 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
       prev = p->ldH[i];
       prev_n = m.dec[i].n_out;
     }
-    if (m.y_proj.ld != prev || m.y_proj.n_in != prev_n || m.y_proj.n_out != m.total_y || m.y_proj.w_off % 4)
+    if (m.y_proj.ld != prev || m.y_proj.n_in != prev_n || m.y_proj.n_out != m.y_rows || m.y_proj.w_off % 4)
       return fail("plan_create: y_projection table inconsistent");
   }
-  // column table: y slices contiguous in schema order, head weights contiguous in schema order
-  int y = 0, hw = m.head_off, total_classes = 0, max_classes = 1;
+  // column table: narrow columns have contiguous y slices and head weights in schema order; the wide categorical
+  // columns follow behind them with 16-byte aligned y slots and weight matrices (include/suave_hip.h)
+  int y = 0, hw = m.head_off, total_classes = 0, max_classes = 1, sum_y = 0;
   for (int c = 0; c < m.n_cols; ++c) {
     const suave_col_t& col = cols[c];
     if (col.type < 0 || col.type > SUAVE_TYPE_ORDINAL) return fail("plan_create: bad column type");
-    if (col.y_off != y || col.y_dim < 1) return fail("plan_create: y slices must be contiguous in schema order");
-    y += col.y_dim;
-    if (col.w_off != hw) return fail("plan_create: head weights must be contiguous in schema order");
+    if (col.y_dim < 1) return fail("plan_create: y_dim must be positive");
     const bool disc = col.type >= SUAVE_TYPE_CAT;
     if (disc && (col.n_classes < 2 || col.n_classes > 32767)) return fail("plan_create: cat/ordinal need 2..32767 classes");
     if (col.x_index < 0 || col.x_index >= (disc ? m.n_disc : m.n_num)) return fail("plan_create: x_index out of range");
+    sum_y += col.y_dim;
+    if (disc) total_classes += col.n_classes;
+    if (col_is_wide(col)) continue;
+    if (col.y_off != y) return fail("plan_create: y slices of the narrow columns must be contiguous in schema order");
+    y += col.y_dim;
+    if (col.w_off != hw) return fail("plan_create: head weights of the narrow columns must be contiguous in schema order");
     int len1 = 0, len2 = 0;
     switch (col.type) {
       case SUAVE_TYPE_REAL: case SUAVE_TYPE_POS: len1 = col.y_dim + K; len2 = K; break;
@@ -815,46 +903,107 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
     }
     if (len2 ? col.w2_off != hw + len1 : col.w2_off != -1) return fail("plan_create: second head tensor misplaced");
     hw += len1 + len2;
-    if (disc) { total_classes += col.n_classes; if (col.type == SUAVE_TYPE_CAT) max_classes = std::max(max_classes, col.n_classes); }
+    if (col.type == SUAVE_TYPE_CAT) max_classes = std::max(max_classes, col.n_classes);
+    ++p->n_narrow;
   }
-  if (y != m.total_y) return fail("plan_create: total_y mismatch");
+  if (sum_y != m.total_y) return fail("plan_create: total_y mismatch");
   if (hw != m.head_off + m.head_len) return fail("plan_create: head_len mismatch");
+  {
+    int yw = round_up(y, 4), ww = round_up(hw, 4), l_off = 0;
+    int cum[3] = {0, 0, 0};
+    std::vector<int32_t> cum_host[3];
+    p->wide_w0 = ww;
+    for (int c = 0; c < m.n_cols; ++c) {
+      const suave_col_t& col = cols[c];
+      if (!col_is_wide(col)) continue;
+      const int ldw = cat_ldw(col, K);
+      if (col.y_off != yw) return fail("plan_create: wide categorical y slots must follow the narrow slices, 16-byte aligned");
+      if (col.w_off != ww || col.w2_off != -1) return fail("plan_create: wide categorical weights must follow the narrow heads, 16-byte aligned");
+      suave::WideCol wc{};
+      wc.col = c; wc.C = col.n_classes; wc.yd = col.y_dim; wc.y_off = yw; wc.l_off = l_off; wc.w_off = ww; wc.ldw = ldw;
+      p->wide_host.push_back(wc);
+      for (int q = 0; q < 3; ++q) cum_host[q].push_back(cum[q]);
+      cum[0] += (col.n_classes - 1 + 127) / 128;
+      cum[1] += (ldw + 127) / 128;
+      cum[2] += ((col.n_classes - 1 + 127) / 128) * ((ldw + 127) / 128);
+      yw += ldw;
+      ww += (col.n_classes - 1) * ldw;
+      l_off += round_up(col.n_classes - 1, 4);
+    }
+    const bool any_wide = !p->wide_host.empty();
+    if (m.y_rows != (any_wide ? yw : m.total_y)) return fail("plan_create: y_rows mismatch");
+    if (m.y_proj.n_out != m.y_rows) return fail("plan_create: y_projection must have y_rows rows");
+    p->ldL = std::max(l_off, 4);
+    p->wide_len = ww - p->wide_w0;
+    if (ww > m.n_params) return fail("plan_create: wide categorical weights exceed the parameter buffer");
+    for (int q = 0; q < 3; ++q) {
+      cum_host[q].push_back(cum[q]);
+      p->wide_cum_total[q] = cum[q];
+    }
+    if (any_wide) {
+      const size_t nw = p->wide_host.size();
+      if (hipMalloc(&p->wide_dev, sizeof(suave::WideCol) * nw) != hipSuccess ||
+          hipMemcpy(p->wide_dev, p->wide_host.data(), sizeof(suave::WideCol) * nw, hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("plan_create: hipMalloc/hipMemcpy of the wide column table failed");
+        suave_plan_destroy(p);
+        return 2;
+      }
+      for (int q = 0; q < 3; ++q) {
+        if (hipMalloc(&p->wide_cum_dev[q], sizeof(int32_t) * (nw + 1)) != hipSuccess ||
+            hipMemcpy(p->wide_cum_dev[q], cum_host[q].data(), sizeof(int32_t) * (nw + 1), hipMemcpyHostToDevice) != hipSuccess) {
+          set_error("plan_create: hipMalloc/hipMemcpy of the wide tile table failed");
+          suave_plan_destroy(p);
+          return 2;
+        }
+      }
+    }
+  }
   p->total_classes = total_classes;
   p->max_classes = max_classes;
-  // chunking of the schema for the loss kernel (LDS budget)
+  // chunking of the narrow columns for the likelihood kernel (LDS budget); a chunk never spans a wide column
   {
     // chunks of about equal y width, ~20 floats of y per tile row: a wave worker's private LDS slice stays near
     // 10 KB (16 workers per CU) and its y tile fits the 8 float4 per lane of the register prefetch
     const int kChunkY = 20;
-    const int n_target = std::max(1, (m.total_y + kChunkY - 1) / kChunkY);
-    const int y_target = (m.total_y + n_target - 1) / n_target;
+    const int n_target = std::max(1, (y + kChunkY - 1) / kChunkY);
+    const int y_target = (y + n_target - 1) / n_target;
     ColChunk cur{0, 0, 0, 0};
-    int hw_max = 0, hw_start = m.head_off, max_y = 0;
+    int hw_max = 0, max_y = 0, max_cc = 1;
+    auto w_end = [&](int c) {
+      for (int n = c + 1; n < m.n_cols; ++n)
+        if (!col_is_wide(cols[n])) return cols[n].w_off;
+      return m.head_off + m.head_len;
+    };
+    auto close = [&]() {
+      if (cur.col_end <= cur.col_begin) return;
+      p->chunks_host.push_back(cur);
+      hw_max = std::max(hw_max, w_end(cur.col_end - 1) - cols[cur.col_begin].w_off);
+      max_y = std::max(max_y, cur.y_len);
+      max_cc = std::max(max_cc, cur.col_end - cur.col_begin);
+    };
     for (int c = 0; c < m.n_cols; ++c) {
+      if (col_is_wide(cols[c])) {
+        close();
+        cur = ColChunk{c + 1, c + 1, 0, 0};
+        continue;
+      }
       if (cur.col_end > cur.col_begin && cur.y_len + cols[c].y_dim > y_target) {
-        p->chunks_host.push_back(cur);
-        hw_max = std::max(hw_max, cols[c].w_off - hw_start);
-        hw_start = cols[c].w_off;
-        max_y = std::max(max_y, cur.y_len);
+        close();
         cur = ColChunk{c, c, cols[c].y_off, 0};
       }
+      if (cur.col_end == cur.col_begin) { cur.col_begin = c; cur.y_begin = cols[c].y_off; }
       cur.col_end = c + 1;
       cur.y_len += cols[c].y_dim;
     }
-    p->chunks_host.push_back(cur);
-    hw_max = std::max(hw_max, m.head_off + m.head_len - hw_start);
-    max_y = std::max(max_y, cur.y_len);
-    p->max_chunk_y = max_y;
-    hw_max = round_up(hw_max, 4);
+    close();
+    p->max_chunk_y = std::max(max_y, 1);
+    hw_max = round_up(std::max(hw_max, 4), 4);
     p->hw_max = hw_max;
-    int max_cc = 1;
-    for (const ColChunk& cc : p->chunks_host) max_cc = std::max(max_cc, cc.col_end - cc.col_begin);
     p->loss_ldx = max_cc | 1;
     p->loss_ldm = (round_up(max_cc, 4) / 4 | 1) * 4;
-    p->loss_lds_bytes = loss_lds_bytes(max_y | 1, K, hw_max, max_classes, p->loss_ldx, p->loss_ldm);
+    p->loss_lds_bytes = loss_lds_bytes(p->max_chunk_y | 1, K, hw_max, max_classes, p->loss_ldx, p->loss_ldm);
     if (p->loss_lds_bytes > 150 * 1024)
-      return fail("plan_create: schema needs more than 150 KB of LDS in the likelihood kernel (very wide categorical "
-                  "columns need the GEMM head path, which this build does not have yet)");
+      return fail("plan_create: a narrow column needs more than 150 KB of LDS in the likelihood kernel");
   }
   // device tables
   hipDeviceProp_t prop;
@@ -879,7 +1028,7 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
     return 2;
   };
   if (hipMalloc(&p->cols_dev, sizeof(suave_col_t) * m.n_cols) != hipSuccess) return dfail("plan_create: hipMalloc failed");
-  if (hipMalloc(&p->chunks_dev, sizeof(ColChunk) * p->chunks_host.size()) != hipSuccess) return dfail("plan_create: hipMalloc failed");
+  if (hipMalloc(&p->chunks_dev, sizeof(ColChunk) * std::max<size_t>(p->chunks_host.size(), 1)) != hipSuccess) return dfail("plan_create: hipMalloc failed");
   if (hipMalloc(&p->enc_map_dev, sizeof(int32_t) * p->ldI) != hipSuccess) return dfail("plan_create: hipMalloc failed");
   if (hipMalloc(&p->cls_off_dev, sizeof(int32_t) * m.n_cols) != hipSuccess) return dfail("plan_create: hipMalloc failed");
   if (hipMalloc(&p->xsrc_dev, sizeof(int32_t) * m.n_cols) != hipSuccess) return dfail("plan_create: hipMalloc failed");
@@ -916,6 +1065,9 @@ extern "C" int suave_plan_destroy(suave_plan* p) {
   if (p->enc_map_dev) (void)hipFree(p->enc_map_dev);
   if (p->cls_off_dev) (void)hipFree(p->cls_off_dev);
   if (p->xsrc_dev) (void)hipFree(p->xsrc_dev);
+  if (p->wide_dev) (void)hipFree(p->wide_dev);
+  for (int q = 0; q < 3; ++q)
+    if (p->wide_cum_dev[q]) (void)hipFree(p->wide_cum_dev[q]);
   delete p;
   return 0;
 }
@@ -1006,8 +1158,8 @@ extern "C" int suave_decode_sample(const suave_plan* p, const float* params, con
   if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, &dummy, nullptr, 0, 1, st))
     return rc;
   if (y_full_out)
-    SUAVE_CHECK_HIP(hipMemcpy2DAsync(y_full_out, sizeof(float) * m.total_y, w.y, sizeof(float) * p->ldY,
-                                     sizeof(float) * m.total_y, B, hipMemcpyDeviceToDevice, st));
+    SUAVE_CHECK_HIP(hipMemcpy2DAsync(y_full_out, sizeof(float) * m.y_rows, w.y, sizeof(float) * p->ldY,
+                                     sizeof(float) * m.y_rows, B, hipMemcpyDeviceToDevice, st));
   return launch_sample_heads(p, p->cls_off_dev, params, w.y, s_dense, component, n, noise_normal, noise_uniform,
                              noise_exp, seed, row_offset, out_num, ld_num, out_codes, ld_disc, st);
 }

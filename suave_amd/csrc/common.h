@@ -36,6 +36,27 @@ constexpr float kLogvarMax = 15.0f;
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// Wide categorical columns (SUAVE_WIDE_CAT_MIN_CLASSES, include/suave_hip.h) run their logits_layer as GEMMs.
+__host__ __device__ inline bool col_is_wide(const suave_col_t& c) {
+  return c.type == SUAVE_TYPE_CAT && c.n_classes >= SUAVE_WIDE_CAT_MIN_CLASSES;
+}
+// row stride of a categorical column's logits_layer weight [C-1, y_dim + K]
+__host__ __device__ inline int cat_ldw(const suave_col_t& c, int K) {
+  return col_is_wide(c) ? (c.y_dim + K + 3) / 4 * 4 : c.y_dim + K;
+}
+
+// One wide categorical column (device table of the plan).
+struct WideCol {
+  int32_t col;     // schema column
+  int32_t C;       // classes
+  int32_t yd;      // y_dim
+  int32_t y_off;   // slot [y (yd) | s (K) | pad] in the internal y buffer, multiple of 4
+  int32_t l_off;   // logits of classes 1..C-1 at columns l_off .. l_off + C - 2 of the wide logits buffer (multiple of 4)
+  int32_t w_off;   // logits_layer weight [C-1, ldw]
+  int32_t ldw;     // round_up(yd + K, 4)
+  int32_t pad;
+};
+
 // A chunk of consecutive schema columns handled by one loss-kernel block column.
 struct ColChunk {
   int32_t col_begin, col_end;
@@ -68,6 +89,15 @@ struct suave_plan {
   int hw_max;         // widest per-chunk range of likelihood-head weights
   int loss_blocks;    // grid.x of the loss kernel
   size_t loss_lds_bytes;
+  // wide categorical columns
+  std::vector<suave::WideCol> wide_host;
+  suave::WideCol* wide_dev = nullptr;
+  int32_t* wide_cum_dev[3] = {nullptr, nullptr, nullptr};  // tile prefixes: forward N tiles, data-grad N tiles, weight-grad tiles
+  int wide_cum_total[3] = {0, 0, 0};
+  int ldL = 0;        // columns of the wide logits buffer
+  int wide_w0 = 0;    // first float of the wide weight region
+  int wide_len = 0;   // floats of the wide weight region
+  int n_narrow = 0;   // columns handled by the fused likelihood kernel
 };
 
 namespace suave {
@@ -186,6 +216,27 @@ __host__ __device__ __forceinline__ int head_row(int q, int c, int K, int D, int
 }
 
 int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream);
+
+// Grouped GEMMs of all wide categorical columns in one launch (gemm.hip).
+//   mode 0: logits  L_j[rows, C-1]   = slot_j[rows, yd+K] * W_j^T                  (decoder.py:201-206)
+//   mode 1: d slot_j[rows, ldw]      = g_j[rows, C-1] * W_j          (g overwrote L in place)
+//   mode 2: d W_j[C-1, ldw] slabs    = g_j^T * slot_j, split over the rows
+struct WideGemmArgs {
+  const WideCol* cols;
+  const int32_t* cum;  // [n_wide + 1] tile prefix of this mode
+  int n_wide, cum_total;
+  const float* params;
+  float* y;
+  int ldY;
+  float* L;
+  int ldL;
+  int rows, K;
+  float* slab;          // mode 2: [splits][wide_len], mirrors the wide weight region
+  int64_t slab_stride;  // wide_len
+  int splits;
+  int wide_w0;
+};
+int launch_gemm_wide(const WideGemmArgs& a, int mode, hipStream_t stream);
 int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t stream);
 
 // ----- optional per-kernel-class timing with HIP events (suave_profile_*) -----

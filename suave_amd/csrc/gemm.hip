@@ -396,7 +396,65 @@ __global__ __launch_bounds__(256) void gemm_pair_kernel(GemmArgs d, GemmArgs w, 
   else gemm_body<DM, DN, false, true, D_GRP, D_EPI>(d, b - w_blocks, 0, smem, perm_s);
 }
 
+// All wide categorical columns in one launch: a block looks up its column in the tile prefix table and runs
+// the ordinary tile body on that column's operands.
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_wide_kernel(WideGemmArgs w) {
+  __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<2, 2>()];
+  __shared__ int perm_s[1];
+  const int tiles_m = MODE == 2 ? 1 : (w.rows + 127) / 128;
+  const int q = blockIdx.x / tiles_m;
+  // binary search: cum[c] <= q < cum[c + 1]   (uniform across the block)
+  int lo = 0, hi = w.n_wide;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (w.cum[mid] <= q) lo = mid; else hi = mid;
+  }
+  const WideCol wc = w.cols[lo];
+  const int local = blockIdx.x - w.cum[lo] * tiles_m;
+  GemmArgs g;
+  g.bias = nullptr; g.H = nullptr; g.keep = nullptr; g.row_ids = nullptr; g.row_begin = 0;
+  g.splits = 1; g.slab_stride = 0; g.ones_col = -1; g.drop_p = 0.f; g.seed = 0; g.step = 0; g.stream_id = 0;
+  g.grouped = 0; g.perm = nullptr; g.chunk_comp = nullptr; g.hK = g.hD = g.hldK = g.hldD = g.q0 = 0;
+  float* slot = w.y + wc.y_off;
+  float* logit = w.L + wc.l_off;
+  const float* wt = w.params + wc.w_off;
+  if (MODE == 0) {
+    g.A = slot; g.B = wt; g.C = logit; g.M = w.rows; g.N = wc.C - 1; g.K = wc.yd + w.K;
+    g.lda = w.ldY; g.ldb = wc.ldw; g.ldc = w.ldL; g.a_kmajor = 0; g.b_kmajor = 0; g.epi = kEpiBias;
+    gemm_body<2, 2, false, false, 0, kEpiBias>(g, local, 0, smem, perm_s);
+  } else if (MODE == 1) {
+    g.A = logit; g.B = wt; g.C = slot; g.M = w.rows; g.N = wc.ldw; g.K = wc.C - 1;
+    g.lda = w.ldL; g.ldb = wc.ldw; g.ldc = w.ldY; g.a_kmajor = 0; g.b_kmajor = 1; g.epi = kEpiBias;
+    gemm_body<2, 2, false, true, 0, kEpiBias>(g, local, 0, smem, perm_s);
+  } else {
+    g.A = logit; g.B = slot; g.C = w.slab + (wc.w_off - w.wide_w0); g.M = wc.C - 1; g.N = wc.ldw; g.K = w.rows;
+    g.lda = w.ldL; g.ldb = w.ldY; g.ldc = wc.ldw; g.a_kmajor = 1; g.b_kmajor = 1; g.epi = kEpiSlab;
+    g.splits = w.splits; g.slab_stride = w.slab_stride;
+    gemm_body<2, 2, true, true, 0, kEpiSlab>(g, local, blockIdx.z, smem, perm_s);
+  }
+}
+
 }  // namespace
+
+int launch_gemm_wide(const WideGemmArgs& a, int mode, hipStream_t stream) {
+  if (a.n_wide <= 0 || a.rows <= 0) return 0;
+  SUAVE_REQUIRE(a.ldY % 4 == 0 && a.ldL % 4 == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.L) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.params) & 15) == 0,
+                "wide gemm: operands must be 16-byte aligned");
+  SUAVE_REQUIRE(mode != 2 || (a.slab != nullptr && a.splits >= 1 && a.slab_stride % 4 == 0 &&
+                              (reinterpret_cast<uintptr_t>(a.slab) & 15) == 0), "wide gemm: bad slab");
+  ProfScope prof_scope(kProfGemm, stream);
+  const int tiles_m = mode == 2 ? 1 : (a.rows + 127) / 128;
+  const int64_t blocks = (int64_t)a.cum_total * tiles_m;
+  SUAVE_REQUIRE(blocks > 0 && blocks < (int64_t(1) << 31), "wide gemm: grid out of range");
+  const dim3 grid((unsigned)blocks, 1, mode == 2 ? a.splits : 1), block(256);
+  if (mode == 0) hipLaunchKernelGGL(gemm_wide_kernel<0>, grid, block, 0, stream, a);
+  else if (mode == 1) hipLaunchKernelGGL(gemm_wide_kernel<1>, grid, block, 0, stream, a);
+  else hipLaunchKernelGGL(gemm_wide_kernel<2>, grid, block, 0, stream, a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 namespace {
 int check_gemm(const GemmArgs& a) {

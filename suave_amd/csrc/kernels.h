@@ -167,6 +167,29 @@ struct MixFinArgs {
   double* sums_slab;       // [gridDim.x, 4]
 };
 
+// Row-wise kernels of the wide categorical columns (wide.hip).
+struct WideRowArgs {
+  const WideCol* wide;
+  int n_wide, n_rows, vdiv, K, ldK;
+  float* y;             // [n_rows, ldY] internal y buffer
+  int ldY;
+  float* L;             // [n_rows, ldL] logits, overwritten with d loss / d logits when GRAD
+  int ldL;
+  const int32_t* kidx;  // [n_rows] component or null -> row % vdiv
+  const float* s_dense; // [n_rows, K] dense assignments (decode) or null
+  const float* row_weight;
+  float c_up;
+  const int32_t* cells; // tile-transposed packed cells (k_expand)
+  int n_cols;
+  float* recon_out;     // [n_rows]
+  float* ds_out;        // [n_rows, ldK] or null
+  double* sums_slab;    // [grid, 4] or null
+};
+int launch_wide_fill(const WideRowArgs& a, hipStream_t s);
+int wide_softmax_grid(int n_rows);
+int launch_wide_softmax(const WideRowArgs& a, bool grad, hipStream_t s);
+int launch_wide_ds(const WideRowArgs& a, hipStream_t s);
+
 int launch_mix_fwd(const MixFwdArgs& a, hipStream_t s);
 int launch_mix_finalize(const MixFinArgs& a, bool grad, int grid, hipStream_t s);
 int launch_colsum(const float* src, int ld, int n_rows, int n_cols, float* slab, int n_blocks, hipStream_t s);

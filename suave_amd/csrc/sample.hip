@@ -66,6 +66,9 @@ struct SampleArgs {
   int ldy, ldon, ldoc;  // LDS row strides
 };
 
+// STAGED: the 64-row y tile and the outputs go through LDS (coalesced global accesses).  Schemas whose y row
+// does not fit (wide categoricals, BASELINE config #4) run unstaged: lane = row reads y from global memory.
+template <bool STAGED>
 __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ytile = lds;                                      // [64][ldy]
@@ -80,26 +83,28 @@ __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t r0 = tile * 64;
     const int nrows = (int)min((int64_t)64, a.n - r0);
-    __syncthreads();
-    const int nq = a.ldY / 4;
-    for (int idx = tid; idx < nrows * nq; idx += 256) {
-      const int lr = idx / nq, q = idx % nq;
-      const float4 v = *reinterpret_cast<const float4*>(a.y + (size_t)(r0 + lr) * a.ldY + q * 4);
-      float* dst = ytile + lr * a.ldy + q * 4;
-      if (q * 4 + 0 < a.Y) dst[0] = v.x;
-      if (q * 4 + 1 < a.Y) dst[1] = v.y;
-      if (q * 4 + 2 < a.Y) dst[2] = v.z;
-      if (q * 4 + 3 < a.Y) dst[3] = v.w;
+    if (STAGED) {
+      __syncthreads();
+      const int nq = a.ldY / 4;
+      for (int idx = tid; idx < nrows * nq; idx += 256) {
+        const int lr = idx / nq, q = idx % nq;
+        const float4 v = *reinterpret_cast<const float4*>(a.y + (size_t)(r0 + lr) * a.ldY + q * 4);
+        float* dst = ytile + lr * a.ldy + q * 4;
+        if (q * 4 + 0 < a.Y) dst[0] = v.x;
+        if (q * 4 + 1 < a.Y) dst[1] = v.y;
+        if (q * 4 + 2 < a.Y) dst[2] = v.z;
+        if (q * 4 + 3 < a.Y) dst[3] = v.w;
+      }
+      if (a.s)
+        for (int idx = tid; idx < nrows * K; idx += 256) s_s[idx] = a.s[(size_t)r0 * K + idx];
+      __syncthreads();
     }
-    if (a.s)
-      for (int idx = tid; idx < nrows * K; idx += 256) s_s[idx] = a.s[(size_t)r0 * K + idx];
-    __syncthreads();
     const bool valid = lane < nrows;
     const int64_t r = r0 + (valid ? lane : 0);
     const uint32_t rid = (uint32_t)(a.row_offset + r), rid_hi = (uint32_t)((uint64_t)(a.row_offset + r) >> 32);
     const int kc = a.s ? 0 : a.comp[r];
-    const float* yrow = ytile + lane * a.ldy;
-    const float* srow = s_s + lane * K;
+    const float* yrow = STAGED ? ytile + lane * a.ldy : a.y + (size_t)r * a.ldY;
+    const float* srow = STAGED ? s_s + lane * K : (a.s ? a.s + (size_t)r * K : nullptr);
 
     // sequential, individually rounded dot of [y ; s] with [w_y ; w_s]
     auto dot = [&](const float* w, const float* yb, int yd) {
@@ -143,7 +148,8 @@ __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
             val = detm::sub(detm::exp(detm::add(mean, detm::mul(nrm, sd))), 1.0f);
           }
         }
-        onum[lane * a.ldon + col.x_index] = val;
+        if (STAGED) onum[lane * a.ldon + col.x_index] = val;
+        else if (valid) a.out_num[(size_t)r * a.ld_num + col.x_index] = val;
       } else {
         const int C = col.n_classes;
         const int coff = a.cls_off[c];
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
         };
         int best_i = 0;
         if (col.type == SUAVE_TYPE_CAT) {  // Gumbel-max == exponential race on softmax(logits)
-          const int ldw = yd + K;
+          const int ldw = cat_ldw(col, K);
           float best = detm::sub(0.f, detm::log(draw_e(0)));
           for (int cl = 1; cl < C; ++cl) {
             const float L = dot(w + (cl - 1) * ldw, yb, yd);
@@ -180,17 +186,20 @@ __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
             if (sc > best) { best = sc; best_i = cl; }
           }
         }
-        ocode[lane * a.ldoc + col.x_index] = best_i;
+        if (STAGED) ocode[lane * a.ldoc + col.x_index] = best_i;
+        else if (valid) a.out_codes[(size_t)r * a.ld_disc + col.x_index] = (int16_t)best_i;
       }
     }
-    __syncthreads();
-    for (int idx = tid; idx < nrows * a.n_num; idx += 256) {
-      const int lr = idx / a.n_num, j = idx % a.n_num;
-      a.out_num[(size_t)(r0 + lr) * a.ld_num + j] = onum[lr * a.ldon + j];
-    }
-    for (int idx = tid; idx < nrows * a.n_disc; idx += 256) {
-      const int lr = idx / a.n_disc, j = idx % a.n_disc;
-      a.out_codes[(size_t)(r0 + lr) * a.ld_disc + j] = (int16_t)ocode[lr * a.ldoc + j];
+    if (STAGED) {
+      __syncthreads();
+      for (int idx = tid; idx < nrows * a.n_num; idx += 256) {
+        const int lr = idx / a.n_num, j = idx % a.n_num;
+        a.out_num[(size_t)(r0 + lr) * a.ld_num + j] = onum[lr * a.ldon + j];
+      }
+      for (int idx = tid; idx < nrows * a.n_disc; idx += 256) {
+        const int lr = idx / a.n_disc, j = idx % a.n_disc;
+        a.out_codes[(size_t)(r0 + lr) * a.ld_disc + j] = (int16_t)ocode[lr * a.ldoc + j];
+      }
     }
   }
 }
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(256) void k_head_params(HeadParamArgs a) {
     } else if (col.type == SUAVE_TYPE_COUNT) {
       o[0] = softplus_f(dot(w, yd)) + kEps;
     } else if (col.type == SUAVE_TYPE_CAT) {
-      const int C = col.n_classes, ldw = yd + K;
+      const int C = col.n_classes, ldw = cat_ldw(col, K);
       float mx = 0.f;
       o[0] = 0.f;
       for (int c = 1; c < C; ++c) { o[c] = dot(w + (c - 1) * ldw, yd); mx = fmaxf(mx, o[c]); }
@@ -472,23 +481,28 @@ int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const f
   const suave_model_t& m = p->model;
   SampleArgs a{};
   a.cols = p->cols_dev; a.cls_off = cls_off_dev; a.params = params; a.y = y; a.s = s; a.comp = comp; a.n = n;
-  a.n_cols = m.n_cols; a.n_num = m.n_num; a.n_disc = m.n_disc; a.K = m.n_components; a.ldY = p->ldY; a.Y = m.total_y;
+  a.n_cols = m.n_cols; a.n_num = m.n_num; a.n_disc = m.n_disc; a.K = m.n_components; a.ldY = p->ldY; a.Y = m.y_rows;
   a.total_classes = p->total_classes;
   a.noise_normal = nn; a.noise_uniform = nu; a.noise_exp = ne; a.seed = seed; a.row_offset = row_offset;
   a.out_num = out_num; a.ld_num = ld_num; a.out_codes = out_codes; a.ld_disc = ld_disc;
   a.ldy = p->ldY | 1; a.ldon = std::max(m.n_num, 1) | 1; a.ldoc = std::max(m.n_disc, 1) | 1;
   const size_t lds = sizeof(float) * ((size_t)64 * a.ldy + 64 * a.ldon + 64 * a.ldoc + 64 * m.n_components);
-  SUAVE_REQUIRE(lds <= 150 * 1024, "decode_sample: schema too wide for the single-chunk sample kernel");
+  const bool staged = lds <= 64 * 1024;
   static thread_local size_t lds_set = 0;
-  if (lds > 48 * 1024 && lds > lds_set) {
-    SUAVE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sample_heads),
+  if (staged && lds > 48 * 1024 && lds > lds_set) {
+    SUAVE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sample_heads<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set = lds;
   }
   const int64_t tiles = (n + 63) / 64;
-  const int grid = (int)std::min<int64_t>(tiles, 2 * (int64_t)p->n_cu);
   ProfScope prof_scope(kProfSample, st);
-  hipLaunchKernelGGL(k_sample_heads, dim3(grid), dim3(256), lds, st, a);
+  if (staged) {
+    const int grid = (int)std::min<int64_t>(tiles, 2 * (int64_t)p->n_cu);
+    hipLaunchKernelGGL(k_sample_heads<true>, dim3(grid), dim3(256), lds, st, a);
+  } else {
+    const int grid = (int)std::min<int64_t>(tiles, 8 * (int64_t)p->n_cu);
+    hipLaunchKernelGGL(k_sample_heads<false>, dim3(grid), dim3(256), 0, st, a);
+  }
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,136 @@
+// Row-wise kernels of the wide categorical columns (SUAVE_WIDE_CAT_MIN_CLASSES and more classes).
+//
+// The reference's CatHead (suave/modules/decoder.py:194-222) applies one bias-free linear to the feature
+// vector [y_col ; s] and scores the one-hot target with log_softmax (distributions.py:57-64).  For a wide
+// column that linear is an MFMA GEMM (gemm.hip, gemm_wide_kernel) on the column's slot of the internal y
+// buffer; the kernels here write the assignment part of the slots, turn the logits into log-likelihoods and
+// (GRAD) into d loss / d logits in place, and collect the assignment gradient out of the slots afterwards.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace suave {
+
+// slot[r, yd .. yd+K) = s[r, :]: one-hot of the row's component (ELBO step, component-indexed decode) or the
+// dense assignment vector (soft imputation, model.py:3635-3644).
+__global__ __launch_bounds__(256) void k_wide_fill(WideRowArgs a) {
+  const int64_t total = (int64_t)a.n_rows * a.n_wide;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / a.n_wide), c = (int)(e % a.n_wide);
+    const WideCol wc = a.wide[c];
+    float* dst = a.y + (size_t)r * a.ldY + wc.y_off + wc.yd;
+    if (a.s_dense) {
+      for (int j = 0; j < a.K; ++j) dst[j] = a.s_dense[(size_t)r * a.K + j];
+    } else {
+      const int k = a.kidx ? a.kidx[r] : (r % a.vdiv);
+      for (int j = 0; j < a.K; ++j) dst[j] = j == k ? 1.f : 0.f;
+    }
+  }
+}
+
+// One wavefront per row walks the wide columns: lanes stride over the classes, two wave reductions give the
+// log-sum-exp (logit 0 is pinned to 0, decoder.py:207-210).  recon_out[r] = sum over the wide columns of
+// log_px; with GRAD the logits are overwritten by g_c = up * (onehot_c - softmax_c) (exactly 0 for masked
+// cells and all-zero one-hot rows, as `_apply_observed_linear` and the x mask give, decoder.py:41-53).
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_wide_softmax(WideRowArgs a) {
+  __shared__ double blk_sum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double wsum = 0.0;
+  for (int r = blockIdx.x * 4 + wave; r < a.n_rows; r += gridDim.x * 4) {
+    const int drow = a.vdiv == 1 ? r : r / a.vdiv;
+    const int32_t* cell_ptr = a.cells + ((size_t)(drow >> 6) * a.n_cols) * 64 + (drow & 63);
+    const float up = GRAD ? a.c_up * (a.row_weight ? a.row_weight[r] : 1.0f) : 0.f;
+    float* Lrow = a.L + (size_t)r * a.ldL;
+    float recon = 0.f;
+    for (int c = 0; c < a.n_wide; ++c) {
+      const WideCol wc = a.wide[c];
+      const int cell = cell_ptr[(size_t)wc.col * 64];
+      const bool obs = cell != kCellMissing;
+      const int code = obs ? cell : -1;
+      const bool live = code >= 0 && code < wc.C;
+      float* Lc = Lrow + wc.l_off;
+      const int n = wc.C - 1;
+      float mx = 0.f;
+      for (int i = lane; i < n; i += 64) mx = fmaxf(mx, Lc[i]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      float se = 0.f;
+      for (int i = lane; i < n; i += 64) se += __expf(Lc[i] - mx);
+      se = wave_sum(se) + __expf(-mx);
+      const float lse = mx + __logf(se);
+      if (live) recon += (code >= 1 ? Lc[code - 1] : 0.f) - lse;
+      if (GRAD) {
+        for (int i = lane; i < n; i += 64) {
+          const float p = __expf(Lc[i] - lse);
+          Lc[i] = live ? up * ((i + 1 == code ? 1.0f : 0.f) - p) : 0.f;
+        }
+      }
+    }
+    if (lane == 0) {
+      a.recon_out[r] = recon;
+      wsum += (double)recon;
+    }
+  }
+  if (a.sums_slab) {
+    if (lane == 0) blk_sum[wave] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double* s = a.sums_slab + (size_t)blockIdx.x * 4;
+      s[0] = ((blk_sum[0] + blk_sum[1]) + blk_sum[2]) + blk_sum[3];
+      s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+    }
+  }
+}
+
+// After the data-gradient GEMM the slots hold d loss / d [y_col ; s].  The assignment part is summed over
+// the wide columns into ds_out[r, 0..K) (the straight-through path needs the full K-vector, SURVEY.md
+// Appendix A) and cleared, so that the slots' pad rows of y_projection see a zero gradient.
+__global__ __launch_bounds__(256) void k_wide_ds(WideRowArgs a) {
+  const int64_t total = (int64_t)a.n_rows * a.K;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / a.K), j = (int)(e % a.K);
+    float t = 0.f;
+    for (int c = 0; c < a.n_wide; ++c) {
+      const WideCol wc = a.wide[c];
+      float* p = a.y + (size_t)r * a.ldY + wc.y_off + wc.yd + j;
+      t += *p;
+      *p = 0.f;
+    }
+    if (a.ds_out) a.ds_out[(size_t)r * a.ldK + j] = t;
+  }
+}
+
+static int wide_grid(int64_t work, int per_block, int cap) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>((work + per_block - 1) / per_block, cap));
+}
+
+int launch_wide_fill(const WideRowArgs& a, hipStream_t s) {
+  if (a.n_rows <= 0 || a.n_wide <= 0) return 0;
+  ProfScope prof_scope(kProfLoss, s);
+  hipLaunchKernelGGL(k_wide_fill, dim3(wide_grid((int64_t)a.n_rows * a.n_wide, 256, 4096)), dim3(256), 0, s, a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int wide_softmax_grid(int n_rows) { return wide_grid(n_rows, 4, 4096); }
+
+int launch_wide_softmax(const WideRowArgs& a, bool grad, hipStream_t s) {
+  if (a.n_rows <= 0 || a.n_wide <= 0) return 0;
+  ProfScope prof_scope(kProfLoss, s);
+  const dim3 grid(wide_softmax_grid(a.n_rows)), block(256);
+  if (grad) hipLaunchKernelGGL(k_wide_softmax<true>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(k_wide_softmax<false>, grid, block, 0, s, a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_wide_ds(const WideRowArgs& a, hipStream_t s) {
+  if (a.n_rows <= 0 || a.n_wide <= 0) return 0;
+  ProfScope prof_scope(kProfLoss, s);
+  hipLaunchKernelGGL(k_wide_ds, dim3(wide_grid((int64_t)a.n_rows * a.K, 256, 4096)), dim3(256), 0, s, a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace suave

@@ -236,7 +236,7 @@ class Engine:
         nbytes = ws.numel() - (base - ws.data_ptr())
         out_num = torch.empty((n, max(L.n_num, 1)), dtype=torch.float32, device=self.device)
         out_codes = torch.empty((n, max(L.n_disc, 1)), dtype=torch.int16, device=self.device)
-        y_out = torch.empty((n, L.total_y), dtype=torch.float32, device=self.device) if want_y else None
+        y_out = torch.empty((n, L.y_rows), dtype=torch.float32, device=self.device) if want_y else None
         rc = self.lib.suave_decode_sample(self._plan, self.params.data_ptr(), z.data_ptr(), _ptr(assignments),
                                           _ptr(component), n, _ptr(noise_normal), _ptr(noise_uniform),
                                           _ptr(noise_exp), int(seed), int(row_offset), base, nbytes, self._stream(),
@@ -244,6 +244,8 @@ class Engine:
                                           int(out_codes.shape[1]), _ptr(y_out))
         _lib.check(rc, "suave_decode_sample")
         if want_y:
+            if L.y_rows != L.total_y:  # internal layout (wide categorical slots) -> the reference's y_full columns
+                y_out = y_out[:, torch.as_tensor(L.y_index, device=self.device)]
             return out_num[:, : L.n_num], out_codes[:, : L.n_disc], y_out
         return out_num[:, : L.n_num], out_codes[:, : L.n_disc]
 

@@ -25,6 +25,7 @@ MAX_HIDDEN = 8
 MAX_COMPONENTS = 32
 TYPE_CODE = {"real": 0, "pos": 1, "count": 2, "cat": 3, "ordinal": 4}
 TYPE_ORDER = ("real", "pos", "count", "cat", "ordinal")  # encoder-input order, model.py:2813-2900
+WIDE_CAT_MIN_CLASSES = 17  # SUAVE_WIDE_CAT_MIN_CLASSES in include/suave_hip.h
 
 
 class ColT(C.Structure):
@@ -45,7 +46,7 @@ class ModelT(C.Structure):
                 ("enc", LayerT * MAX_HIDDEN), ("enc_head", LayerT), ("dec", LayerT * MAX_HIDDEN), ("y_proj", LayerT),
                 ("head_off", C.c_int32), ("head_len", C.c_int32), ("prior_logits_off", C.c_int32),
                 ("prior_mu_off", C.c_int32), ("prior_logvar_off", C.c_int32), ("pm_w_off", C.c_int32),
-                ("pm_b_off", C.c_int32)]
+                ("pm_b_off", C.c_int32), ("y_rows", C.c_int32)]
 
 
 class BatchT(C.Structure):
@@ -77,6 +78,7 @@ class TensorSlot:
     shape: Tuple[int, ...]
     ld: int  # row stride in the flat buffer (== shape[-1] for unpadded tensors)
     row0: int = 0  # first row inside a stacked matrix
+    row_index: Optional[np.ndarray] = None  # tensor row i lives at buffer row row_index[i] (y_projection, wide schemas)
 
 
 @dataclass
@@ -95,6 +97,8 @@ class ModelLayout:
     # derived
     enc_in: int = 0
     total_y: int = 0
+    y_rows: int = 0  # rows of the internal y buffer / y_projection matrix (== total_y without wide categoricals)
+    y_index: Optional[np.ndarray] = None  # reference y_full column -> internal y column
     n_num: int = 0
     n_disc: int = 0
     n_params: int = 0
@@ -166,19 +170,45 @@ class ModelLayout:
         for i, h in enumerate(self.hidden):
             add_layer(m.dec[i], f"decoder.backbone.{i * step}.weight", f"decoder.backbone.{i * step}.bias", h, prev)
             prev = h
-        add_layer(m.y_proj, "decoder.y_projection.weight", "decoder.y_projection.bias", self.total_y, prev)
-        # likelihood heads, contiguous, schema order (all bias-free, decoder.py:61-62,105-106,153,190-192,233-236)
+        # internal y layout: the slices of the narrow columns are contiguous in schema order (as in the reference,
+        # decoder.py:306-314); every wide categorical column (C >= WIDE_CAT_MIN_CLASSES) then gets a 16-byte aligned
+        # slot [y (C) | assignment s (K) | pad] behind them, so that its logits_layer is one aligned MFMA GEMM on
+        # the reference's own feature vector [y_col ; s] (decoder.py:201-206)
+        def is_wide(spec) -> bool:
+            return spec.type == "cat" and int(spec.n_classes) >= WIDE_CAT_MIN_CLASSES
+
+        y_start: Dict[str, int] = {}
+        pos_y = 0
+        for n in names:
+            if not is_wide(schema[n]):
+                y_start[n] = pos_y
+                pos_y += int(ydims[n])
+        pos_y = _r4(pos_y)
+        for n in names:
+            if is_wide(schema[n]):
+                y_start[n] = pos_y
+                pos_y += _r4(int(ydims[n]) + K)
+        self.y_rows = max(pos_y, 1) if any(is_wide(schema[n]) for n in names) else self.total_y
+        self.y_index = np.concatenate([np.arange(y_start[n], y_start[n] + int(ydims[n])) for n in names]).astype(np.int64)
+        add_layer(m.y_proj, "decoder.y_projection.weight", "decoder.y_projection.bias", self.y_rows, prev)
+        if self.y_rows != self.total_y:
+            for key in ("decoder.y_projection.weight", "decoder.y_projection.bias"):
+                sl = self.slots[key]
+                sl.shape = (self.total_y,) + tuple(sl.shape[1:])
+                sl.row_index = self.y_index
+        # likelihood heads (all bias-free, decoder.py:61-62,105-106,153,190-192,233-236): narrow columns contiguous in
+        # schema order, then the wide categorical weight matrices [C-1, ld] with ld = (C + K) rounded up to 4 floats
         m.head_off = off
-        y_off = 0
         i_num = i_disc = 0
         cls_off = 0
+        wide_cols = []
         for n in names:
             spec = schema[n]
             yd = int(ydims[n])
             col = ColT()
             col.type = TYPE_CODE[spec.type]
             col.n_classes = int(spec.n_classes or 0)
-            col.y_off, col.y_dim = y_off, yd
+            col.y_off, col.y_dim = y_start[n], yd
             col.enc_off, col.enc_mask = enc_off[n], enc_mask[n]
             col.w_off, col.w2_off = off, -1
             col.scale, col.shift = 1.0, 0.0
@@ -200,8 +230,11 @@ class ModelLayout:
                 off += yd + K
             elif spec.type == "cat":
                 Cn = int(spec.n_classes)
-                self.slots[p + "logits_layer.weight"] = TensorSlot(p + "logits_layer.weight", off, (Cn - 1, yd + K), yd + K)
-                off += (Cn - 1) * (yd + K)
+                if is_wide(spec):
+                    wide_cols.append((n, col))
+                else:
+                    self.slots[p + "logits_layer.weight"] = TensorSlot(p + "logits_layer.weight", off, (Cn - 1, yd + K), yd + K)
+                    off += (Cn - 1) * (yd + K)
             else:
                 Cn = int(spec.n_classes)
                 self.slots[p + "partition_layer.weight"] = TensorSlot(p + "partition_layer.weight", off, (Cn - 1, K), K)
@@ -217,11 +250,17 @@ class ModelLayout:
                 i_disc += 1
                 self.class_offsets[n] = cls_off
                 cls_off += int(spec.n_classes)
-            y_off += yd
             self.cols.append(col)
-        self.total_classes = cls_off
         m.head_len = off - m.head_off
         off = _r4(off)
+        for n, col in wide_cols:
+            Cn, yd = int(schema[n].n_classes), int(ydims[n])
+            ldw = _r4(yd + K)
+            col.w_off = off
+            key = f"decoder.heads.{n}.logits_layer.weight"
+            self.slots[key] = TensorSlot(key, off, (Cn - 1, yd + K), ldw)
+            off += (Cn - 1) * ldw
+        self.total_classes = cls_off
         self.group_ranges["decoder"] = (g0, off)
         g0 = off
         m.prior_logits_off = m.prior_mu_off = m.prior_logvar_off = m.pm_w_off = m.pm_b_off = -1
@@ -246,7 +285,7 @@ class ModelLayout:
         self.n_params = off
         m.n_cols, m.n_num, m.n_disc = len(names), self.n_num, self.n_disc
         m.n_components, m.latent_dim, m.n_hidden = K, D, len(self.hidden)
-        m.enc_in, m.total_y = self.enc_in, self.total_y
+        m.enc_in, m.total_y, m.y_rows = self.enc_in, self.total_y, self.y_rows
         m.behaviour = 0 if self.behaviour == "supervised" else 1
         m.n_params = off
         m.dropout = float(self.dropout)
@@ -269,12 +308,19 @@ class ModelLayout:
         for name, slot in self.slots.items():
             t = np.asarray(tensors[name], np.float32).reshape(slot.shape)
             if len(slot.shape) == 1:
-                flat[slot.offset : slot.offset + slot.shape[0]] = t
+                if slot.row_index is not None:
+                    flat[slot.offset + slot.row_index] = t
+                else:
+                    flat[slot.offset : slot.offset + slot.shape[0]] = t
             else:
                 rows, cols = slot.shape
+                n_rows = rows if slot.row_index is None else int(slot.row_index.max()) + 1
                 view = np.lib.stride_tricks.as_strided(
-                    flat[slot.offset :], shape=(rows, cols), strides=(slot.ld * 4, 4), writeable=True)
-                view[...] = t
+                    flat[slot.offset :], shape=(n_rows, cols), strides=(slot.ld * 4, 4), writeable=True)
+                if slot.row_index is not None:
+                    view[slot.row_index] = t
+                else:
+                    view[...] = t
         return flat
 
     def unpack(self, flat: np.ndarray) -> Dict[str, np.ndarray]:
@@ -284,11 +330,15 @@ class ModelLayout:
         out: Dict[str, np.ndarray] = {}
         for name, slot in self.slots.items():
             if len(slot.shape) == 1:
-                out[name] = flat[slot.offset : slot.offset + slot.shape[0]].copy()
+                if slot.row_index is not None:
+                    out[name] = flat[slot.offset + slot.row_index].copy()
+                else:
+                    out[name] = flat[slot.offset : slot.offset + slot.shape[0]].copy()
             else:
                 rows, cols = slot.shape
-                view = np.lib.stride_tricks.as_strided(flat[slot.offset :], shape=(rows, cols), strides=(slot.ld * 4, 4))
-                out[name] = view.copy()
+                n_rows = rows if slot.row_index is None else int(slot.row_index.max()) + 1
+                view = np.lib.stride_tricks.as_strided(flat[slot.offset :], shape=(n_rows, cols), strides=(slot.ld * 4, 4))
+                out[name] = view[slot.row_index].copy() if slot.row_index is not None else view.copy()
         return out
 
     def init_params(self, seed: int = 0) -> Dict[str, np.ndarray]:

@@ -176,6 +176,16 @@ def make_columns(kind: str):
             orc.Column("n0", "count", y_dim=2, stats={"offset": 1.0}),
             orc.Column("o0", "ordinal", n_classes=4, y_dim=1),
         ]
+    if kind == "wide7":  # two wide categoricals (>= 17 classes: GEMM head path) between narrow columns
+        return [
+            orc.Column("r0", "real", stats={"mean": 3.0, "std": 2.0}),
+            orc.Column("w0", "cat", n_classes=40),
+            orc.Column("p0", "pos", stats={"mean_log": 0.9, "std_log": 0.45}),
+            orc.Column("c0", "cat", n_classes=3),
+            orc.Column("o0", "ordinal", n_classes=5),
+            orc.Column("w1", "cat", n_classes=17),
+            orc.Column("n0", "count", stats={"offset": 1.0}),
+        ]
     raise ValueError(kind)
 
 
@@ -455,21 +465,33 @@ def gen_tensorise(name, seed, n=40):
 
 
 def main():
+    only = set(sys.argv[1:])  # optional fixture names: regenerate just those
+
+    def want(name):
+        return not only or name in only
+
     check_multinomial_equivalence()
-    gen_tensorise("tensorise_mixed8", 51)
-    gen_elbo("elbo_sup_mixed7_k3", "mixed7", 3, 6, (16, 8), 64, 0.3, 0.0, "supervised", 11)
-    gen_elbo("elbo_sup_mixed7_k1", "mixed7", 1, 2, (8,), 4, 0.0, 0.0, "supervised", 12)
-    gen_elbo("elbo_sup_mixed12_drop", "mixed12", 3, 6, (32, 16), 64, 0.3, 0.1, "supervised", 13, tau=0.7)
-    gen_elbo("elbo_sup_ydim", "ydim", 2, 4, (16, 8), 32, 0.2, 0.0, "supervised", 14)
-    gen_elbo("elbo_unsup_mixed7_k3", "mixed7", 3, 6, (16, 8), 64, 0.3, 0.0, "unsupervised", 21,
-             temperature=0.8)
-    gen_elbo("elbo_unsup_mixed12_notemp", "mixed12", 2, 4, (16, 8), 32, 0.3, 0.0, "unsupervised", 22,
-             temperature=None)
-    gen_elbo("elbo_unsup_mixed7_drop", "mixed7", 3, 6, (16, 8), 16, 0.3, 0.1, "unsupervised", 23,
-             temperature=0.9)
-    gen_decode("decode_mixed12", "mixed12", 3, 6, (16, 8), 64, 31)
-    gen_decode("decode_ydim", "ydim", 2, 4, (16, 8), 32, 32)
-    gen_posterior("posterior_mixed7", "mixed7", 3, 6, (16, 8), 64, 41)
+    jobs = [
+        (gen_tensorise, ("tensorise_mixed8", 51), {}),
+        (gen_elbo, ("elbo_sup_mixed7_k3", "mixed7", 3, 6, (16, 8), 64, 0.3, 0.0, "supervised", 11), {}),
+        (gen_elbo, ("elbo_sup_mixed7_k1", "mixed7", 1, 2, (8,), 4, 0.0, 0.0, "supervised", 12), {}),
+        (gen_elbo, ("elbo_sup_mixed12_drop", "mixed12", 3, 6, (32, 16), 64, 0.3, 0.1, "supervised", 13), {"tau": 0.7}),
+        (gen_elbo, ("elbo_sup_ydim", "ydim", 2, 4, (16, 8), 32, 0.2, 0.0, "supervised", 14), {}),
+        (gen_elbo, ("elbo_unsup_mixed7_k3", "mixed7", 3, 6, (16, 8), 64, 0.3, 0.0, "unsupervised", 21), {"temperature": 0.8}),
+        (gen_elbo, ("elbo_unsup_mixed12_notemp", "mixed12", 2, 4, (16, 8), 32, 0.3, 0.0, "unsupervised", 22),
+         {"temperature": None}),
+        (gen_elbo, ("elbo_unsup_mixed7_drop", "mixed7", 3, 6, (16, 8), 16, 0.3, 0.1, "unsupervised", 23), {"temperature": 0.9}),
+        (gen_decode, ("decode_mixed12", "mixed12", 3, 6, (16, 8), 64, 31), {}),
+        (gen_decode, ("decode_ydim", "ydim", 2, 4, (16, 8), 32, 32), {}),
+        (gen_posterior, ("posterior_mixed7", "mixed7", 3, 6, (16, 8), 64, 41), {}),
+        # wide categorical columns (BASELINE config #4 in miniature)
+        (gen_elbo, ("elbo_sup_wide7", "wide7", 3, 6, (16, 8), 48, 0.3, 0.0, "supervised", 61), {}),
+        (gen_elbo, ("elbo_unsup_wide7", "wide7", 2, 4, (16, 8), 24, 0.3, 0.0, "unsupervised", 62), {"temperature": 0.8}),
+        (gen_decode, ("decode_wide7", "wide7", 3, 6, (16, 8), 32, 63), {}),
+    ]
+    for fn, args, kw in jobs:
+        if want(args[0]):
+            fn(*args, **kw)
 
 
 if __name__ == "__main__":

@@ -72,6 +72,29 @@ def s64_columns(n_cols: int = 64, real_variant: str = "std"):
     return cols
 
 
+def w1024_columns(n_real=400, n_pos=200, n_count=100, n_cat=224, n_ord=100, seed=4):
+    """categorical class counts cycle [2,4,8,16,32,64,128,256], ordinal [3,5,7,10];
+    the column types are interleaved by a seeded shuffle.  Smaller counts give the same shape in miniature."""
+
+    cat_c, ord_c = [2, 4, 8, 16, 32, 64, 128, 256], [3, 5, 7, 10]
+    cols = []
+    cols += [("real", None)] * n_real + [("pos", None)] * n_pos + [("count", None)] * n_count
+    cols += [("cat", cat_c[i % 8]) for i in range(n_cat)] + [("ordinal", ord_c[i % 4]) for i in range(n_ord)]
+    order = np.random.default_rng(seed).permutation(len(cols))
+    out = []
+    for j, i in enumerate(order):
+        t, c = cols[i]
+        if t == "real":
+            out.append(orc.Column(f"f{j}", t, stats={"mean": 50.0, "std": 12.0} if j % 2 else {"mean": 0.0, "std": 1.0}))
+        elif t == "pos":
+            out.append(orc.Column(f"f{j}", t, stats={"mean_log": 1.2, "std_log": 0.45}))
+        elif t == "count":
+            out.append(orc.Column(f"f{j}", t, stats={"offset": 1.0}))
+        else:
+            out.append(orc.Column(f"f{j}", t, n_classes=c))
+    return out
+
+
 def synth_packed(cols, B, mask_rate, seed):
     rng = np.random.default_rng(seed)
     n_num = sum(c.type in ("real", "pos", "count") for c in cols)

@@ -53,7 +53,7 @@ def _unpack(om, layout, onum, ocodes):
     return out
 
 
-@pytest.mark.parametrize("name", ["decode_mixed12", "decode_ydim"])
+@pytest.mark.parametrize("name", ["decode_mixed12", "decode_ydim", "decode_wide7"])
 def test_golden_decode(name):
     import torch
 
@@ -78,17 +78,29 @@ def test_golden_decode(name):
 
 @pytest.mark.parametrize("dense_s", [False, True])
 def test_s64_decode_bit_exact_given_y(dense_s):
+    _decode_given_y(s64_columns(64, real_variant="scaled"), (256, 128), 5000, dense_s)
+
+
+@pytest.mark.parametrize("dense_s", [False, True])
+def test_w1024_miniature_decode_bit_exact_given_y(dense_s):
+    """BASELINE config #4 in miniature: the y row no longer fits LDS, so the unstaged sample kernel runs, and the
+    wide categorical columns read their padded weight layout."""
+
+    from tests.helpers import w1024_columns
+
+    _decode_given_y(w1024_columns(25, 12, 6, 14, 7), (48, 32), 700, dense_s)
+
+
+def _decode_given_y(cols, hidden, n, dense_s):
     import torch
 
-    cols = s64_columns(64, real_variant="scaled")
-    om = orc.OracleModel(cols, n_components=10, latent_dim=32, hidden=(256, 128))
+    om = orc.OracleModel(cols, n_components=10, latent_dim=32, hidden=hidden)
     P = om.init_params(seed=7)
     rng = np.random.default_rng(8)
     for k in P:
         if ".heads." in k:
             P[k] = (0.5 * rng.standard_normal(P[k].shape)).astype(np.float32)
     eng = _engine(om, P)
-    n = 5000
     z = rng.standard_normal((n, 32)).astype(np.float32)
     comp = rng.integers(0, 10, n).astype(np.int32)
     if dense_s:

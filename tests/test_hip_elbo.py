@@ -10,12 +10,12 @@ import pytest
 
 from oracle import suave_oracle as orc
 from tests.helpers import (fixture_model, fixture_noise, layout_from_columns, load_golden, rel_err, s64_columns,
-                           synth_packed, torch_noise)
+                           synth_packed, torch_noise, w1024_columns)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
-SUP = ["elbo_sup_mixed7_k3", "elbo_sup_mixed7_k1", "elbo_sup_mixed12_drop", "elbo_sup_ydim"]
+SUP = ["elbo_sup_mixed7_k3", "elbo_sup_mixed7_k1", "elbo_sup_mixed12_drop", "elbo_sup_ydim", "elbo_sup_wide7"]
 
 
 def _engine(om, P, device="cuda:0"):
@@ -114,6 +114,51 @@ def test_s64_step_matches_oracle(B, dropout):
     _grad_check(eng.grad_state(), ref["grads"])
 
 
+@pytest.mark.parametrize("behaviour", ["supervised", "unsupervised"])
+def test_w1024_miniature_step_matches_oracle(behaviour):
+    """BASELINE config #4 in miniature (64 columns, categoricals up to 256 classes: the GEMM head path next to
+    the fused kernel) against the CPU oracle, ragged batch."""
+
+    import torch
+    from suave_amd.engine import PackedTable
+
+    cols = w1024_columns(25, 12, 6, 14, 7)
+    K, D, hidden = (10, 16, (48, 32)) if behaviour == "supervised" else (3, 8, (32, 16))
+    om = orc.OracleModel(cols, n_components=K, latent_dim=D, hidden=hidden, dropout=0.0, behaviour=behaviour)
+    P = om.init_params(seed=3)
+    rng = np.random.default_rng(5)
+    for k in P:
+        if ".heads." in k:
+            P[k] = (0.3 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    B = 300 if behaviour == "supervised" else 150
+    xnum, codes, mask = synth_packed(cols, B, 0.1, seed=77)
+    x_enc, data, masks = orc.dense_from_packed(om, xnum, codes, mask)
+    eng = _engine(om, P)
+    assert eng.layout.y_rows > eng.layout.total_y  # wide slots present
+    table = PackedTable(xnum, codes, mask, eng.device)
+    if behaviour == "supervised":
+        noise = {"exp": rng.exponential(size=(B, K)).astype(np.float32), "eps": rng.standard_normal((B, D)).astype(np.float32)}
+        ref = orc.elbo_supervised(om, P, x_enc, data, masks, noise, beta_scale=1.5, tau=1.0, training=True)
+        res = eng.elbo(table, 0, B, beta_scale=1.5, tau=1.0, grad=True, noise=torch_noise(noise, eng.device),
+                       want=("reconstruction", "categorical_kl", "gaussian_kl", "latent", "component"), accumulate_sums=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(res["component"].cpu().numpy().astype(np.int64), ref["component_indices"])
+    else:
+        noise = {"exp": rng.exponential(size=(B, K)).astype(np.float32),
+                 "eps": rng.standard_normal((B, K, D)).astype(np.float32)}
+        ref = orc.elbo_unsupervised(om, P, x_enc, data, masks, noise, beta_scale=1.5, temperature=0.8, training=True)
+        res = eng.elbo(table, 0, B, beta_scale=1.5, tau=0.8, grad=True, noise=torch_noise(noise, eng.device),
+                       want=("reconstruction", "categorical_kl", "gaussian_kl", "latent"), accumulate_sums=True)
+        torch.cuda.synchronize()
+    assert rel_err(res["reconstruction"].cpu().numpy(), ref["reconstruction"]) < TOL
+    assert rel_err(res["categorical_kl"].cpu().numpy(), ref["categorical_kl"]) < TOL
+    assert rel_err(res["gaussian_kl"].cpu().numpy(), ref["gaussian_kl"]) < TOL
+    assert rel_err(res["latent"].cpu().numpy(), ref["latent"]) < TOL
+    sums = eng.sums.cpu().numpy()
+    assert abs(sums[0] - float(ref["reconstruction"].sum())) < TOL * abs(float(ref["reconstruction"].sum()))
+    _grad_check(eng.grad_state(), ref["grads"])
+
+
 def test_row_index_gather_and_determinism():
     """A permuted batch through row_index equals the contiguous batch of the permuted table, bit for bit,
     and two identical launches give bit-identical gradients (no float atomics anywhere)."""
@@ -144,7 +189,8 @@ def test_row_index_gather_and_determinism():
     assert torch.equal(g2, eng.grads)
 
 
-UNSUP = ["elbo_unsup_mixed7_k3", "elbo_unsup_mixed12_notemp", "elbo_unsup_mixed7_drop"]
+UNSUP = ["elbo_unsup_mixed7_k3", "elbo_unsup_mixed12_notemp", "elbo_unsup_mixed7_drop",
+         "elbo_unsup_wide7"]
 
 
 @pytest.mark.parametrize("name", UNSUP)

@@ -32,4 +32,4 @@ def test_ctypes_struct_sizes_match_header():
     assert ctypes.sizeof(plan.LayerT) == 20
     assert ctypes.sizeof(plan.BatchT) == 56
     assert ctypes.sizeof(plan.NoiseT) == 16 + 16 * 8 + 16
-    assert ctypes.sizeof(plan.ModelT) == 11 * 4 + (2 * 8 + 2) * 20 + 7 * 4
+    assert ctypes.sizeof(plan.ModelT) == 11 * 4 + (2 * 8 + 2) * 20 + 8 * 4

@@ -16,8 +16,9 @@ from tests.helpers import fixture_model, fixture_noise, load_golden, rel_err
 
 TOL = 1e-4
 
-SUP = ["elbo_sup_mixed7_k3", "elbo_sup_mixed7_k1", "elbo_sup_mixed12_drop", "elbo_sup_ydim"]
-UNSUP = ["elbo_unsup_mixed7_k3", "elbo_unsup_mixed12_notemp", "elbo_unsup_mixed7_drop"]
+SUP = ["elbo_sup_mixed7_k3", "elbo_sup_mixed7_k1", "elbo_sup_mixed12_drop", "elbo_sup_ydim", "elbo_sup_wide7"]
+UNSUP = ["elbo_unsup_mixed7_k3", "elbo_unsup_mixed12_notemp", "elbo_unsup_mixed7_drop",
+         "elbo_unsup_wide7"]
 
 
 def _run(name):
@@ -100,7 +101,7 @@ def test_posterior_statistics_match_reference():
     assert rel_err(pp, fx["out/post_probs_t05"]) < TOL
 
 
-@pytest.mark.parametrize("name", ["decode_mixed12", "decode_ydim"])
+@pytest.mark.parametrize("name", ["decode_mixed12", "decode_ydim", "decode_wide7"])
 def test_decode_matches_reference(name):
     """Head parameters, both log-likelihood masks, and sampled values (bit-exact for
     categorical / ordinal / count) on injected draws."""
