@@ -172,11 +172,14 @@ int suave_elbo_forward(const suave_plan* plan, const float* params, const suave_
  * loss.backward() (model.py:1496-1505).  loss = -mean_b(recon - beta*(KLs)) over
  * global_rows rows (== batch rows on one GPU; the global batch under data
  * parallelism, so that summing rank gradients gives the single-batch gradient).
- * grads [n_params] is overwritten with d loss / d params. */
+ * grads [n_params] is overwritten with d loss / d params.
+ * dlatent (may be NULL; supervised branch only) is [B,D] = d(extra loss)/d latent, added to the
+ * gradient that reaches outputs["latent"]: the classification loss of joint fine-tuning
+ * (`logits = classifier(outputs["latent"])`, model.py:1987-1991), whose head lives outside this library. */
 int suave_elbo_backward(const suave_plan* plan, const float* params, const suave_batch_t* batch,
                         const suave_noise_t* noise, float beta_scale, float tau,
                         int64_t global_rows, void* workspace, size_t workspace_bytes, void* stream,
-                        const suave_elbo_out_t* out, float* grads);
+                        const suave_elbo_out_t* out, float* grads, const float* dlatent);
 
 /* torch.optim.Adam step (defaults betas=(0.9,0.999), eps=1e-8, no weight decay;
  * model.py:1443) on the flat buffers.  group_begin[g]..group_begin[g+1] is the

@@ -376,6 +376,13 @@ __global__ void k_sum_chunks(const float* part, int n_chunks, int n_rows, float*
 // Unsupervised (expectation-form) ELBO: SUAVE._forward_elbo_batch with behaviour="unsupervised"
 // (model.py:1576-1580, :1619-1654).  The decoder runs on B*K virtual rows (row v = b*K + k uses the
 // latent of component k and the one-hot assignment k); tau <= 0 means "temperature is None".
+__global__ void k_add_rows(float* dst, int ld_dst, const float* src, int ld_src, int n_rows, int n_cols) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)n_rows * n_cols; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / n_cols), c = (int)(e % n_cols);
+    dst[(size_t)r * ld_dst + c] += src[(size_t)r * ld_src + c];
+  }
+}
+
 int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_t* batch, const suave_noise_t* noise,
                     float beta_scale, float tau, int training, int64_t global_rows, void* workspace,
                     size_t workspace_bytes, hipStream_t s, const suave_elbo_out_t* out, float* grads) {
@@ -554,10 +561,11 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
 
 int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* batch, const suave_noise_t* noise,
               float beta_scale, float tau, int training, int64_t global_rows, void* workspace,
-              size_t workspace_bytes, hipStream_t s, const suave_elbo_out_t* out, float* grads) {
+              size_t workspace_bytes, hipStream_t s, const suave_elbo_out_t* out, float* grads, const float* dlatent) {
   SUAVE_REQUIRE(p != nullptr && params != nullptr, "plan/params is null");
   if (int rc = check_batch(p, batch)) return rc;
   const suave_model_t& m = p->model;
+  SUAVE_REQUIRE(dlatent == nullptr || m.behaviour == 0, "dlatent is only defined for the supervised branch (model.py:1987-1991)");
   if (m.behaviour == 1)
     return elbo_unsup_impl(p, params, batch, noise, beta_scale, tau, training, global_rows, workspace, workspace_bytes, s,
                            out, grads);
@@ -717,6 +725,10 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
       }
     }
     // ---- latent backward ----
+    if (dlatent) {  // classification loss of joint fine-tuning reaches the encoder through outputs["latent"]
+      hipLaunchKernelGGL(k_add_rows, dim3(std::min((B * D + 255) / 256, 2048)), dim3(256), 0, s, w.dz, p->ldD, dlatent, D, B, D);
+      SUAVE_CHECK_HIP(hipGetLastError());
+    }
     {
       LatentBwdArgs a{};
       a.sel = w.sel; a.ldS = ldS; a.K = K; a.D = D; a.ldK = p->ldK; a.ldD = p->ldD;
@@ -1086,16 +1098,16 @@ extern "C" int suave_elbo_forward(const suave_plan* plan, const float* params, c
                                   void* workspace, size_t workspace_bytes, void* stream,
                                   const suave_elbo_out_t* out) {
   return elbo_impl(plan, params, batch, noise, beta_scale, tau, training, batch ? std::max(batch->n_rows, 1) : 1,
-                   workspace, workspace_bytes, static_cast<hipStream_t>(stream), out, nullptr);
+                   workspace, workspace_bytes, static_cast<hipStream_t>(stream), out, nullptr, nullptr);
 }
 
 extern "C" int suave_elbo_backward(const suave_plan* plan, const float* params, const suave_batch_t* batch,
                                    const suave_noise_t* noise, float beta_scale, float tau, int64_t global_rows,
                                    void* workspace, size_t workspace_bytes, void* stream,
-                                   const suave_elbo_out_t* out, float* grads) {
+                                   const suave_elbo_out_t* out, float* grads, const float* dlatent) {
   SUAVE_REQUIRE(grads != nullptr, "elbo_backward: grads is null");
   return elbo_impl(plan, params, batch, noise, beta_scale, tau, 1, global_rows, workspace, workspace_bytes,
-                   static_cast<hipStream_t>(stream), out, grads);
+                   static_cast<hipStream_t>(stream), out, grads, dlatent);
 }
 
 extern "C" int suave_encode(const suave_plan* p, const float* params, const suave_batch_t* batch,

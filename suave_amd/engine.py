@@ -128,7 +128,8 @@ class Engine:
     def elbo(self, table: PackedTable, row_begin: int, n_rows: int, *, row_index: Optional[torch.Tensor] = None,
              beta_scale: float, tau: Optional[float] = 1.0, grad: bool = True, training: bool = True,
              global_rows: Optional[int] = None, noise: Optional[Mapping[str, object]] = None, seed: int = 0,
-             step: int = 0, want: Sequence[str] = (), accumulate_sums: bool = False) -> Dict[str, torch.Tensor]:
+             step: int = 0, want: Sequence[str] = (), accumulate_sums: bool = False,
+             dlatent: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """One ELBO forward (+ backward into ``self.grads``).  ``want`` selects
         per-row outputs among reconstruction, categorical_kl, gaussian_kl,
         latent, component, enc_out."""
@@ -158,7 +159,7 @@ class Engine:
         if grad:
             rc = self.lib.suave_elbo_backward(self._plan, self.params.data_ptr(), C.byref(batch), C.byref(nz),
                                               float(beta_scale), float(tau), int(global_rows or B), base, nbytes,
-                                              self._stream(), C.byref(out), self.grads.data_ptr())
+                                              self._stream(), C.byref(out), self.grads.data_ptr(), _ptr(dlatent))
             _lib.check(rc, "suave_elbo_backward")
         else:
             rc = self.lib.suave_elbo_forward(self._plan, self.params.data_ptr(), C.byref(batch), C.byref(nz),

@@ -66,7 +66,7 @@ def load():
     lib.suave_elbo_forward.argtypes = [vp, vp, C.POINTER(BatchT), C.POINTER(NoiseT), f32, f32, C.c_int, vp, sz, vp,
                                        C.POINTER(ElboOutT)]
     lib.suave_elbo_backward.argtypes = [vp, vp, C.POINTER(BatchT), C.POINTER(NoiseT), f32, f32, i64, vp, sz, vp,
-                                        C.POINTER(ElboOutT), vp]
+                                        C.POINTER(ElboOutT), vp, vp]
     lib.suave_adam_step.argtypes = [vp, vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, i64, f32, f32, f32, vp]
     lib.suave_encode.argtypes = [vp, vp, C.POINTER(BatchT), f32, vp, sz, vp, vp, vp, vp, vp]
     lib.suave_prior_latents.argtypes = [vp, vp, vp, vp, vp, u64, i64, i64, vp, vp, vp]

@@ -356,6 +356,57 @@ def gen_elbo(name, kind, K, D, hidden, B, mask_rate, dropout, behaviour, seed,
     print("wrote", name, "loss", float(out["loss"]))
 
 
+def gen_joint(name, kind, K, D, hidden, B, mask_rate, seed, n_classes=3, cls_weight=0.7):
+    """One joint fine-tuning step (model.py:1973-1999): ELBO loss + weight * cross-entropy of
+    ``classifier(outputs["latent"])``; gradients of the JOINT loss on every parameter."""
+
+    from suave.modules.heads import ClassificationHead
+
+    rng = np.random.default_rng(seed)
+    cols = make_columns(kind)
+    model, om = build_reference(cols, K, D, hidden, 0.0, "supervised", seed)
+    torch.manual_seed(seed + 3)
+    clf = ClassificationHead(D, n_classes, class_weight=[1.0, 2.0, 0.5][:n_classes])
+    xnum, codes, mask = make_batch(cols, B, mask_rate, rng)
+    x_enc, data_t, mask_t = to_torch_batches(om, xnum, codes, mask)
+    targets = torch.from_numpy(rng.integers(0, n_classes, B).astype(np.int64))
+    P0 = ref_params(model, "supervised")
+    model._encoder.train()
+    model._decoder.train()
+    clf.train()
+    named = ref_named_parameters(model, "supervised")
+    with NoiseTape() as tape:
+        out = model._forward_elbo_batch(x_enc, data_t, mask_t, beta_scale=model.beta, temperature=None)
+        logits = clf(out["latent"])
+        class_loss = clf.loss(logits, targets)
+        joint = out["loss"] + class_loss * cls_weight
+        for _, p in named:
+            p.grad = None
+        joint.backward()
+    rec = {
+        "meta": json.dumps(dict(kind=kind, K=K, D=D, hidden=list(hidden), B=B, mask_rate=mask_rate, dropout=0.0,
+                                behaviour="supervised", beta_scale=float(model.beta), tau=1.0, seed=seed,
+                                n_classes=n_classes, cls_weight=cls_weight)),
+        "columns": cols_json(cols),
+        "xnum": xnum, "codes": codes, "mask": mask,
+        "noise/exp": tape.exp[0].numpy(), "noise/eps": tape.randn[0].numpy(),
+        "targets": targets.numpy(),
+        "clf/linear.weight": clf.linear.weight.detach().numpy(), "clf/linear.bias": clf.linear.bias.detach().numpy(),
+        "clf/class_weight": clf.class_weight.numpy(),
+        "clf_grad/linear.weight": clf.linear.weight.grad.numpy(), "clf_grad/linear.bias": clf.linear.bias.grad.numpy(),
+        "out/class_loss": class_loss.detach().numpy(), "out/joint_loss": joint.detach().numpy(),
+        "out/logits": logits.detach().numpy(),
+    }
+    for k, v in P0.items():
+        rec["param/" + k] = v
+    for k, p in named:
+        rec["grad/" + k] = p.grad.detach().numpy().copy() if p.grad is not None else np.zeros(p.shape, np.float32)
+    for key in ("loss", "reconstruction", "categorical_kl", "gaussian_kl", "latent"):
+        rec["out/" + key] = out[key].detach().numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print("wrote", name, "joint loss", float(joint))
+
+
 def gen_decode(name, kind, K, D, hidden, B, seed):
     """Decoder forward on placeholder batches (sampling path, model.py:4397-4420):
     head params, log-likelihoods with both masks, injected draws and samples."""
@@ -488,6 +539,7 @@ def main():
         (gen_elbo, ("elbo_sup_wide7", "wide7", 3, 6, (16, 8), 48, 0.3, 0.0, "supervised", 61), {}),
         (gen_elbo, ("elbo_unsup_wide7", "wide7", 2, 4, (16, 8), 24, 0.3, 0.0, "unsupervised", 62), {"temperature": 0.8}),
         (gen_decode, ("decode_wide7", "wide7", 3, 6, (16, 8), 32, 63), {}),
+        (gen_joint, ("joint_sup_mixed7", "mixed7", 3, 6, (16, 8), 48, 0.3, 71), {}),
     ]
     for fn, args, kw in jobs:
         if want(args[0]):

@@ -232,6 +232,41 @@ def test_golden_unsupervised_step(name):
         assert np.allclose(upd[nzm], upd_ref[nzm], atol=2e-3 * meta["lr"], rtol=0), k
 
 
+def test_golden_joint_finetune_step():
+    """Joint fine-tuning step (model.py:1973-1999): the classifier's cross-entropy reaches the encoder through
+    outputs["latent"]; its gradient is injected as `dlatent` and the JOINT-loss gradients match the reference."""
+
+    import torch
+    import torch.nn.functional as F
+    from suave_amd.engine import PackedTable
+
+    fx = load_golden("joint_sup_mixed7")
+    om, P, meta = fixture_model(fx)
+    eng = _engine(om, P)
+    table = PackedTable(fx["xnum"], fx["codes"], fx["mask"], eng.device)
+    noise = torch_noise({"exp": fx["noise/exp"], "eps": fx["noise/eps"]}, eng.device)
+    B = meta["B"]
+    fwd = eng.elbo(table, 0, B, beta_scale=meta["beta_scale"], tau=meta["tau"], grad=False, training=True, noise=noise,
+                   want=("latent",))
+    latent = fwd["latent"].clone().requires_grad_(True)
+    W = torch.from_numpy(fx["clf/linear.weight"]).to(eng.device).requires_grad_(True)
+    b = torch.from_numpy(fx["clf/linear.bias"]).to(eng.device).requires_grad_(True)
+    logits = latent @ W.t() + b
+    class_loss = F.cross_entropy(logits, torch.from_numpy(fx["targets"]).to(eng.device),
+                                 weight=torch.from_numpy(fx["clf/class_weight"]).to(eng.device))
+    (class_loss * meta["cls_weight"]).backward()
+    assert abs(float(class_loss) - float(fx["out/class_loss"])) < TOL * abs(float(fx["out/class_loss"]))
+    res = eng.elbo(table, 0, B, beta_scale=meta["beta_scale"], tau=meta["tau"], grad=True, noise=noise,
+                   want=("latent", "reconstruction"), dlatent=latent.grad.contiguous())
+    torch.cuda.synchronize()
+    assert rel_err(res["latent"].cpu().numpy(), fx["out/latent"]) < TOL
+    assert rel_err(res["reconstruction"].cpu().numpy(), fx["out/reconstruction"]) < TOL
+    ref_grads = {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")}
+    _grad_check(eng.grad_state(), ref_grads)
+    assert rel_err(W.grad.cpu().numpy(), fx["clf_grad/linear.weight"]) < TOL
+    assert rel_err(b.grad.cpu().numpy(), fx["clf_grad/linear.bias"]) < TOL
+
+
 def test_forward_only_matches_backward_outputs():
     """suave_elbo_forward (validation path, model.py:2497-2559) returns the same per-row terms as the training call."""
 
