@@ -8,10 +8,15 @@ path: constructor kwargs (model.py:277-312), ``fit`` (:883-901), ``encode``
 What is covered: the ELBO warm-up phase for both behaviours (the whole
 unsupervised ``fit`` is this phase, model.py:1382-1560), per-epoch validation
 ELBO (:2497-2559), posterior-statistics caches (:1669-1741, :2725-2761),
-generation, imputation and the Monte-Carlo posterior predictive.  The
-supervised classifier head / joint fine-tune / decoder-refine phases
-(model.py:1743-2445) and temperature calibration are outside the hot path
- and are not implemented here.
+generation, imputation, the Monte-Carlo posterior predictive, and the
+supervised schedule: classifier-head phase
+(:1743-1864), joint fine-tuning with early stopping (:1866-2086), the four
+decoder-refine modes incl. the closed-form EM prior refresh (:2088-2495),
+``predict`` / ``predict_proba`` / ``calibrate`` / ``predict_confidence_interval``
+and ``save`` / ``load``.  Every encoder / decoder / likelihood computation runs
+in ``libsuave_hip.so``; the tiny classifier head and the temperature scaler stay
+on PyTorch-ROCm (``supervised.py``) and exchange ``latent`` / ``dlatent`` with
+the library.
 """
 
 from __future__ import annotations
@@ -24,22 +29,30 @@ import pandas as pd
 import torch
 
 from . import data as data_utils
+from . import supervised as sup
 from .engine import Engine, PackedTable
 from .plan import ModelLayout
 from .types import Schema
 
 _DEFAULTS = dict(latent_dim=32, n_components=1, beta=1.5, hidden_dims=(256, 128), dropout=0.1, learning_rate=1e-3,
                  batch_size=128, kl_warmup_epochs=10, warmup_epochs=10, val_split=0.2, random_state=0,
-                 gumbel_temperature=1.0)  # model.py:51-68
+                 gumbel_temperature=1.0, head_epochs=5, finetune_epochs=10, joint_decoder_lr_scale=0.1,
+                 early_stop_patience=5)  # model.py:51-68
+_REFINE_MODES = ("decoder_only", "decoder_prior", "prior_em_only", "prior_em_decoder")
 
 
 class SUAVE:
     def __init__(self, schema: Optional[Schema] = None, *, behaviour: Literal["supervised", "unsupervised"] = "supervised",
                  latent_dim: Optional[int] = None, n_components: int = 1, beta: float = 1.5,
-                 hidden_dims: Optional[Iterable[int]] = None, dropout: Optional[float] = None,
+                 hidden_dims: Optional[Iterable[int]] = None, head_hidden_dims: Iterable[int] = (),
+                 classification_loss_weight: Optional[float] = None, dropout: Optional[float] = None,
                  learning_rate: Optional[float] = None, batch_size: Optional[int] = None,
                  warmup_epochs: Optional[int] = None, kl_warmup_epochs: Optional[int] = None,
-                 val_split: float = 0.2, random_state: int = 0, gumbel_temperature: float = 1.0,
+                 head_epochs: Optional[int] = None, finetune_epochs: Optional[int] = None,
+                 decoder_refine_epochs: Optional[int] = None, decoder_refine_mode: str = "decoder_prior",
+                 decoder_refine_prior_lambda: float = 1e-4, early_stop_patience: Optional[int] = None,
+                 joint_decoder_lr_scale: float = 0.1, val_split: float = 0.2, stratify: bool = True,
+                 random_state: int = 0, gumbel_temperature: float = 1.0,
                  tau_start: float = 1.0, tau_min: float = 1e-3, tau_decay: float = 0.01,
                  device: Optional[str] = None) -> None:
         behaviour = str(behaviour).lower()
@@ -68,6 +81,22 @@ class SUAVE:
             raise ValueError("batch_size must be positive")
         self.warmup_epochs = int(_DEFAULTS["warmup_epochs"] if warmup_epochs is None else warmup_epochs)
         self.kl_warmup_epochs = int(_DEFAULTS["kl_warmup_epochs"] if kl_warmup_epochs is None else kl_warmup_epochs)
+        self.head_hidden_dims = tuple(int(h) for h in head_hidden_dims)
+        if any(h <= 0 for h in self.head_hidden_dims):
+            raise ValueError("head_hidden_dims must contain positive integers")
+        self._classification_loss_weight_user = classification_loss_weight is not None
+        self.classification_loss_weight = None if classification_loss_weight is None else float(classification_loss_weight)
+        self.head_epochs = int(_DEFAULTS["head_epochs"] if head_epochs is None else head_epochs)
+        self.finetune_epochs = int(_DEFAULTS["finetune_epochs"] if finetune_epochs is None else finetune_epochs)
+        self._decoder_refine_epochs_user = decoder_refine_epochs is not None
+        self.decoder_refine_epochs = None if decoder_refine_epochs is None else int(decoder_refine_epochs)
+        if decoder_refine_mode not in _REFINE_MODES:
+            raise ValueError("decoder_refine_mode must be one of " + ", ".join(_REFINE_MODES))
+        self.decoder_refine_mode = decoder_refine_mode
+        self.decoder_refine_prior_lambda = float(decoder_refine_prior_lambda)
+        self.early_stop_patience = int(_DEFAULTS["early_stop_patience"] if early_stop_patience is None else early_stop_patience)
+        self.joint_decoder_lr_scale = float(joint_decoder_lr_scale)
+        self.stratify = bool(stratify)
         self.val_split = float(val_split)
         self.random_state = int(random_state)
         self.gumbel_temperature = float(gumbel_temperature)
@@ -83,6 +112,13 @@ class SUAVE:
         self._train_cache: Dict[str, torch.Tensor] = {}
         self._warmup_val_history: list = []
         self._train_history: list = []
+        self._classifier: Optional[sup.ClassificationHead] = None
+        self._temperature_scaler = sup.TemperatureScaler()
+        self._is_calibrated = False
+        self._joint_val_metrics: Optional[Dict[str, float]] = None
+        self._joint_history: list = []
+        self._refine_history: list = []
+        self._step = 0
 
     # ------------------------------------------------------------------
     def _select_device(self) -> torch.device:
@@ -110,8 +146,11 @@ class SUAVE:
     # ------------------------------------------------------------------
     def fit(self, X: pd.DataFrame, y=None, *, schema: Optional[Schema] = None, epochs: Optional[int] = None,
             batch_size: Optional[int] = None, kl_warmup_epochs: Optional[int] = None,
-            warmup_epochs: Optional[int] = None) -> "SUAVE":
-        """ELBO warm-up training (the whole ``fit`` for behaviour="unsupervised")."""
+            warmup_epochs: Optional[int] = None, head_epochs: Optional[int] = None,
+            finetune_epochs: Optional[int] = None, decoder_refine_epochs: Optional[int] = None,
+            joint_decoder_lr_scale: Optional[float] = None, early_stop_patience: Optional[int] = None) -> "SUAVE":
+        """The reference's staged schedule (model.py:883-1380): ELBO warm-up, then for behaviour="supervised" the
+        classifier-head phase, joint fine-tuning and decoder refinement.  ``epochs`` overrides the warm-up length."""
 
         if schema is not None:
             self.schema = schema
@@ -125,47 +164,127 @@ class SUAVE:
         bs = int(batch_size or self.batch_size)
         n_epochs = int(epochs if epochs is not None else (warmup_epochs if warmup_epochs is not None else self.warmup_epochs))
         kl_epochs = int(self.kl_warmup_epochs if kl_warmup_epochs is None else kl_warmup_epochs)
+        n_head = int(self.head_epochs if head_epochs is None else head_epochs)
+        n_joint = int(self.finetune_epochs if finetune_epochs is None else finetune_epochs)
+        if decoder_refine_epochs is not None:
+            n_refine = int(decoder_refine_epochs)
+        elif self._decoder_refine_epochs_user:
+            n_refine = int(self.decoder_refine_epochs)
+        else:
+            n_refine = n_epochs  # model.py:1160-1166
+        lr_scale = float(self.joint_decoder_lr_scale if joint_decoder_lr_scale is None else joint_decoder_lr_scale)
+        patience = int(self.early_stop_patience if early_stop_patience is None else early_stop_patience)
         X = X.loc[:, list(self.schema.feature_names)].reset_index(drop=True)
         n = len(X)
         rng = np.random.default_rng(self.random_state)
-        order = rng.permutation(n)
-        n_val = int(round(n * self.val_split)) if n > 1 else 0  # split_train_val (data.py:17-104), unstratified
+        y_arr = None if y is None else np.asarray(y).reshape(-1)
+        if y_arr is not None and len(y_arr) != n:
+            raise ValueError("X and y must have matching first dimensions")
+        n_val = int(round(n * self.val_split)) if n > 1 else 0  # split_train_val (data.py:17-104)
         n_val = min(max(n_val, 0), max(n - 1, 0))
-        val_idx, train_idx = np.sort(order[:n_val]), np.sort(order[n_val:])
+        if y_arr is not None and self.stratify and n_val > 0:  # per-class share of the validation rows
+            val_parts = []
+            for c in np.unique(y_arr):
+                idx_c = rng.permutation(np.flatnonzero(y_arr == c))
+                val_parts.append(idx_c[: int(round(len(idx_c) * self.val_split))])
+            val_idx = np.sort(np.concatenate(val_parts)) if val_parts else np.empty(0, np.int64)
+            train_idx = np.setdiff1d(np.arange(n), val_idx)
+            if len(train_idx) == 0:
+                train_idx, val_idx = val_idx[:1], val_idx[1:]
+        else:
+            order = rng.permutation(n)
+            val_idx, train_idx = np.sort(order[:n_val]), np.sort(order[n_val:])
+        n_val = len(val_idx)
         X_train, X_val = X.iloc[train_idx], X.iloc[val_idx]
         self._norm_stats_per_col = data_utils.fit_norm_stats(X_train, self.schema)  # statistics from the train split
-        if y is not None:
-            y_arr = np.asarray(y).reshape(-1)
-            self._classes = np.unique(y_arr)
+        y_train_t = y_val_t = None
+        class_weights = None
+        if y_arr is not None:
+            self._classes = np.unique(y_arr[train_idx])
+            self.classes_ = self._classes
             self._class_to_index = {c.item() if isinstance(c, np.generic) else c: i for i, c in enumerate(self._classes)}
-            self._train_target_indices = np.asarray([self._class_to_index[v.item() if isinstance(v, np.generic) else v]
-                                                     for v in y_arr[train_idx]], dtype=np.int64)
+            self._train_target_indices = self._map_targets(y_arr[train_idx])
+            counts = np.bincount(self._train_target_indices, minlength=len(self._classes)).astype(np.float32)
+            class_weights = counts.sum() / (len(counts) * counts)  # model.py:1116-1122
         self._layout = ModelLayout(self.schema, self.n_components, self.latent_dim, self.hidden_dims, self.dropout,
                                    self.behaviour, self._norm_stats_per_col)
         self._engine = eng = Engine(self._layout, self._select_device())
         eng.load_state(self._layout.init_params(seed=self.random_state))
+        if y_arr is not None:
+            y_train_t = torch.from_numpy(self._train_target_indices).to(eng.device)
+            if n_val:
+                y_val_t = torch.from_numpy(self._map_targets(y_arr[val_idx])).to(eng.device)
         train = self._table(X_train)
         val = self._table(X_val) if n_val else None
+        self._gen = torch.Generator(device=eng.device)
+        self._gen.manual_seed(self.random_state)
+        self._step = 0
+        self._classifier = None
+        self._warmup_phase(train, val, n_epochs, bs, kl_epochs)
+        supervised = self.behaviour == "supervised" and y_train_t is not None
+        if supervised:
+            torch.manual_seed(self.random_state)
+            self._classifier = sup.ClassificationHead(self.latent_dim, max(len(self._classes), 2), class_weight=(
+                class_weights if len(self._classes) >= 2 else None), dropout=self.dropout,
+                hidden_dims=self.head_hidden_dims).to(eng.device)
+            self._train_head_phase(self._posterior_mean(train), y_train_t, n_head, bs)
+            warmup_scale = self._warmup_val_history[-1]["nll"] if self._warmup_val_history else None
+            ce_scale = None
+            if val is not None and y_val_t is not None:
+                ce_scale = self._validation_scores(val, bs, y_val_t, None).get("classification_loss")
+            if not (self._classification_loss_weight_user and self.classification_loss_weight is not None):
+                self.classification_loss_weight = sup.derive_classification_loss_weight(warmup_scale, ce_scale)
+            self._joint_finetune(train, val, y_train_t, y_val_t, n_joint, bs, lr_scale, patience,
+                                 float(self.classification_loss_weight))
+            self._refine_decoder(train, val, n_refine, bs, patience)
+        else:
+            self._joint_val_metrics = self._warmup_val_history[-1] if self._warmup_val_history else None
+        self._cache_training_statistics(train, bs)
+        self._temperature_scaler = sup.TemperatureScaler()
+        self._is_calibrated = False
+        self._is_fitted = True
+        return self
+
+    def _map_targets(self, values) -> np.ndarray:
+        """model.py `_map_targets_to_indices`: labels -> class indices, unknown labels raise."""
+
+        out = np.empty(len(values), np.int64)
+        for i, v in enumerate(np.asarray(values).reshape(-1)):
+            key = v.item() if isinstance(v, np.generic) else v
+            if key not in self._class_to_index:
+                raise ValueError(f"Unknown class label '{key}'")
+            out[i] = self._class_to_index[key]
+        return out
+
+    # ------------------------------------------------------------------
+    def _epoch_batches(self, n_rows: int, eff: int):
+        perm = torch.randperm(n_rows, device=self._engine.device, generator=self._gen, dtype=torch.int64)
+        perm32 = perm.to(torch.int32)
+        for start in range(0, n_rows, max(eff, 1)):  # last batch ragged, no drop-last (model.py:1475-1476)
+            yield perm[start:start + eff], perm32[start:start + eff]
+
+    def _warmup_phase(self, train: PackedTable, val: Optional[PackedTable], n_epochs: int, bs: int, kl_epochs: int) -> None:
+        """_run_warmup_phase (model.py:1382-1560)."""
+
+        eng = self._engine
         n_train = train.n_rows
         eff = min(bs, n_train) if n_train else bs
         n_batches = max(1, math.ceil(max(n_train, 1) / max(eff, 1)))
         kl_steps = max(1, kl_epochs * n_batches)  # model.py:1448
-        gen = torch.Generator(device=eng.device)
-        gen.manual_seed(self.random_state)
-        step = 0
+        eng.reset_optimizer()
+        warm_step = 0
         self._train_history, self._warmup_val_history = [], []
         for epoch in range(n_epochs):
             tau = self._gumbel_temperature_for_epoch(epoch) if self.behaviour == "unsupervised" else self.gumbel_temperature
             if self.behaviour == "unsupervised":
                 self._inference_tau = tau
-            perm = torch.randperm(n_train, device=eng.device, generator=gen, dtype=torch.int64).to(torch.int32)
             eng.sums.zero_()
-            for start in range(0, n_train, max(eff, 1)):  # last batch ragged, no drop-last (model.py:1475-1476)
-                idx = perm[start:start + eff]
-                step += 1
-                beta = self.beta * min(step, kl_steps) / kl_steps  # losses.kl_warmup
+            for _, idx in self._epoch_batches(n_train, eff):
+                warm_step += 1
+                self._step += 1
+                beta = self.beta * min(warm_step, kl_steps) / kl_steps  # losses.kl_warmup
                 eng.elbo(train, 0, int(idx.numel()), row_index=idx, beta_scale=beta, tau=tau, grad=True,
-                         seed=self.random_state, step=step, accumulate_sums=True)
+                         seed=self.random_state, step=self._step, accumulate_sums=True)
                 eng.adam_step(self.learning_rate)
             s = eng.sums.cpu().numpy()  # ONE host sync per epoch (the reference syncs 4-5x per batch)
             cnt = max(s[3], 1.0)
@@ -173,9 +292,250 @@ class SUAVE:
                                         "gaussian_kl": s[2] / cnt})
             if val is not None and val.n_rows:
                 self._warmup_val_history.append(self._elbo_on_table(val, bs, tau, seed=self.random_state + 1 + epoch))
-        self._cache_training_statistics(train, bs)
-        self._is_fitted = True
-        return self
+
+    def _posterior_mean(self, table: PackedTable) -> torch.Tensor:
+        """posterior["mean"] of _collect_posterior_statistics (model.py:1669-1741), kept on the device."""
+
+        tau = self._inference_tau if self.behaviour == "unsupervised" else None
+        outs = [self._engine.encode(table, s0, min(65536, table.n_rows - s0), temperature=tau)["mean"]
+                for s0 in range(0, table.n_rows, 65536)]
+        return torch.cat(outs) if outs else torch.empty((0, self.latent_dim), device=self._engine.device)
+
+    def _train_head_phase(self, latent_mu: torch.Tensor, y_t: torch.Tensor, epochs: int, bs: int) -> None:
+        """_train_head_phase (model.py:1743-1864): Adam on the classifier over cached latent means."""
+
+        if self._classifier is None or epochs <= 0 or latent_mu.shape[0] == 0:
+            return
+        n = latent_mu.shape[0]
+        eff = min(bs, n)
+        opt = torch.optim.Adam(self._classifier.parameters(), lr=self.learning_rate)
+        self._classifier.train()
+        self._head_history = []
+        for _ in range(epochs):
+            tot = torch.zeros((), device=latent_mu.device, dtype=torch.float64)
+            for idx, _ in self._epoch_batches(n, eff):
+                loss = self._classifier.loss(self._classifier(latent_mu[idx]), y_t[idx])
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                tot += loss.detach().double() * idx.numel()
+            self._head_history.append(float(tot.item()) / n)
+        self._classifier.eval()
+
+    def _validation_scores(self, val: Optional[PackedTable], bs: int, y_val_t: Optional[torch.Tensor],
+                           weight: Optional[float]) -> Dict[str, float]:
+        """_compute_validation_scores (model.py:2561-2634)."""
+
+        if val is None or val.n_rows == 0:
+            return {}
+        tau = self._inference_tau if self.behaviour == "unsupervised" else self.gumbel_temperature
+        self._val_calls = getattr(self, "_val_calls", 0) + 1
+        m = dict(self._elbo_on_table(val, bs, tau, seed=self.random_state + 7919 * self._val_calls))
+        for key in ("brier", "ece", "classification_loss", "auroc", "joint_objective"):
+            m.setdefault(key, float("nan"))
+        if self._classifier is None or y_val_t is None:
+            if weight is not None and math.isfinite(m["nll"]):
+                m["joint_objective"] = m["nll"]
+            return m
+        was_training = self._classifier.training
+        self._classifier.eval()
+        with torch.no_grad():
+            logits = self._classifier(self._posterior_mean(val))
+            m["classification_loss"] = float(self._classifier.loss(logits, y_val_t).item())
+            probs = torch.softmax(logits, dim=-1).cpu().numpy()
+        t = y_val_t.cpu().numpy()
+        for key, fn in (("brier", sup.compute_brier), ("ece", sup.compute_ece), ("auroc", sup.compute_auroc)):
+            try:
+                m[key] = float(fn(probs, t))
+            except ValueError:
+                m[key] = float("nan")
+        if weight is not None:
+            ok = math.isfinite(m["classification_loss"]) and math.isfinite(m["nll"])
+            m["joint_objective"] = m["nll"] + float(weight) * m["classification_loss"] if ok else float("nan")
+        if was_training:
+            self._classifier.train()
+        return m
+
+    def _capture_state(self) -> Dict[str, object]:
+        """_capture_model_state (model.py:2680-2694): device-side copies."""
+
+        st = {"params": self._engine.params.clone()}
+        if self._classifier is not None:
+            st["classifier"] = {k: v.detach().clone() for k, v in self._classifier.state_dict().items()}
+        return st
+
+    def _restore_state(self, st: Dict[str, object]) -> None:
+        self._engine.params.copy_(st["params"])
+        if self._classifier is not None and "classifier" in st:
+            self._classifier.load_state_dict(st["classifier"])
+
+    def _joint_finetune(self, train: PackedTable, val: Optional[PackedTable], y_t: torch.Tensor,
+                        y_val_t: Optional[torch.Tensor], epochs: int, bs: int, lr_scale: float, patience: int,
+                        weight: float) -> int:
+        """_run_joint_finetune (model.py:1866-2086): ELBO + weight * CE(classifier(latent)); encoder and classifier
+        at lr, decoder and prior at lr * lr_scale; early stopping on the validation metrics."""
+
+        self._joint_history = []
+        if epochs <= 0 or self._classifier is None:
+            return 0
+        eng, clf = self._engine, self._classifier
+        weight = float(max(weight, 0.0))
+        eng.reset_optimizer()  # the reference builds a fresh Adam per phase (model.py:1909)
+        clf_opt = torch.optim.Adam(clf.parameters(), lr=self.learning_rate)
+        lrs = {"encoder": self.learning_rate, "decoder": self.learning_rate * lr_scale, "prior": self.learning_rate * lr_scale}
+        clf.train()
+        n = train.n_rows
+        eff = min(bs, n) if n else bs
+        best_state = self._capture_state()
+        best = self._validation_scores(val, bs, y_val_t, weight) or None
+        if best:
+            self._joint_val_metrics = best
+        bad, done = 0, 0
+        tau = self.gumbel_temperature
+        for _ in range(epochs):
+            eng.sums.zero_()
+            ce_tot = torch.zeros((), device=eng.device, dtype=torch.float64)
+            for idx64, idx in self._epoch_batches(n, eff):
+                nb = int(idx.numel())
+                self._step += 1
+                fwd = eng.elbo(train, 0, nb, row_index=idx, beta_scale=self.beta, tau=tau, grad=False, training=True,
+                               seed=self.random_state, step=self._step, want=("latent",))
+                latent = fwd["latent"].requires_grad_(True)
+                class_loss = clf.loss(clf(latent), y_t[idx64])
+                clf_opt.zero_grad()
+                (class_loss * weight).backward()
+                eng.elbo(train, 0, nb, row_index=idx, beta_scale=self.beta, tau=tau, grad=True, seed=self.random_state,
+                         step=self._step, accumulate_sums=True, dlatent=latent.grad.contiguous())
+                eng.adam_step(lrs)
+                clf_opt.step()
+                ce_tot += class_loss.detach().double() * nb
+            s = eng.sums.cpu().numpy()
+            cnt = max(s[3], 1.0)
+            elbo_loss = -(s[0] - self.beta * (s[1] + s[2])) / cnt
+            ce = float(ce_tot.item()) / cnt
+            metrics = self._validation_scores(val, bs, y_val_t, weight)
+            self._joint_history.append({"train_elbo_loss": elbo_loss, "train_classification_loss": ce,
+                                        "train_joint": elbo_loss + weight * ce, "val": metrics})
+            done += 1
+            if best is None or sup.is_better_metrics(metrics, best):
+                best, best_state, bad = metrics, self._capture_state(), 0
+            else:
+                bad += 1
+                if bad > patience:
+                    break
+        self._restore_state(best_state)
+        self._joint_val_metrics = best
+        clf.eval()
+        return done
+
+    def _prior_view(self, name: str) -> torch.Tensor:
+        slot = self._layout.slots[name]
+        return self._engine.params[slot.offset: slot.offset + int(np.prod(slot.shape))].view(*slot.shape)
+
+    def _closed_form_prior_update(self, train: PackedTable) -> None:
+        """_closed_form_prior_update_from_stats (model.py:2447-2495) from posterior responsibilities."""
+
+        eng, K, D = self._engine, self.n_components, self.latent_dim
+        w = torch.zeros(K, device=eng.device, dtype=torch.float64)
+        m1 = torch.zeros((K, D), device=eng.device, dtype=torch.float64)
+        m2 = torch.zeros((K, D), device=eng.device, dtype=torch.float64)
+        for s0 in range(0, train.n_rows, 65536):
+            o = eng.encode(train, s0, min(65536, train.n_rows - s0))
+            p = o["probs"].double()
+            mu = o["enc_out"][:, K:K + K * D].reshape(-1, K, D).double()
+            lv = o["enc_out"][:, K + K * D:].reshape(-1, K, D).double()
+            w += p.sum(dim=0)
+            m1 += (p.unsqueeze(-1) * mu).sum(dim=0)
+            m2 += (p.unsqueeze(-1) * (torch.exp(lv) + mu * mu)).sum(dim=0)
+        total = float(w.sum().item())
+        if total <= 0.0:
+            return
+        cw = torch.clamp(w.unsqueeze(-1), min=1e-6)
+        means = m1 / cw
+        var = torch.clamp(m2 / cw - means * means, min=1e-6)
+        self._prior_view("prior.logits").copy_(torch.log(torch.clamp(w / total, min=1e-6)).float())
+        self._prior_view("prior.mu").copy_(means.float())
+        self._prior_view("prior.logvar").copy_(torch.log(var).float())
+
+    def _refine_decoder(self, train: PackedTable, val: Optional[PackedTable], epochs: int, bs: int, patience: int) -> int:
+        """_refine_decoder_after_joint (model.py:2088-2445): encoder and classifier frozen."""
+
+        self._refine_history = []
+        if self.behaviour != "supervised" or epochs <= 0 or train.n_rows == 0:
+            return 0
+        eng, mode = self._engine, self.decoder_refine_mode
+        patience = max(int(patience), 0)
+        w_cls = self.classification_loss_weight
+        frozen_ce = (self._joint_val_metrics or {}).get("classification_loss")
+        frozen_ce = float(frozen_ce) if frozen_ce is not None and math.isfinite(float(frozen_ce)) else None
+
+        def decorate(m: Dict[str, float]) -> Optional[Dict[str, float]]:
+            if not m:
+                return None
+            m = dict(m)
+            if w_cls is not None and frozen_ce is not None:
+                m["classification_loss"] = frozen_ce
+                if math.isfinite(m.get("nll", float("nan"))):
+                    m["joint_objective"] = m["nll"] + float(w_cls) * frozen_ce
+            if m.get("joint_objective") is None:
+                m["joint_objective"] = m.get("nll")
+            m.setdefault("classification_loss", None)
+            return m
+
+        tau = self.gumbel_temperature
+        self._val_calls = getattr(self, "_val_calls", 0)
+
+        def val_elbo():
+            if val is None or val.n_rows == 0:
+                return {}
+            self._val_calls += 1
+            return self._elbo_on_table(val, bs, tau, seed=self.random_state + 7919 * self._val_calls)
+
+        consumed, after_em = 0, None
+        if mode in ("prior_em_only", "prior_em_decoder"):
+            self._closed_form_prior_update(train)
+            after_em = val_elbo()
+            consumed = 1
+            if mode == "prior_em_only":
+                return 1
+        train_prior = mode == "decoder_prior"
+        lrs = {"encoder": 0.0, "decoder": self.learning_rate, "prior": self.learning_rate if train_prior else 0.0}
+        eng.reset_optimizer()
+        anchors = None
+        if train_prior:
+            anchors = [(self._layout.slots[k], self._prior_view(k).clone())
+                       for k in ("prior.logits", "prior.mu", "prior.logvar")]
+        best_state = self._capture_state()
+        best = decorate(after_em or val_elbo())
+        bad, done = 0, 0
+        n = train.n_rows
+        eff = min(bs, n)
+        lam = float(self.decoder_refine_prior_lambda)
+        for _ in range(epochs):
+            eng.sums.zero_()
+            for _, idx in self._epoch_batches(n, eff):
+                self._step += 1
+                eng.elbo(train, 0, int(idx.numel()), row_index=idx, beta_scale=self.beta, tau=tau, grad=True,
+                         seed=self.random_state, step=self._step, accumulate_sums=True)
+                if anchors and lam != 0.0:  # + lambda * sum_t mse(prior_t, anchor_t)  (model.py:2338-2346)
+                    for slot, snap in anchors:
+                        nel = int(np.prod(slot.shape))
+                        g = eng.grads[slot.offset: slot.offset + nel].view(*slot.shape)
+                        g.add_((self._prior_view(slot.name) - snap) * (2.0 * lam / nel))
+                eng.adam_step(lrs)
+            done += 1
+            s = eng.sums.cpu().numpy()
+            cnt = max(s[3], 1.0)
+            m = decorate(val_elbo())
+            self._refine_history.append({"train_elbo_loss": -(s[0] - self.beta * (s[1] + s[2])) / cnt, "val": m})
+            if m is not None and (best is None or sup.is_better_metrics(m, best)):
+                best, best_state, bad = m, self._capture_state(), 0
+            else:
+                bad += 1
+                if patience > 0 and bad > patience:
+                    break
+        self._restore_state(best_state)
+        return done + consumed
 
     def _elbo_on_table(self, table: PackedTable, batch_size: int, tau: float, seed: int) -> Dict[str, float]:
         """_compute_elbo_on_dataset (model.py:2497-2559): eval mode, beta = self.beta, fresh noise."""
@@ -340,6 +700,219 @@ class SUAVE:
         onum, ocodes = eng.decode_sample(z, component=comp, assignments=assign, seed=seed + 1)
         recon = data_utils.frame_from_packed(onum.cpu().numpy(), ocodes.cpu().numpy(), self.schema,
                                              self._norm_stats_per_col)
+        return self._merge_observed(X, aligned, recon, mask, only_missing)
+
+    # ------------------------------------------------------------------
+    def _ensure_classifier(self, what: str) -> None:
+        if self.behaviour == "unsupervised":
+            raise RuntimeError(f"{what} is unavailable when behaviour='unsupervised': the classifier head is disabled")
+        if not self._is_fitted or self._classifier is None or self._classes is None:
+            raise RuntimeError(f"Model must be fitted before calling {what}")
+
+    def _compute_logits(self, X: pd.DataFrame) -> np.ndarray:
+        """_compute_logits (model.py:3449-3486): classifier on the posterior-mean latent."""
+
+        table = self._table(X.loc[:, list(self.schema.feature_names)])
+        if table.n_rows == 0:
+            return np.empty((0, len(self._classes)), np.float32)
+        self._classifier.eval()
+        with torch.no_grad():
+            return self._classifier(self._posterior_mean(table)).cpu().numpy()
+
+    def _resolve_attribute(self, attr):
+        names = list(self.schema.feature_names)
+        if isinstance(attr, (int, np.integer)):
+            if not 0 <= int(attr) < len(names):
+                raise ValueError(f"Attribute index {attr} is out of range")
+            name = names[int(attr)]
+        else:
+            if attr not in self.schema:
+                raise ValueError(f"Unknown attribute '{attr}'")
+            name = str(attr)
+        return name, self.schema[name], names.index(name)
+
+    def _masked_attr_table(self, X: pd.DataFrame, attr_name: str, mask) -> PackedTable:
+        """_normalize_inputs (model.py:3257-3302): the attribute is always decoded as missing; ``mask`` (True =
+        missing) overrides the NaN-derived pattern."""
+
+        names = list(self.schema.feature_names)
+        aligned = X.loc[:, names].reset_index(drop=True)
+        xnum, codes, m = data_utils.pack_frame(aligned, self.schema, self._norm_stats_per_col)
+        if mask is not None:
+            mm = np.asarray(mask.loc[:, names] if isinstance(mask, pd.DataFrame) else mask, dtype=bool)
+            m = (m.astype(bool) & ~mm).astype(np.uint8)
+        j = names.index(attr_name)
+        m[:, j] = 0
+        i_num = i_disc = 0
+        for jj, nme in enumerate(names):
+            if self.schema[nme].type in ("real", "pos", "count"):
+                xnum[m[:, jj] == 0, i_num] = 0.0
+                i_num += 1
+            else:
+                codes[m[:, jj] == 0, i_disc] = -1
+                i_disc += 1
+        return PackedTable(xnum, codes, m, self._engine.device)
+
+    def predict_proba(self, X: pd.DataFrame, attr=None, *, mask=None, L: int = 100, seed: Optional[int] = None):
+        """attr=None: calibrated classifier probabilities (model.py:3797-3815).  Otherwise the Monte-Carlo posterior
+        predictive of a categorical / ordinal attribute (model.py:3816-3867)."""
+
+        if attr is None:
+            self._ensure_classifier("predict_proba")
+            logits = self._compute_logits(X)
+            if self._is_calibrated:
+                logits = self._temperature_scaler.transform(logits)
+            logits = np.asarray(logits, np.float32)
+            e = np.exp(logits - logits.max(axis=1, keepdims=True)) if logits.size else logits
+            return e / e.sum(axis=1, keepdims=True) if logits.size else logits
+        self._require_fitted("predict_proba")
+        attr_name, spec, j = self._resolve_attribute(attr)
+        if spec.type not in {"cat", "ordinal"}:
+            raise ValueError("predict_proba is only defined for categorical or ordinal attributes")
+        if L <= 0:
+            raise ValueError("L must be a positive integer")
+        eng = self._engine
+        seed = self.random_state if seed is None else int(seed)
+        table = self._masked_attr_table(X, attr_name, mask)
+        n_classes = int(spec.n_classes)
+        if table.n_rows == 0:
+            return torch.empty((0, n_classes), dtype=torch.float32)
+        enc = eng.encode(table, 0, table.n_rows)["enc_out"]
+        z, comp = eng.posterior_draws(enc, int(L), seed=seed)
+        probs = eng.decode_params(z, j, component=comp)
+        probs = probs.view(int(L), table.n_rows, -1).mean(dim=0).clamp(min=1e-8)
+        probs = probs / probs.sum(dim=-1, keepdim=True).clamp_min(1e-8)
+        return probs.cpu()
+
+    def predict_confidence_interval(self, X: pd.DataFrame, attr, *, mask=None, L: int = 1000, ci: float = 0.95,
+                                    statistic: Optional[str] = None, return_samples: bool = False,
+                                    seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """Monte-Carlo posterior predictive statistics of a real / pos / count attribute (model.py:3869-4013):
+        L draws of (s, z) ~ q(.|x_obs), one draw of the attribute's likelihood per latent draw."""
+
+        self._require_fitted("predict_confidence_interval")
+        attr_name, spec, j = self._resolve_attribute(attr)
+        if spec.type in {"cat", "ordinal"}:
+            raise ValueError("predict_confidence_interval is only available for real, pos or count attributes")
+        if L <= 0:
+            raise ValueError("L must be a positive integer")
+        if not (0.0 < ci < 1.0):
+            raise ValueError("ci must lie strictly between 0 and 1")
+        if statistic not in {None, "mean", "median"}:
+            raise ValueError("statistic must be one of None, 'mean' or 'median'")
+        eng = self._engine
+        seed = self.random_state if seed is None else int(seed)
+        table = self._masked_attr_table(X, attr_name, mask)
+        B = table.n_rows
+        if B == 0:
+            empty = torch.empty(0, dtype=torch.float32)
+            out = {"point": empty, "lower": empty, "upper": empty}
+            if return_samples:
+                out["samples"] = empty.view(0, 0)
+            return out
+        i_num = [n for n in self.schema.feature_names if self.schema[n].type in ("real", "pos", "count")].index(attr_name)
+        samples = torch.empty((int(L), B), dtype=torch.float32, device=eng.device)
+        chunk = max(1, (1 << 20) // int(L))  # at most ~1M decoded rows at a time
+        for s0 in range(0, B, chunk):
+            nb = min(chunk, B - s0)
+            enc = eng.encode(table, s0, nb)["enc_out"]
+            z, comp = eng.posterior_draws(enc, int(L), seed=seed, row_offset=s0 * int(L))
+            onum, _ = eng.decode_sample(z, component=comp, seed=seed + 1, row_offset=s0 * int(L))
+            col = onum[:, i_num].view(int(L), nb)
+            if spec.type == "count":  # decoder_outputs_to_frame rounds counts (sampling.py:160-163)
+                col = col.round().clamp(min=0)
+            samples[:, s0:s0 + nb] = col
+        lo_q = (1.0 - ci) / 2.0
+        lower = torch.quantile(samples, lo_q, dim=0)
+        upper = torch.quantile(samples, 1.0 - lo_q, dim=0)
+        if statistic == "mean" or (statistic is None and spec.type in {"real", "count"}):
+            point = samples.mean(dim=0)
+        else:
+            point = samples.median(dim=0).values
+        out = {"point": point.cpu(), "lower": lower.cpu(), "upper": upper.cpu(), "std": samples.std(dim=0, unbiased=False).cpu()}
+        if return_samples:
+            out["samples"] = samples.transpose(0, 1).contiguous().cpu()
+        return out
+
+    def predict(self, X: pd.DataFrame, attr=None, *, mask=None, L: int = 50, mode: str = "point",
+                seed: Optional[int] = None):
+        """Class labels (attr=None, model.py:4062-4083) or attribute predictions (model.py:4085-4117)."""
+
+        if attr is None:
+            probs = self.predict_proba(X)
+            return self._classes[np.argmax(probs, axis=1)] if len(probs) else np.empty(0, dtype=self._classes.dtype)
+        attr_name, spec, _ = self._resolve_attribute(attr)
+        if mode not in {"point", "sample"}:
+            raise ValueError("mode must be either 'point' or 'sample'")
+        seed = self.random_state if seed is None else int(seed)
+        if spec.type in {"cat", "ordinal"}:
+            probs = self.predict_proba(X, attr=attr_name, mask=mask, L=L, seed=seed)
+            if probs.numel() == 0:
+                return probs.new_empty((0,), dtype=torch.long)
+            if mode == "point":
+                return probs.argmax(dim=1)
+            g = torch.Generator()
+            g.manual_seed(seed)
+            return torch.multinomial(probs, 1, generator=g).squeeze(1)
+        stats = self.predict_confidence_interval(X, attr_name, mask=mask, L=max(1, L), statistic=None,
+                                                 return_samples=(mode == "sample"), seed=seed)
+        if mode == "point" or stats.get("samples") is None or stats["samples"].size(1) == 0:
+            return stats["point"]
+        g = torch.Generator()
+        g.manual_seed(seed)
+        pick = torch.randint(0, stats["samples"].size(1), (stats["samples"].size(0),), generator=g)
+        return stats["samples"].gather(1, pick.view(-1, 1)).squeeze(1)
+
+    def calibrate(self, X: pd.DataFrame, y) -> "SUAVE":
+        """Temperature scaling on the classifier logits of ``X`` (model.py:4122-4169)."""
+
+        self._ensure_classifier("calibrate")
+        if len(X) != len(y):
+            raise ValueError("X and y must have matching first dimensions")
+        logits = self._compute_logits(X)
+        self._temperature_scaler.fit(logits, self._map_targets(np.asarray(y)))
+        self._is_calibrated = True
+        return self
+
+    # ------------------------------------------------------------------
+    def impute_mc(self, X: pd.DataFrame, *, L: int = 32, only_missing: bool = True, seed: Optional[int] = None
+                  ) -> pd.DataFrame:
+        """Posterior-predictive Monte-Carlo imputation (BASELINE config #5): ``L`` draws of (s, z) ~ q(.|x_obs) per
+        row, every cell decoded per draw; missing numeric cells get the mean over the draws (counts rounded),
+        missing categorical / ordinal cells the most frequent drawn level.  This generalises the per-attribute MC
+        path (model.py:3304-3421) to all attributes; the reference's own ``impute`` is the single pass above."""
+
+        self._require_fitted("impute_mc")
+        if L <= 0:
+            raise ValueError("L must be a positive integer")
+        eng = self._engine
+        seed = self.random_state if seed is None else int(seed)
+        names = list(self.schema.feature_names)
+        aligned = X.loc[:, names].reset_index(drop=True)
+        xnum, codes, mask = data_utils.pack_frame(aligned, self.schema, self._norm_stats_per_col)
+        table = PackedTable(xnum, codes, mask, eng.device)
+        B, L = table.n_rows, int(L)
+        lay = self._layout
+        onum_all = torch.empty((B, max(lay.n_num, 1)), device=eng.device)
+        ocode_all = torch.empty((B, max(lay.n_disc, 1)), dtype=torch.int16, device=eng.device)
+        is_count = torch.tensor([self.schema[n].type == "count" for n in lay.numeric_columns], device=eng.device)
+        chunk = max(1, (1 << 20) // L)
+        for s0 in range(0, B, chunk):
+            nb = min(chunk, B - s0)
+            enc = eng.encode(table, s0, nb)["enc_out"]
+            z, comp = eng.posterior_draws(enc, L, seed=seed, row_offset=s0 * L)
+            onum, ocodes = eng.decode_sample(z, component=comp, seed=seed + 1, row_offset=s0 * L)
+            if lay.n_num:
+                v = onum.view(L, nb, -1)
+                v = torch.where(is_count, v.round().clamp(min=0), v)
+                onum_all[s0:s0 + nb, : lay.n_num] = v.mean(dim=0)
+            if lay.n_disc:
+                ocode_all[s0:s0 + nb, : lay.n_disc] = torch.mode(ocodes.view(L, nb, -1), dim=0).values
+        recon = data_utils.frame_from_packed(onum_all[:, : lay.n_num].cpu().numpy(), ocode_all[:, : lay.n_disc].cpu().numpy(),
+                                             self.schema, self._norm_stats_per_col)
+        return self._merge_observed(X, aligned, recon, mask, only_missing)
+
+    def _merge_observed(self, X, aligned, recon, mask, only_missing):
         if only_missing:
             imputed = recon.copy()
             for j, column in enumerate(recon.columns):
@@ -364,50 +937,76 @@ class SUAVE:
         return imputed.loc[:, X.columns]
 
     # ------------------------------------------------------------------
-    def predict_proba(self, X: pd.DataFrame, attr=None, *, mask=None, L: int = 100, seed: Optional[int] = None):
-        """Monte-Carlo posterior predictive of a categorical / ordinal attribute (model.py:3816-3867)."""
+    def save(self, path) -> None:
+        """Persist the model in the reference's payload layout (model.py:4456-4579): ``metadata``, ``modules``
+        (``encoder`` / ``decoder`` / ``prior`` / ``classifier`` state dicts under the reference's key names, so an
+        archive written here loads into the reference's modules and vice versa), ``artefacts``."""
 
-        self._require_fitted("predict_proba")
-        if attr is None:
-            raise RuntimeError("classifier probabilities (attr=None) need the supervised head phases, which are "
-                               "outside this package's hot path; pass attr=<categorical or ordinal column>")
-        names = list(self.schema.feature_names)
-        if isinstance(attr, (int, np.integer)):
-            if not 0 <= int(attr) < len(names):
-                raise ValueError(f"Attribute index {attr} is out of range")
-            attr_name = names[int(attr)]
-        else:
-            if attr not in self.schema:
-                raise ValueError(f"Unknown attribute '{attr}'")
-            attr_name = str(attr)
-        spec = self.schema[attr_name]
-        if spec.type not in {"cat", "ordinal"}:
-            raise ValueError("predict_proba is only defined for categorical or ordinal attributes")
-        if L <= 0:
-            raise ValueError("L must be a positive integer")
-        eng = self._engine
-        seed = self.random_state if seed is None else int(seed)
-        aligned = X.loc[:, names].reset_index(drop=True)
-        xnum, codes, m = data_utils.pack_frame(aligned, self.schema, self._norm_stats_per_col)
-        if mask is not None:  # True marks missing (model.py:3748-3756)
-            mm = np.asarray(mask.loc[:, names] if isinstance(mask, pd.DataFrame) else mask, dtype=bool)
-            m = (m.astype(bool) & ~mm).astype(np.uint8)
-        j = names.index(attr_name)
-        m[:, j] = 0  # the attribute is always decoded as missing
-        i_disc = [n for n in names if self.schema[n].type in ("cat", "ordinal")].index(attr_name)
-        codes[:, i_disc] = -1
-        i_num = 0
-        for jj, nme in enumerate(names):
-            if self.schema[nme].type in ("real", "pos", "count"):
-                xnum[m[:, jj] == 0, i_num] = 0.0
-                i_num += 1
-        table = PackedTable(xnum, codes, m, eng.device)
-        n_classes = int(spec.n_classes)
-        if table.n_rows == 0:
-            return torch.empty((0, n_classes), dtype=torch.float32)
-        enc = eng.encode(table, 0, table.n_rows)["enc_out"]
-        z, comp = eng.posterior_draws(enc, int(L), seed=seed)
-        probs = eng.decode_params(z, j, component=comp)
-        probs = probs.view(int(L), table.n_rows, -1).mean(dim=0).clamp(min=1e-8)
-        probs = probs / probs.sum(dim=-1, keepdim=True).clamp_min(1e-8)
-        return probs.cpu()
+        self._require_fitted("save")
+        st = self._engine.state()
+        enc = {k[len("encoder."):]: torch.from_numpy(v.copy()) for k, v in st.items() if k.startswith("encoder.")}
+        dec = {k[len("decoder."):]: torch.from_numpy(v.copy()) for k, v in st.items() if k.startswith("decoder.")}
+        prior = {k: torch.from_numpy(v.copy()) for k, v in st.items() if k.startswith("prior")}
+        meta = dict(behaviour=self.behaviour, latent_dim=self.latent_dim, n_components=self.n_components, beta=self.beta,
+                    hidden_dims=list(self.hidden_dims), head_hidden_dims=list(self.head_hidden_dims), dropout=self.dropout,
+                    learning_rate=self.learning_rate, batch_size=self.batch_size, random_state=self.random_state,
+                    gumbel_temperature=self.gumbel_temperature, inference_tau=self._inference_tau,
+                    classification_loss_weight=self.classification_loss_weight,
+                    schema=self.schema.to_dict(), format="suave_amd/1")
+        payload = {
+            "metadata": meta,
+            "modules": {"encoder": enc, "decoder": dec, "prior": prior,
+                        "classifier": ({k: v.detach().cpu() for k, v in self._classifier.state_dict().items()}
+                                       if self._classifier is not None else None),
+                        "temperature_scaler": self._temperature_scaler.state_dict()},
+            "artefacts": {
+                "norm_stats_per_col": self._norm_stats_per_col,
+                "classes": None if self._classes is None else self._classes.tolist(),
+                "is_calibrated": self._is_calibrated,
+                "train_target_indices": (None if getattr(self, "_train_target_indices", None) is None
+                                         else torch.from_numpy(np.asarray(self._train_target_indices))),
+                "train_cache": {k: v.detach().cpu() for k, v in self._train_cache.items()},
+            },
+        }
+        torch.save(payload, path)
+
+    @classmethod
+    def load(cls, path, *, device: Optional[str] = None) -> "SUAVE":
+        """Restore a model written by :meth:`save` (model.py:4581-4681).  Only plain containers and tensors are
+        stored, so the archive is read with ``weights_only=True``."""
+
+        payload = torch.load(path, map_location="cpu", weights_only=True)
+        meta, mods, art = payload["metadata"], payload["modules"], payload["artefacts"]
+        model = cls(Schema(meta["schema"]), behaviour=meta["behaviour"], latent_dim=meta["latent_dim"],
+                    n_components=meta["n_components"], beta=meta["beta"], hidden_dims=meta["hidden_dims"],
+                    head_hidden_dims=meta.get("head_hidden_dims", ()), dropout=meta["dropout"],
+                    learning_rate=meta["learning_rate"], batch_size=meta["batch_size"], random_state=meta["random_state"],
+                    gumbel_temperature=meta["gumbel_temperature"],
+                    classification_loss_weight=meta.get("classification_loss_weight"), device=device)
+        model._inference_tau = float(meta.get("inference_tau", 1.0))
+        model._norm_stats_per_col = art["norm_stats_per_col"]
+        model._layout = ModelLayout(model.schema, model.n_components, model.latent_dim, model.hidden_dims, model.dropout,
+                                    model.behaviour, model._norm_stats_per_col)
+        model._engine = eng = Engine(model._layout, model._select_device())
+        tensors = {"encoder." + k: v.numpy() for k, v in mods["encoder"].items()}
+        tensors.update({"decoder." + k: v.numpy() for k, v in mods["decoder"].items()})
+        tensors.update({k: v.numpy() for k, v in mods["prior"].items()})
+        eng.load_state(tensors)
+        if art.get("classes") is not None:
+            model._classes = np.asarray(art["classes"])
+            model.classes_ = model._classes
+            model._class_to_index = {c.item() if isinstance(c, np.generic) else c: i for i, c in enumerate(model._classes)}
+        if art.get("train_target_indices") is not None:
+            model._train_target_indices = art["train_target_indices"].numpy()
+        if mods.get("classifier") is not None:
+            cstate = mods["classifier"]
+            model._classifier = sup.ClassificationHead(model.latent_dim, int(cstate["linear.weight"].shape[0]),
+                                                       class_weight=cstate["class_weight"].numpy(), dropout=model.dropout,
+                                                       hidden_dims=model.head_hidden_dims).to(eng.device)
+            model._classifier.load_state_dict(cstate)
+            model._classifier.eval()
+        model._temperature_scaler.load_state_dict(mods.get("temperature_scaler", {}))
+        model._is_calibrated = bool(art.get("is_calibrated", False))
+        model._train_cache = {k: v.to(eng.device) for k, v in art.get("train_cache", {}).items()}
+        model._is_fitted = True
+        return model

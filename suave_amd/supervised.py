@@ -1,0 +1,218 @@
+"""Supervised extras around the HIP ELBO step: classification head, temperature
+scaling and the validation metrics the training schedule compares.
+
+These are the small pieces SURVEY.md §2 rows 16-17 keep on stock PyTorch-ROCm
+(a ``[B, D] x [D, C]`` linear and a one-parameter fit): the head consumes the
+``latent`` output of ``suave_elbo_forward`` and hands ``d loss / d latent``
+back to ``suave_elbo_backward`` (``dlatent``), so the encoder / decoder math of
+joint fine-tuning stays in the HIP library.
+
+Reference: ``suave/modules/heads.py`` (ClassificationHead),
+``suave/modules/calibrate.py`` (TemperatureScaler), ``suave/evaluate.py:88-297``
+(AUROC / Brier / ECE as used by ``model.py:2609-2622``).
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+
+class ClassificationHead(nn.Module):
+    """heads.py:12-91: optional ``Linear -> ReLU -> Dropout`` stack, then ``linear``; weighted cross-entropy.
+    Parameter names match the reference ``state_dict`` (``hidden_layers.<i>.*``, ``linear.*``, ``class_weight``)."""
+
+    def __init__(self, in_features: int, n_classes: int, *, class_weight=None, dropout: float = 0.0,
+                 hidden_dims: Iterable[int] = ()) -> None:
+        super().__init__()
+        if n_classes < 2:
+            raise ValueError("Classification head requires at least two classes")
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError("dropout must lie in the interval [0, 1)")
+        hidden_dims = tuple(int(d) for d in hidden_dims)
+        if any(d <= 0 for d in hidden_dims):
+            raise ValueError("hidden_dims must contain positive integers")
+        layers = []
+        prev = int(in_features)
+        for h in hidden_dims:
+            layers += [nn.Linear(prev, h), nn.ReLU()]
+            if dropout:
+                layers.append(nn.Dropout(float(dropout)))
+            prev = h
+        self.hidden_layers = nn.Sequential(*layers) if layers else None
+        self._final_dropout = nn.Dropout(float(dropout)) if dropout and not hidden_dims else None
+        self.linear = nn.Linear(prev, n_classes)
+        if class_weight is not None:
+            w = torch.as_tensor(np.asarray(class_weight), dtype=torch.float32)
+            if w.numel() != n_classes:
+                raise ValueError("class_weight must provide a value for every target class")
+            self.register_buffer("class_weight", w)
+            self._use_weight = True
+        else:
+            self.register_buffer("class_weight", torch.ones(n_classes))
+            self._use_weight = False
+
+    def forward(self, latents: torch.Tensor) -> torch.Tensor:
+        if self.hidden_layers is not None:
+            latents = self.hidden_layers(latents)
+        elif self._final_dropout is not None:
+            latents = self._final_dropout(latents)
+        return self.linear(latents)
+
+    def loss(self, logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        return F.cross_entropy(logits, targets, weight=self.class_weight if self._use_weight else None)
+
+
+class TemperatureScaler:
+    """calibrate.py:16-112: one log-temperature fitted by Adam on the cross-entropy of ``logits / T``."""
+
+    def __init__(self, temperature: float = 1.0, fitted: bool = False) -> None:
+        self.temperature = float(temperature)
+        self.fitted = bool(fitted)
+
+    def fit(self, logits, targets, *, max_iter: int = 100, learning_rate: float = 0.01) -> "TemperatureScaler":
+        logits = np.asarray(logits, dtype=np.float32)
+        targets = np.asarray(targets, dtype=np.int64)
+        if logits.ndim != 2:
+            raise ValueError("logits must be a 2D array")
+        if logits.shape[0] != targets.shape[0]:
+            raise ValueError("logits and targets must have matching rows")
+        if targets.size == 0:
+            raise ValueError("calibration targets must be non-empty")
+        lt, tt = torch.from_numpy(logits), torch.from_numpy(targets)
+        log_t = torch.tensor(math.log(max(self.temperature, 1e-3)), dtype=lt.dtype, requires_grad=True)
+        opt = torch.optim.Adam([log_t], lr=learning_rate)
+        for _ in range(max_iter):
+            opt.zero_grad()
+            loss = F.cross_entropy(lt / torch.exp(log_t), tt)
+            if not torch.isfinite(loss):
+                break
+            loss.backward()
+            opt.step()
+        self.temperature = float(torch.exp(log_t.detach()).clamp(min=1e-3, max=1e3).item())
+        self.fitted = True
+        return self
+
+    def transform(self, logits):
+        if self.temperature <= 0:
+            raise ValueError("temperature must be positive")
+        if isinstance(logits, torch.Tensor):
+            return logits / float(self.temperature)
+        return np.asarray(logits, dtype=np.float32) / float(self.temperature)
+
+    __call__ = transform
+
+    def state_dict(self) -> Dict[str, object]:
+        return {"temperature": float(self.temperature), "fitted": bool(self.fitted)}
+
+    def load_state_dict(self, state) -> None:
+        t = float(state.get("temperature", 1.0))
+        if t <= 0:
+            raise ValueError("Loaded temperature must be positive")
+        self.temperature = t
+        self.fitted = bool(state.get("fitted", False))
+
+
+# ---------------------------------------------------------------------------
+# validation metrics (evaluate.py:88-297 semantics: binary -> positive column, multi-class -> macro OvR)
+# ---------------------------------------------------------------------------
+def _auc_binary(score: np.ndarray, y: np.ndarray) -> float:
+    pos, neg = int((y == 1).sum()), int((y == 0).sum())
+    if pos == 0 or neg == 0:
+        raise ValueError("AUROC needs both classes")
+    order = np.argsort(score, kind="mergesort")
+    s = score[order]
+    ranks = np.empty(len(s), np.float64)
+    i = 0
+    while i < len(s):  # average ranks over ties
+        j = i
+        while j + 1 < len(s) and s[j + 1] == s[i]:
+            j += 1
+        ranks[i:j + 1] = 0.5 * (i + j) + 1.0
+        i = j + 1
+    r = np.empty(len(s), np.float64)
+    r[order] = ranks
+    return float((r[y == 1].sum() - pos * (pos + 1) / 2.0) / (pos * neg))
+
+
+def compute_auroc(probabilities: np.ndarray, targets: np.ndarray) -> float:
+    p = np.asarray(probabilities, np.float64)
+    t = np.asarray(targets).astype(np.int64).reshape(-1)
+    if p.ndim == 1 or p.shape[1] == 1:
+        return _auc_binary(p.reshape(-1), t)
+    if p.shape[1] == 2:
+        return _auc_binary(p[:, 1], t)
+    vals = []
+    for c in range(p.shape[1]):
+        if (t == c).any() and (t != c).any():
+            vals.append(_auc_binary(p[:, c], (t == c).astype(np.int64)))
+    if not vals:
+        raise ValueError("AUROC undefined")
+    return float(np.mean(vals))
+
+
+def compute_brier(probabilities: np.ndarray, targets: np.ndarray) -> float:
+    p = np.asarray(probabilities, np.float64)
+    t = np.asarray(targets).astype(np.int64).reshape(-1)
+    if p.ndim == 2 and p.shape[1] == 2:
+        return float(np.mean((p[:, 1] - t) ** 2))
+    onehot = np.eye(p.shape[1])[t]
+    return float(np.mean(np.sum((p - onehot) ** 2, axis=1)))
+
+
+def compute_ece(probabilities: np.ndarray, targets: np.ndarray, n_bins: int = 10) -> float:
+    p = np.asarray(probabilities, np.float64)
+    t = np.asarray(targets).astype(np.int64).reshape(-1)
+    if p.ndim == 2 and p.shape[1] == 2:
+        conf, correct = p[:, 1], (t == 1).astype(np.float64)
+    else:
+        conf, correct = p.max(axis=1), (p.argmax(axis=1) == t).astype(np.float64)
+    edges = np.linspace(0.0, 1.0, n_bins + 1)
+    ece = 0.0
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        sel = (conf > lo) & (conf <= hi) if lo > 0 else (conf >= lo) & (conf <= hi)
+        if sel.any():
+            ece += sel.mean() * abs(correct[sel].mean() - conf[sel].mean())
+    return float(ece)
+
+
+def is_better_metrics(candidate: Dict[str, float], best: Dict[str, float]) -> bool:
+    """model.py:2637-2678: lexicographic comparison joint_objective, nll, classification_loss, brier, ece (min), auroc (max)."""
+
+    for key, mode in (("joint_objective", "min"), ("nll", "min"), ("classification_loss", "min"), ("brier", "min"),
+                      ("ece", "min"), ("auroc", "max")):
+        c, b = candidate.get(key), best.get(key)
+        c = float(c) if c is not None else float("nan")
+        b = float(b) if b is not None else float("nan")
+        cf, bf = math.isfinite(c), math.isfinite(b)
+        if not cf and not bf:
+            continue
+        if cf and not bf:
+            return True
+        if not cf and bf:
+            return False
+        if mode == "min":
+            if c < b - 1e-8:
+                return True
+            if c > b + 1e-8:
+                return False
+        else:
+            if c > b + 1e-8:
+                return True
+            if c < b - 1e-8:
+                return False
+    return False
+
+
+def derive_classification_loss_weight(elbo_scale: Optional[float], ce_scale: Optional[float]) -> float:
+    """model.py:634-664."""
+
+    if (elbo_scale is None or not math.isfinite(float(elbo_scale)) or ce_scale is None
+            or not math.isfinite(float(ce_scale)) or float(ce_scale) <= 0.0):
+        return 1.0
+    return float(np.clip(float(elbo_scale) / max(float(ce_scale), 1e-8), 0.1, 1000.0))

@@ -255,7 +255,7 @@ def test_golden_joint_finetune_step():
     class_loss = F.cross_entropy(logits, torch.from_numpy(fx["targets"]).to(eng.device),
                                  weight=torch.from_numpy(fx["clf/class_weight"]).to(eng.device))
     (class_loss * meta["cls_weight"]).backward()
-    assert abs(float(class_loss) - float(fx["out/class_loss"])) < TOL * abs(float(fx["out/class_loss"]))
+    assert abs(float(class_loss.detach()) - float(fx["out/class_loss"])) < TOL * abs(float(fx["out/class_loss"]))
     res = eng.elbo(table, 0, B, beta_scale=meta["beta_scale"], tau=meta["tau"], grad=True, noise=noise,
                    want=("latent", "reconstruction"), dlatent=latent.grad.contiguous())
     torch.cuda.synchronize()

@@ -39,7 +39,8 @@ def test_fit_encode_sample_impute_predict(behaviour):
     df, g = _frame(1200, seed=1)
     model = SUAVE(_schema(), behaviour=behaviour, latent_dim=8, n_components=3, hidden_dims=(32, 16), dropout=0.1,
                   batch_size=128, learning_rate=3e-3, random_state=0)
-    model.fit(df, y=g if behaviour == "supervised" else None, epochs=12, kl_warmup_epochs=4)
+    model.fit(df, y=g if behaviour == "supervised" else None, epochs=12, kl_warmup_epochs=4, head_epochs=4,
+              finetune_epochs=4, decoder_refine_epochs=2)
     hist = model._train_history
     assert len(hist) == 12 and len(model._warmup_val_history) == 12
     assert hist[-1]["reconstruction"] > hist[0]["reconstruction"] + 0.5  # training improves the log-likelihood
@@ -83,6 +84,65 @@ def test_fit_encode_sample_impute_predict(behaviour):
         model.predict_proba(sub, attr="age")
     with pytest.raises(ValueError):
         model.predict_proba(sub, attr="grade", L=0)
+
+
+@pytest.mark.parametrize("refine_mode", ["decoder_prior", "prior_em_decoder", "prior_em_only", "decoder_only"])
+def test_supervised_schedule_classifier_and_persistence(refine_mode, tmp_path):
+    """Head phase, joint fine-tuning, decoder refine (all four modes), classifier prediction, calibration,
+    confidence intervals, MC imputation and save/load (reference tests: test_training_schedule.py,
+    test_calibration.py, test_posterior_predictive.py:74-129, test_model_serialization.py)."""
+
+    import torch
+    from suave_amd.model import SUAVE
+
+    df, g = _frame(1500, seed=2)
+    labels = np.where(g == 1, "pos", "neg")
+    model = SUAVE(_schema(), latent_dim=8, n_components=2, hidden_dims=(32, 16), dropout=0.05, batch_size=128,
+                  learning_rate=3e-3, random_state=1, decoder_refine_mode=refine_mode)
+    model.fit(df, y=labels, warmup_epochs=8, kl_warmup_epochs=3, head_epochs=6, finetune_epochs=5, decoder_refine_epochs=3)
+    assert len(model._train_history) == 8 and 1 <= len(model._joint_history) <= 5
+    assert model._joint_val_metrics is not None and np.isfinite(model._joint_val_metrics["joint_objective"])
+    assert 0.1 <= model.classification_loss_weight <= 1000.0
+    assert len(model._refine_history) == (0 if refine_mode == "prior_em_only" else 3) or len(model._refine_history) >= 1
+    proba = model.predict_proba(df)
+    assert proba.shape == (len(df), 2) and np.allclose(proba.sum(axis=1), 1.0, atol=1e-5)
+    pred = model.predict(df)
+    assert set(np.unique(pred)) <= {"neg", "pos"}
+    assert (pred == labels).mean() > 0.7  # the label shifts age / lab / visits / grade
+    assert model._joint_val_metrics["auroc"] > 0.75
+    model.calibrate(df.iloc[:400], labels[:400])
+    assert model._is_calibrated and model._temperature_scaler.temperature > 0
+    assert np.allclose(model.predict_proba(df).sum(axis=1), 1.0, atol=1e-5)
+    with pytest.raises(ValueError):
+        model.calibrate(df.iloc[:10], labels[:5])
+    # posterior predictive statistics (test_posterior_predictive.py:74-129)
+    sub = df.iloc[:120]
+    ci = model.predict_confidence_interval(sub, "visits", L=64, return_samples=True)
+    assert ci["samples"].shape == (120, 64) and bool((ci["lower"] <= ci["upper"]).all())
+    assert torch.allclose(ci["point"], ci["samples"].mean(dim=1), atol=1e-4)  # count -> mean
+    ci_pos = model.predict_confidence_interval(sub, "lab", L=64, return_samples=True)
+    assert torch.allclose(ci_pos["point"], ci_pos["samples"].median(dim=1).values, atol=1e-5)  # pos -> median
+    assert torch.equal(model.predict(sub, attr="visits", L=64), ci["point"])  # same seed -> same draws
+    with pytest.raises(ValueError):
+        model.predict_confidence_interval(sub, "sex")
+    masked = sub.copy()
+    masked["age"] = 1e6  # the attribute is always decoded as missing: its value must not matter
+    a = model.predict_confidence_interval(sub, "age", L=32)["point"]
+    b = model.predict_confidence_interval(masked, "age", L=32)["point"]
+    assert torch.equal(a, b)
+    imp = model.impute_mc(sub, L=16)
+    assert imp.isna().sum().sum() == 0
+    obs = sub["lab"].notna()
+    assert np.allclose(imp.loc[obs, "lab"].astype(float), sub.loc[obs, "lab"].astype(float), rtol=1e-6)
+    # persistence
+    path = tmp_path / "model.pt"
+    model.save(path)
+    clone = SUAVE.load(path)
+    assert np.allclose(clone.predict_proba(df), model.predict_proba(df), atol=1e-6)
+    pd.testing.assert_frame_equal(clone.sample(200, seed=5), model.sample(200, seed=5))
+    pd.testing.assert_frame_equal(clone.sample(100, conditional=True, y=np.array(["pos", "neg"] * 50), seed=5),
+                                  model.sample(100, conditional=True, y=np.array(["pos", "neg"] * 50), seed=5))
+    assert np.allclose(clone.encode(sub), model.encode(sub), atol=1e-6)
 
 
 def test_unfitted_and_validation_errors():
