@@ -662,9 +662,15 @@ class SUAVE:
 
     # ------------------------------------------------------------------
     def impute(self, X: pd.DataFrame, *, only_missing: bool = True,
-               assignment_strategy: Optional[Literal["soft", "hard", "sample"]] = None, seed: Optional[int] = None
+               assignment_strategy: Optional[Literal["soft", "hard", "sample"]] = None, seed: Optional[int] = None,
+               _noise: Optional[Dict[str, torch.Tensor]] = None, _routing: Optional[Dict[str, torch.Tensor]] = None
                ) -> pd.DataFrame:
-        """Single-pass imputation at the posterior mean latent (model.py:3512-3692)."""
+        """Single-pass imputation at the posterior mean latent (model.py:3512-3692).
+
+        ``_noise`` injects the draws instead of generating them from ``seed`` (parity tests): ``assign_exp``
+        [B,K] Exp(1) of the relaxed Gumbel assignment, ``normal`` / ``uniform`` [B,n_cols] and ``exp``
+        [B,total classes] of the head samplers.  ``_routing`` (a dict) receives the (latent, assignments) pair
+        handed to the decoder -- what the reference's tests spy on (tests/test_impute.py:141-146)."""
 
         self._require_fitted("impute")
         missing_cols = [c for c in self.schema.feature_names if c not in X.columns]
@@ -692,12 +698,21 @@ class SUAVE:
             z = out["mean"]
         else:  # relaxed Gumbel-softmax weights, model.py:3638-3644
             t = max(float(self._inference_tau if self.behaviour == "unsupervised" else self.gumbel_temperature), 1e-6)
-            g = torch.Generator(device=eng.device)
-            g.manual_seed(seed)
-            e = torch.empty_like(probs).exponential_(generator=g)
+            if _noise is not None and _noise.get("assign_exp") is not None:
+                e = _noise["assign_exp"].to(eng.device)
+            else:
+                g = torch.Generator(device=eng.device)
+                g.manual_seed(seed)
+                e = torch.empty_like(probs).exponential_(generator=g)
             assign = torch.softmax((enc[:, :K] - torch.log(e)) / t, dim=1).contiguous()
             z = (assign.unsqueeze(-1) * mu).sum(dim=1).contiguous()
-        onum, ocodes = eng.decode_sample(z, component=comp, assignments=assign, seed=seed + 1)
+        if _routing is not None:
+            _routing["latent"] = z
+            _routing["assignments"] = assign if assign is not None else torch.nn.functional.one_hot(comp.long(), K).float()
+        nz = _noise or {}
+        onum, ocodes = eng.decode_sample(z, component=comp, assignments=assign, seed=seed + 1,
+                                         noise_normal=nz.get("normal"), noise_uniform=nz.get("uniform"),
+                                         noise_exp=nz.get("exp"))
         recon = data_utils.frame_from_packed(onum.cpu().numpy(), ocodes.cpu().numpy(), self.schema,
                                              self._norm_stats_per_col)
         return self._merge_observed(X, aligned, recon, mask, only_missing)

@@ -92,11 +92,19 @@ class NoiseTape:
 
         def multinomial(probs, num_samples, replacement=False, *, generator=None):
             # torch's single-draw path: q ~ Exp(1); argmax(probs / q)
-            assert num_samples == 1
-            q = torch.empty_like(probs)
+            if num_samples == 1:
+                q = torch.empty_like(probs)
+                tape._orig["exponential_"](q)
+                tape.multinomial_exp.append(q.detach().clone())
+                return torch.argmax(probs / q, dim=-1, keepdim=True)
+            # Categorical.sample((L,)) (model.py:3322-3323): torch inverts the CDF with float64 uniforms,
+            # which cannot be injected in binary32; the build defines the draw as L independent
+            # exponential races and the same map replaces the primitive here (like torch.poisson below)
+            assert replacement
+            q = torch.empty((num_samples,) + tuple(probs.shape), dtype=probs.dtype)
             tape._orig["exponential_"](q)
             tape.multinomial_exp.append(q.detach().clone())
-            return torch.argmax(probs / q, dim=-1, keepdim=True)
+            return torch.argmax(probs.unsqueeze(0) / q, dim=-1).T.contiguous()
 
         def poisson(rate, generator=None):
             # build-defined (uniform, normal) -> count map (torch.poisson consumes
@@ -483,6 +491,124 @@ def gen_posterior(name, kind, K, D, hidden, B, seed, L=8):
     print("wrote", name)
 
 
+def gen_predictive(name, kind, K, D, hidden, B, seed, L=6):
+    """Monte-Carlo posterior predictive of every attribute (model.py:3304-3421): ``_posterior_predictive_params``
+    (L component / latent draws per row, decoder trunk on L*B rows, ONE head) and ``_draw_predictive_samples``."""
+
+    rng = np.random.default_rng(seed)
+    cols = make_columns(kind)
+    model, om = build_reference(cols, K, D, hidden, 0.0, "supervised", seed)
+    model._encoder.eval()
+    model._decoder.eval()
+    xnum, codes, mask = make_batch(cols, B, 0.3, rng)
+    x_enc, data_t, mask_t = to_torch_batches(om, xnum, codes, mask)
+    rec = {"columns": cols_json(cols),
+           "meta": json.dumps(dict(kind=kind, K=K, D=D, hidden=list(hidden), B=B, seed=seed, L=L)),
+           "xnum": xnum, "codes": codes, "mask": mask}
+    for k_, v in ref_params(model, "supervised").items():
+        rec["param/" + k_] = v
+    for c in cols:
+        attr_data = data_t[c.type][c.name]
+        attr_mask = torch.zeros_like(mask_t[c.type][c.name])  # the attribute is decoded as missing (model.py:3300-3301)
+        with NoiseTape() as tape, torch.no_grad():
+            res = model._posterior_predictive_params(x_enc, c.name, c.type, attr_data, attr_mask, L)
+            samples = None
+            if c.type in ("real", "pos", "count"):
+                samples = model._draw_predictive_samples(c.type, res["params"], L, B, torch.device("cpu"))
+        rec[f"noise/{c.name}/comp_exp"] = tape.multinomial_exp[0].numpy()   # [L,B,K]
+        rec[f"noise/{c.name}/eps"] = tape.randn[0].numpy()                  # [L,B,D]
+        for pk, pv in res["params"].items():
+            rec[f"out/{c.name}/params/{pk}"] = pv.numpy()
+        # order of the tape: posterior draw, eps, the head's own (discarded) sample draw, then the predictive draw
+        if c.type in ("real", "pos"):
+            rec[f"noise/{c.name}/normal"] = tape.randn[2].numpy().reshape(L, B)
+        elif c.type == "count":
+            rec[f"noise/{c.name}/uniform"] = tape.poisson_u[1].numpy().reshape(L, B)
+            rec[f"noise/{c.name}/normal"] = tape.poisson_n[1].numpy().reshape(L, B)
+        if samples is not None:
+            rec[f"out/{c.name}/samples"] = samples.numpy()                   # [L,B]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print("wrote", name)
+
+
+def gen_impute(name, seed, n=48, K=3, D=5, hidden=(16, 8)):
+    """SUAVE.impute end to end (model.py:3512-3692) on a raw frame with NaNs, for the three assignment
+    strategies: the (latent, assignments) handed to Decoder.forward (what the reference's own
+    tests/test_impute.py:107-146 spies on), the injected draws, the reconstruction and the merged frame."""
+
+    import pandas as pd
+    from unittest.mock import patch
+    from suave import data as ref_data
+
+    rng = np.random.default_rng(seed)
+    raw = {
+        "r0": rng.normal(50, 12, n), "p0": rng.lognormal(1.0, 0.5, n), "n0": rng.poisson(3.0, n).astype(float),
+        "c0": rng.integers(0, 3, n).astype(float), "o0": rng.integers(0, 4, n).astype(float),
+        "r1": rng.normal(0, 1, n), "n1": (rng.poisson(2.0, n) + 1).astype(float), "c1": rng.integers(0, 5, n).astype(float),
+    }
+    for k in raw:
+        raw[k][rng.random(n) < 0.25] = np.nan
+    X = pd.DataFrame(raw)
+    spec = {"r0": {"type": "real"}, "p0": {"type": "pos"}, "n0": {"type": "count"},
+            "c0": {"type": "cat", "n_classes": 3}, "o0": {"type": "ordinal", "n_classes": 4},
+            "r1": {"type": "real"}, "n1": {"type": "count"}, "c1": {"type": "cat", "n_classes": 5}}
+    schema = Schema(spec)
+    _, stats = ref_data.standardize(X, schema)
+    cols = [orc.Column(nm, sp["type"], sp.get("n_classes"), None,
+                       {k: float(v) for k, v in stats[nm].items() if isinstance(v, (int, float, np.floating, np.integer))})
+            for nm, sp in spec.items()]
+    rec = {"schema": json.dumps(schema.to_dict()),
+           "stats": json.dumps({k: {kk: (vv if not isinstance(vv, (np.floating, np.integer)) else float(vv))
+                                    for kk, vv in v.items()} for k, v in stats.items()}),
+           "columns": cols_json(cols)}
+    for k, v in raw.items():
+        rec["raw/" + k] = v
+    for behaviour in ("supervised", "unsupervised"):
+        model, om = build_reference(cols, K, D, hidden, 0.0, behaviour, seed)
+        model._norm_stats_per_col = stats
+        model._is_fitted = True
+        model._inference_tau = 0.7
+        model.gumbel_temperature = 0.9
+        for k_, v in ref_params(model, behaviour).items():
+            rec[f"{behaviour}/param/{k_}"] = v
+        for strategy in ("hard", "soft", "sample"):
+            with NoiseTape() as tape, patch.object(model._decoder, "forward", wraps=model._decoder.forward) as spy:
+                recon = model.impute(X, only_missing=False, assignment_strategy=strategy)
+                latent_arg, assign_arg = spy.call_args[0][:2]
+            pre = f"{behaviour}/{strategy}/"
+            rec[pre + "latent"] = latent_arg.detach().numpy()
+            rec[pre + "assignments"] = assign_arg.detach().numpy()
+            if strategy == "sample":
+                rec[pre + "noise/assign_exp"] = tape.exp[0].numpy()
+            i_rn = i_mn = i_ps = 0
+            for c in cols:
+                if c.type in ("real", "pos"):
+                    rec[pre + f"noise/{c.name}/normal"] = tape.randn[i_rn].numpy()
+                    i_rn += 1
+                elif c.type in ("cat", "ordinal"):
+                    rec[pre + f"noise/{c.name}/exp"] = tape.multinomial_exp[i_mn].numpy()
+                    i_mn += 1
+                else:
+                    rec[pre + f"noise/{c.name}/uniform"] = tape.poisson_u[i_ps].numpy()
+                    rec[pre + f"noise/{c.name}/normal"] = tape.poisson_n[i_ps].numpy()
+                    i_ps += 1
+                v = recon[c.name]
+                rec[pre + f"recon/{c.name}"] = (np.asarray(v.cat.codes, np.int64) if c.type in ("cat", "ordinal")
+                                                else v.to_numpy())
+            # merged frame (only_missing=True) follows from the reconstruction: observed cells keep the input
+            with NoiseTape(), torch.no_grad():
+                torch.manual_seed(seed)
+                merged = model.impute(X, only_missing=True, assignment_strategy="hard")
+            if strategy == "hard":
+                for c in cols:
+                    v = merged[c.name]
+                    obs = ~X[c.name].isna().to_numpy()
+                    got = np.asarray(v.cat.codes if c.type in ("cat", "ordinal") else v, np.float64)
+                    rec[f"{behaviour}/merged_observed/{c.name}"] = got[obs]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print("wrote", name)
+
+
 def gen_tensorise(name, seed, n=40):
     """standardize -> _apply_training_normalization -> _prepare_training_tensors on a frame with NaNs
     (data.py:133-266, model.py:3116-3213, 2784-2922): raw columns in, encoder_inputs + stats out."""
@@ -540,6 +666,8 @@ def main():
         (gen_elbo, ("elbo_unsup_wide7", "wide7", 2, 4, (16, 8), 24, 0.3, 0.0, "unsupervised", 62), {"temperature": 0.8}),
         (gen_decode, ("decode_wide7", "wide7", 3, 6, (16, 8), 32, 63), {}),
         (gen_joint, ("joint_sup_mixed7", "mixed7", 3, 6, (16, 8), 48, 0.3, 71), {}),
+        (gen_predictive, ("predictive_mixed7", "mixed7", 3, 6, (16, 8), 24, 81), {}),
+        (gen_impute, ("impute_mixed8", 91), {}),
     ]
     for fn, args, kw in jobs:
         if want(args[0]):

@@ -200,3 +200,115 @@ def test_encode_matches_reference():
     assert rel_err(out["mean"].cpu().numpy(), fx["out/post_mean_t05"]) < TOL
     assert rel_err(out["logvar"].cpu().numpy(), fx["out/post_logvar_t05"]) < TOL
     assert rel_err(out["probs"].cpu().numpy(), fx["out/post_probs_t05"]) < TOL
+
+
+def test_golden_posterior_predictive():
+    """suave_posterior_draws + suave_decode_params + suave_decode_sample against the reference's
+    _posterior_predictive_params / _draw_predictive_samples (model.py:3304-3421), every attribute, L draws."""
+
+    import torch
+    from suave_amd.engine import PackedTable
+
+    fx = load_golden("predictive_mixed7")
+    om, P, meta = fixture_model(fx)
+    eng = _engine(om, P)
+    L, B, K, D = meta["L"], meta["B"], om.K, om.D
+    dev = eng.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    table = PackedTable(fx["xnum"], fx["codes"], fx["mask"], dev)
+    enc = eng.encode(table, 0, B)["enc_out"]
+    lg, mu, lv, _ = orc.encoder_forward(om, P, orc.dense_from_packed(om, fx["xnum"], fx["codes"], fx["mask"])[0])
+    names = [c.name for c in om.columns]
+    num_names = [c.name for c in om.columns if c.type in ("real", "pos", "count")]
+    for j, c in enumerate(om.columns):
+        e, eps = fx[f"noise/{c.name}/comp_exp"], fx[f"noise/{c.name}/eps"]
+        z, comp = eng.posterior_draws(enc, L, e=t(e), eps=t(eps))
+        k_ref, z_ref = sorc.posterior_draws(lg, mu, lv, e, eps)
+        assert np.array_equal(comp.cpu().numpy().astype(np.int64), k_ref.reshape(-1)), c.name  # bit-exact components
+        assert rel_err(z.cpu().numpy(), z_ref.reshape(L * B, D)) < TOL
+        prm = eng.decode_params(z, j, component=comp).cpu().numpy()
+        ref = {kk.split("/")[-1]: v for kk, v in fx.items() if kk.startswith(f"out/{c.name}/params/")}
+        order = {"real": ["mean", "var"], "pos": ["mean_log", "var_log", "mean"], "count": ["rate"],
+                 "cat": ["probs"], "ordinal": ["probs"]}[c.type]
+        if c.type in ("cat", "ordinal"):
+            assert rel_err(prm, ref["probs"]) < TOL, c.name
+        else:
+            for i, kk in enumerate(order):
+                assert rel_err(prm[:, i], ref[kk].reshape(-1)) < TOL, (c.name, kk)
+        if c.type in ("real", "pos", "count"):
+            nn = np.zeros((L * B, len(names)), np.float32)
+            nu = np.full((L * B, len(names)), 0.5, np.float32)
+            nn[:, j] = fx[f"noise/{c.name}/normal"].reshape(-1)
+            if c.type == "count":
+                nu[:, j] = fx[f"noise/{c.name}/uniform"].reshape(-1)
+            onum, _ = eng.decode_sample(z, component=comp, noise_normal=t(nn), noise_uniform=t(nu))
+            got = onum.cpu().numpy()[:, num_names.index(c.name)].reshape(L, B)
+            if c.type == "count":
+                assert np.array_equal(np.rint(got), np.rint(fx[f"out/{c.name}/samples"])), c.name
+            else:
+                assert rel_err(got, fx[f"out/{c.name}/samples"]) < TOL, c.name
+
+
+@pytest.mark.parametrize("behaviour", ["supervised", "unsupervised"])
+@pytest.mark.parametrize("strategy", ["hard", "soft", "sample"])
+def test_golden_impute_end_to_end(behaviour, strategy):
+    """SUAVE.impute on a raw frame with NaNs against the reference's own impute (model.py:3512-3692): the
+    (latent, assignments) handed to the decoder (tests/test_impute.py:107-146), the reconstruction under
+    injected draws (discrete cells bit-exact) and the preserved observed cells."""
+
+    import json
+
+    import pandas as pd
+    import torch
+    from suave_amd.engine import Engine
+    from suave_amd.model import SUAVE
+    from suave_amd.plan import ModelLayout
+    from suave_amd.types import Schema
+    from tests.helpers import columns_from_json
+
+    fx = load_golden("impute_mixed8")
+    cols = columns_from_json(fx["columns"])
+    schema = Schema(json.loads(str(fx["schema"])))
+    stats = json.loads(str(fx["stats"]))
+    P = {k[len(behaviour) + 7:]: v for k, v in fx.items() if k.startswith(behaviour + "/param/")}
+    K, D, hidden = 3, 5, (16, 8)
+    m = SUAVE(schema, behaviour=behaviour, latent_dim=D, n_components=K, hidden_dims=hidden, dropout=0.0,
+              gumbel_temperature=0.9)
+    m._norm_stats_per_col = stats
+    m._layout = ModelLayout(schema, K, D, hidden, 0.0, behaviour, stats)
+    m._engine = Engine(m._layout, "cuda:0")
+    m._engine.load_state(P)
+    m._inference_tau = 0.7
+    m._is_fitted = True
+    X = pd.DataFrame({k[4:]: v for k, v in fx.items() if k.startswith("raw/")})
+    n = len(X)
+    pre = f"{behaviour}/{strategy}/"
+    om = orc.OracleModel(cols, n_components=K, latent_dim=D, hidden=hidden, behaviour=behaviour)
+    per_col = {c.name: {k.split("/")[-1]: v for k, v in fx.items() if k.startswith(pre + f"noise/{c.name}/")} for c in cols}
+    nn, nu, ne = _pack_noise(om, m._layout, per_col, n)
+    dev = m._engine.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    noise = {"normal": t(nn), "uniform": t(nu), "exp": t(ne)}
+    if strategy == "sample":
+        noise["assign_exp"] = t(fx[pre + "noise/assign_exp"])
+    routing = {}
+    recon = m.impute(X, only_missing=False, assignment_strategy=strategy, _noise=noise, _routing=routing)
+    assert rel_err(routing["latent"].cpu().numpy(), fx[pre + "latent"]) < TOL
+    assert rel_err(routing["assignments"].cpu().numpy(), fx[pre + "assignments"]) < TOL
+    for c in cols:
+        ref = fx[pre + f"recon/{c.name}"]
+        if c.type in ("real", "pos"):
+            assert rel_err(recon[c.name].to_numpy(), ref) < TOL, c.name
+        elif c.type == "count":
+            assert np.array_equal(recon[c.name].to_numpy().astype(np.int64), ref.astype(np.int64)), c.name
+        else:
+            assert np.array_equal(np.asarray(recon[c.name].cat.codes, np.int64), ref), c.name
+    merged = m.impute(X, only_missing=True, assignment_strategy=strategy, _noise=noise)
+    assert not merged.isna().any().any()
+    for c in cols:
+        obs = ~X[c.name].isna().to_numpy()
+        v = merged[c.name]
+        got = np.asarray(v.cat.codes if c.type in ("cat", "ordinal") else v, np.float64)[obs]
+        if strategy == "hard":
+            assert np.allclose(got, fx[f"{behaviour}/merged_observed/{c.name}"], rtol=1e-6), c.name
+        assert np.allclose(got, X[c.name].to_numpy()[obs], rtol=1e-6), c.name

@@ -1,0 +1,157 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full single-GPU size (config #2: 1M rows x 64
+mixed columns, K=10, latent 32), where the numpy oracle would take minutes: chunking invariance of the per-row
+ELBO terms, linearity of the gradient in the rows, determinism, row-sharding invariance of generation, value
+ranges of the sampled cells, and empty inputs."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROWS = 1_000_000
+
+
+@pytest.fixture(scope="module")
+def s64():
+    import torch
+    from bench import HIDDEN, K_COMP, LATENT, s64_schema, synth_table_device
+    from suave_amd.engine import Engine, PackedTable
+    from suave_amd.plan import ModelLayout
+    from suave_amd.types import Schema
+
+    spec, stats = s64_schema()
+    layout = ModelLayout(Schema(spec), K_COMP, LATENT, HIDDEN, 0.1, "supervised", stats)
+    eng = Engine(layout, "cuda:0")
+    P = layout.init_params(seed=0)
+    rng = np.random.default_rng(5)
+    for k in P:  # O(1) head weights and a non-trivial prior so that every term is exercised
+        if ".heads." in k or k.startswith("prior."):
+            P[k] = (0.3 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    eng.load_state(P)
+    xnum, codes, mask = synth_table_device(layout, ROWS, eng.device, seed=20201021)
+    table = PackedTable.__new__(PackedTable)
+    table.xnum, table.codes, table.mask = xnum, codes, mask
+    table.n_rows, table.ld_num, table.ld_disc, table.ld_mask = ROWS, xnum.shape[1], codes.shape[1], mask.shape[1]
+    return eng, table, layout
+
+
+def _terms(eng, table, chunk, training):
+    import torch
+
+    outs = {k: [] for k in ("reconstruction", "categorical_kl", "gaussian_kl", "component")}
+    for s0 in range(0, ROWS, chunk):
+        nb = min(chunk, ROWS - s0)
+        o = eng.elbo(table, s0, nb, beta_scale=1.0, tau=1.0, grad=False, training=training, seed=77, step=3,
+                     want=tuple(outs))
+        for k in outs:
+            outs[k].append(o[k].clone())
+    return {k: torch.cat(v) for k, v in outs.items()}
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_full_table_elbo_terms_do_not_depend_on_the_batching(s64, training):
+    """Rows are independent terms (model.py:1617) and the in-kernel noise / dropout is keyed by the table row, so
+    the per-row ELBO terms of all 1M rows are the same whether the table is walked in 65 536-row batches or in
+    ragged 40 000-row batches (last batch of 1M % 40 000 = 0 rows -> use 48 000: last batch 40 000)."""
+
+    import torch
+
+    eng, table, _ = s64
+    a = _terms(eng, table, 65536, training)
+    b = _terms(eng, table, 48000, training)
+    assert torch.equal(a["component"], b["component"])  # bit-exact assignments
+    for k in ("reconstruction", "categorical_kl", "gaussian_kl"):
+        assert bool(torch.isfinite(a[k]).all()), k
+        err = float((a[k] - b[k]).abs().max() / a[k].abs().max().clamp_min(1e-6))
+        assert err < 1e-6, (k, err)  # tolerance 1e-6 relative; observed 0 (k-ordered fp32 FMA chains per row)
+    # sanity of the values themselves: KL terms are non-negative, mean reconstruction is a finite negative number
+    assert float(a["categorical_kl"].min()) > -1e-5 and float(a["gaussian_kl"].min()) > -1e-5
+    assert float(a["reconstruction"].double().mean()) < 0.0
+
+
+def test_gradient_is_linear_in_the_rows_and_deterministic(s64):
+    """loss = -mean_b(elbo_b): the gradient of a 65 536-row batch equals the sum of the gradients of its two
+    halves computed with global_rows = 65 536 (this is exactly what the data-parallel all-reduce relies on), to
+    1e-5 of each tensor's largest entry; two runs of the same batch give bit-identical gradients."""
+
+    import torch
+
+    eng, table, layout = s64
+    B = 65536
+    idx = torch.randperm(ROWS, device=eng.device, generator=torch.Generator(device=eng.device).manual_seed(1),
+                         dtype=torch.int64)[:B].to(torch.int32)
+    kw = dict(beta_scale=0.8, tau=1.0, grad=True, global_rows=B, seed=9, step=2)
+    eng.elbo(table, 0, B, row_index=idx, **kw)
+    g_full = eng.grads.clone()
+    eng.elbo(table, 0, B, row_index=idx, **kw)
+    assert torch.equal(g_full, eng.grads)
+    eng.elbo(table, 0, B // 2, row_index=idx[: B // 2].contiguous(), **kw)
+    g_half = eng.grads.clone()
+    eng.elbo(table, 0, B - B // 2, row_index=idx[B // 2:].contiguous(), **kw)
+    g_sum = g_half + eng.grads
+    assert bool(torch.isfinite(g_full).all())
+    for name, (b, e) in layout.group_ranges.items():
+        ref = g_full[b:e]
+        err = float((g_sum[b:e] - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
+        assert err < 1e-5, (name, err)
+
+
+def test_generation_is_invariant_to_row_sharding_and_in_range(s64):
+    """sample(): 1M rows decoded in one shard layout equal the same rows decoded in another (counter = global
+    row index, no collective); codes lie in [0, C), counts are non-negative integers, numerics finite."""
+
+    import torch
+    from oracle import sampling_oracle as sorc
+
+    eng, _, layout = s64
+    P = eng.state()
+    cdf = torch.from_numpy(sorc.prior_cdf(P["prior.logits"])).to(eng.device)
+
+    def run(chunk):
+        num, code, comp = [], [], []
+        for s0 in range(0, ROWS, chunk):
+            nb = min(chunk, ROWS - s0)
+            z, k = eng.prior_latents(nb, cdf, seed=21, row_offset=s0)
+            onum, ocodes = eng.decode_sample(z, component=k, seed=22, row_offset=s0)
+            num.append(onum.clone()); code.append(ocodes.clone()); comp.append(k.clone())
+        return torch.cat(num), torch.cat(code), torch.cat(comp)
+
+    n1, c1, k1 = run(1 << 18)
+    n2, c2, k2 = run(300_000)
+    assert torch.equal(k1, k2) and torch.equal(c1, c2) and torch.equal(n1, n2)
+    assert bool(torch.isfinite(n1).all())
+    i_num = i_disc = 0
+    for name in layout.schema.feature_names:
+        sp = layout.schema[name]
+        if sp.type in ("cat", "ordinal"):
+            col = c1[:, i_disc]
+            assert int(col.min()) >= 0 and int(col.max()) < int(sp.n_classes), name
+            assert int(torch.unique(col).numel()) == int(sp.n_classes), name  # every level is reachable in 1M draws
+            i_disc += 1
+        else:
+            col = n1[:, i_num]
+            if sp.type == "count":
+                assert float(col.min()) >= 0.0 and bool((col == col.round()).all()), name
+            if sp.type == "pos":
+                assert float(col.min()) > -1.0, name  # exp(.) - 1
+            i_num += 1
+    # the prior's component frequencies over 1M draws match softmax(prior_logits) (inverse-CDF draw)
+    p = np.exp(P["prior.logits"] - P["prior.logits"].max()); p /= p.sum()
+    freq = torch.bincount(k1.long(), minlength=len(p)).cpu().numpy() / ROWS
+    assert np.abs(freq - p).max() < 5e-3
+
+
+def test_empty_inputs_are_accepted(s64):
+    """Zero-row batches: every entry point returns success and touches nothing (reference: batch == 0 guards,
+    model.py:3361-3362, 3398-3399, 4238)."""
+
+    import torch
+
+    eng, table, layout = s64
+    g0 = eng.grads.clone()
+    eng.elbo(table, 0, 0, beta_scale=1.0, grad=True, global_rows=1)
+    assert torch.equal(g0, eng.grads)
+    assert eng.encode(table, 0, 0)["enc_out"].shape[0] == 0
+    z = torch.empty((0, layout.latent_dim), device=eng.device)
+    onum, ocodes = eng.decode_sample(z, component=torch.empty((0,), dtype=torch.int32, device=eng.device))
+    assert onum.shape[0] == 0 and ocodes.shape[0] == 0

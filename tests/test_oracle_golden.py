@@ -129,3 +129,83 @@ def test_decode_matches_reference(name):
             assert rel_err(got, ref) < TOL, c.name
         else:
             assert np.array_equal(got.astype(np.int64), ref.astype(np.int64)), c.name
+
+
+def _dummy_noise(om, n):
+    nz = {}
+    for c in om.columns:
+        if c.type in ("real", "pos"):
+            nz[c.name] = {"normal": np.zeros(n, np.float32)}
+        elif c.type == "count":
+            nz[c.name] = {"normal": np.zeros(n, np.float32), "uniform": np.full(n, 0.5, np.float32)}
+        else:
+            nz[c.name] = {"exp": np.ones((n, c.n_classes), np.float32)}
+    return nz
+
+
+def test_posterior_predictive_matches_reference():
+    """_posterior_draws / _posterior_predictive_params / _draw_predictive_samples (model.py:3304-3421)."""
+
+    fx = load_golden("predictive_mixed7")
+    om, P, meta = fixture_model(fx)
+    L, B, K, D = meta["L"], meta["B"], om.K, om.D
+    x_enc, _, _ = orc.dense_from_packed(om, fx["xnum"], fx["codes"], fx["mask"])
+    lg, mu, lv, _ = orc.encoder_forward(om, P, x_enc)
+    for c in om.columns:
+        k, z = sorc.posterior_draws(lg, mu, lv, fx[f"noise/{c.name}/comp_exp"], fx[f"noise/{c.name}/eps"])
+        y, _ = orc.decoder_trunk_forward(om, P, z.reshape(L * B, D))
+        s = np.eye(K, dtype=np.float32)[k.reshape(-1)]
+        nz = _dummy_noise(om, L * B)
+        for key in ("normal", "uniform"):
+            if f"noise/{c.name}/{key}" in fx:
+                nz[c.name][key] = fx[f"noise/{c.name}/{key}"].reshape(-1)
+        out = sorc.sample_heads(om, P, y, s, nz)
+        prm = out["_params"][c.name]
+        ref = {kk.split("/")[-1]: v for kk, v in fx.items() if kk.startswith(f"out/{c.name}/params/")}
+        if c.type == "cat":
+            lgt = prm["logits"]
+            pr = np.exp(lgt - lgt.max(-1, keepdims=True))
+            assert rel_err(pr / pr.sum(-1, keepdims=True), ref["probs"]) < TOL, c.name
+        else:
+            for kk, v in prm.items():
+                assert rel_err(v.reshape(ref[kk].shape), ref[kk]) < TOL, (c.name, kk)
+        if c.type in ("real", "pos"):
+            assert rel_err(out[c.name].reshape(L, B), fx[f"out/{c.name}/samples"]) < TOL, c.name
+        elif c.type == "count":  # bit-exact: same (rate, u, n) -> count map
+            assert np.array_equal(out[c.name].reshape(L, B), np.rint(fx[f"out/{c.name}/samples"]).astype(np.int64)), c.name
+
+
+@pytest.mark.parametrize("behaviour", ["supervised", "unsupervised"])
+def test_impute_routing_matches_reference(behaviour):
+    """SUAVE.impute's (latent, assignments) per strategy (model.py:3618-3644; tests/test_impute.py:107-146)."""
+
+    import json
+
+    from tests.helpers import columns_from_json
+
+    fx = load_golden("impute_mixed8")
+    cols = columns_from_json(fx["columns"])
+    P = {k[len(behaviour) + 7:]: v for k, v in fx.items() if k.startswith(behaviour + "/param/")}
+    K, D = 3, 5
+    om = orc.OracleModel(cols, n_components=K, latent_dim=D, hidden=(16, 8), behaviour=behaviour)
+    import pandas as pd
+
+    from suave_amd import data as host_data
+    from suave_amd.types import Schema
+
+    X = pd.DataFrame({k[4:]: v for k, v in fx.items() if k.startswith("raw/")})
+    schema = Schema(json.loads(str(fx["schema"])))
+    xnum, codes, mask = host_data.pack_frame(X.loc[:, list(schema.feature_names)], schema, json.loads(str(fx["stats"])))
+    x_enc, _, _ = orc.dense_from_packed(om, xnum, codes, mask)
+    lg, mu, lv, _ = orc.encoder_forward(om, P, x_enc)
+    pm, _, pp = orc.mixture_posterior_statistics(lg, mu, lv, temperature=0.7 if behaviour == "unsupervised" else None)
+    kh = pp.argmax(-1)
+    assert rel_err(mu[np.arange(len(kh)), kh], fx[f"{behaviour}/hard/latent"]) < TOL
+    assert np.array_equal(np.eye(K, dtype=np.float32)[kh], fx[f"{behaviour}/hard/assignments"])
+    assert rel_err(pm, fx[f"{behaviour}/soft/latent"]) < TOL
+    assert rel_err(pp, fx[f"{behaviour}/soft/assignments"]) < TOL
+    tau = 0.7 if behaviour == "unsupervised" else 0.9
+    e = fx[f"{behaviour}/sample/noise/assign_exp"]
+    w = orc.softmax((lg - np.log(e)) / np.float32(tau))
+    assert rel_err(w, fx[f"{behaviour}/sample/assignments"]) < TOL
+    assert rel_err((w[:, :, None] * mu).sum(1), fx[f"{behaviour}/sample/latent"]) < TOL
