@@ -281,7 +281,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=["s64", "w1024"], default="s64",
                     help="s64 = BASELINE config #2/#3 (headline); w1024 = config #4 (wide schema, latent 128)")
-    ap.add_argument("--batch", type=int, default=0, help="rows per GPU per step (default 65536 for s64, 8192 for w1024)")
+    ap.add_argument("--batch", type=int, default=0, help="rows per GPU per step (default 65536 for s64, 32768 for w1024)")
     ap.add_argument("--rows", type=int, default=0, help="table rows per GPU (default 1M at N=1, 2M at N>1)")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -315,7 +315,7 @@ def main():
     spec, stats = w1024_schema() if wide else s64_schema()
     latent, hidden = (128, (384, 256)) if wide else (LATENT, HIDDEN)
     if not args.batch:
-        args.batch = 8192 if wide else 65536
+        args.batch = 32768 if wide else 65536
     if wide and not args.rows:
         args.rows = 131072
     layout = ModelLayout(Schema(spec), K_COMP, latent, hidden, args.dropout, "supervised", stats)

@@ -62,3 +62,7 @@ run("enc L1 dW", 256, 205, B, 1, 1, EPI_SLAB, splits=64)
 run("enc L2 dW", 128, 256, B, 1, 1, EPI_SLAB, splits=128)
 run("long-K ff", 8192, 256, 4096, 0, 0, EPI_BIAS)
 run("long-K ft", 8192, 256, 4096, 0, 1, EPI_BIAS)
+for sp in (32, 64, 128, 256):
+    run("enc L1 dW sweep", 256, 205, B, 1, 1, EPI_SLAB, splits=sp)
+for sp in (64, 128, 256, 512):
+    run("enc L2 dW sweep", 128, 256, B, 1, 1, EPI_SLAB, splits=sp)

@@ -1143,13 +1143,14 @@ extern "C" int suave_decode_sample(const suave_plan* p, const float* params, con
                                    int64_t row_offset, void* workspace, size_t workspace_bytes, void* stream,
                                    float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc,
                                    float* y_full_out) {
-  SUAVE_REQUIRE(p && params && z, "decode_sample: null argument");
-  SUAVE_REQUIRE(s_dense != nullptr || component != nullptr, "decode_sample: need dense assignments or component indices");
+  SUAVE_REQUIRE(p && params, "decode_sample: null plan/params");
   const suave_model_t& m = p->model;
   SUAVE_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "decode_sample: row count out of range");
+  if (n == 0) return 0;  // empty request: nothing to read or write, buffers may be null
+  SUAVE_REQUIRE(z != nullptr, "decode_sample: z is null");
+  SUAVE_REQUIRE(s_dense != nullptr || component != nullptr, "decode_sample: need dense assignments or component indices");
   SUAVE_REQUIRE((m.n_num == 0 || (out_num && ld_num >= m.n_num)) && (m.n_disc == 0 || (out_codes && ld_disc >= m.n_disc)),
                 "decode_sample: output buffers missing or too narrow");
-  if (n == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   Workspace w;
   carve(p, n, workspace, &w);
@@ -1213,11 +1214,12 @@ extern "C" int suave_head_params_width(const suave_plan* p, int32_t col_index, i
 extern "C" int suave_decode_params(const suave_plan* p, const float* params, const float* z, const float* s_dense,
                                    const int32_t* component, int64_t n, int32_t col_index, void* workspace,
                                    size_t workspace_bytes, void* stream, float* out_params) {
-  SUAVE_REQUIRE(p && params && z && out_params, "decode_params: null argument");
-  SUAVE_REQUIRE(s_dense != nullptr || component != nullptr, "decode_params: need dense assignments or component indices");
+  SUAVE_REQUIRE(p && params, "decode_params: null plan/params");
   SUAVE_REQUIRE(col_index >= 0 && col_index < p->model.n_cols, "decode_params: column out of range");
   SUAVE_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "decode_params: row count out of range");
-  if (n == 0) return 0;
+  if (n == 0) return 0;  // empty request: buffers may be null
+  SUAVE_REQUIRE(z && out_params, "decode_params: null argument");
+  SUAVE_REQUIRE(s_dense != nullptr || component != nullptr, "decode_params: need dense assignments or component indices");
   const suave_model_t& m = p->model;
   hipStream_t st = static_cast<hipStream_t>(stream);
   Workspace w;

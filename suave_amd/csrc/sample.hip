@@ -514,8 +514,9 @@ using namespace suave;
 extern "C" int suave_prior_latents(const suave_plan* p, const float* params, const float* cdf, const float* u,
                                    const float* eps, uint64_t seed, int64_t row_offset, int64_t n, void* stream,
                                    float* z, int32_t* component) {
-  SUAVE_REQUIRE(p && params && cdf && z && component, "prior_latents: null argument");
-  if (n <= 0) return 0;
+  SUAVE_REQUIRE(p && params, "prior_latents: null plan/params");
+  if (n <= 0) return 0;  // empty request: nothing to read or write, buffers may be null
+  SUAVE_REQUIRE(cdf && z && component, "prior_latents: null argument");
   PriorArgs a{};
   a.params = params;
   a.prior_mu_off = p->model.prior_mu_off; a.prior_logvar_off = p->model.prior_logvar_off;
@@ -533,9 +534,10 @@ extern "C" int suave_conditional_latents(const suave_plan* p, const int64_t* cla
                                          const float* train_logvar, const float* u_row, const float* e_comp,
                                          const float* eps, uint64_t seed, int64_t row_offset, int64_t n, void* stream,
                                          float* z, int32_t* component) {
-  SUAVE_REQUIRE(p && class_offsets && class_rows && labels && train_probs && train_mu && train_logvar && z && component,
+  SUAVE_REQUIRE(p, "conditional_latents: null plan");
+  if (n <= 0) return 0;  // empty request: buffers may be null
+  SUAVE_REQUIRE(class_offsets && class_rows && labels && train_probs && train_mu && train_logvar && z && component,
                 "conditional_latents: null argument");
-  if (n <= 0) return 0;
   CondArgs a{};
   a.class_offsets = class_offsets; a.class_rows = class_rows; a.labels = labels; a.train_probs = train_probs;
   a.train_mu = train_mu; a.train_logvar = train_logvar; a.u_row = u_row; a.e_comp = e_comp; a.eps = eps;
@@ -550,10 +552,11 @@ extern "C" int suave_conditional_latents(const suave_plan* p, const int64_t* cla
 extern "C" int suave_posterior_draws(const suave_plan* p, const float* enc_out, int64_t n_rows, int32_t n_draws,
                                      const float* e, const float* eps, uint64_t seed, int64_t row_offset, void* stream,
                                      float* z, int32_t* component) {
-  SUAVE_REQUIRE(p && enc_out && z && component, "posterior_draws: null argument");
+  SUAVE_REQUIRE(p, "posterior_draws: null plan");
   SUAVE_REQUIRE(n_draws >= 1, "posterior_draws: L must be a positive integer");  // model.py:3313-3314
   SUAVE_REQUIRE(n_rows >= 0 && n_rows * (int64_t)n_draws < (int64_t(1) << 31), "posterior_draws: too many rows");
-  if (n_rows == 0) return 0;
+  if (n_rows == 0) return 0;  // empty request: buffers may be null
+  SUAVE_REQUIRE(enc_out && z && component, "posterior_draws: null argument");
   PostDrawArgs a{};
   a.enc_out = enc_out; a.e = e; a.eps = eps; a.seed = seed; a.row_offset = row_offset; a.B = (int)n_rows; a.L = n_draws;
   a.K = p->model.n_components; a.D = p->model.latent_dim; a.z = z; a.comp = component;

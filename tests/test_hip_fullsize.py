@@ -155,3 +155,10 @@ def test_empty_inputs_are_accepted(s64):
     z = torch.empty((0, layout.latent_dim), device=eng.device)
     onum, ocodes = eng.decode_sample(z, component=torch.empty((0,), dtype=torch.int32, device=eng.device))
     assert onum.shape[0] == 0 and ocodes.shape[0] == 0
+    K, D = layout.n_components, layout.latent_dim
+    z0, k0 = eng.posterior_draws(torch.empty((0, K + 2 * K * D), device=eng.device), 4)
+    assert z0.shape[0] == 0 and k0.shape[0] == 0
+    from suave_amd.lib import SuaveHipError
+    with pytest.raises(SuaveHipError, match="positive integer"):  # model.py:3313-3314
+        eng.posterior_draws(torch.empty((0, K + 2 * K * D), device=eng.device), 0)
+    assert eng.decode_params(z, 0, component=torch.empty((0,), dtype=torch.int32, device=eng.device)).shape[0] == 0
