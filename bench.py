@@ -117,7 +117,10 @@ def synth_table_device(layout, n_rows, device, seed):
 def gemm_flops_per_row(layout):
     """Algorithmic FLOPs of the dense layers, forward + backward (2*MAC, x3): SURVEY.md §8d."""
 
-    I, Y, K, D = layout.enc_in, layout.total_y, layout.n_components, layout.latent_dim
+    # first layer, sparse-aware (SURVEY.md §8d): the dense input columns plus ONE row of W1 per embedded
+    # (wide categorical) column -- the one-hot blocks themselves are never multiplied
+    n_embed = sum(1 for c in layout.cols if c.enc_embed >= 0)
+    I, Y, K, D = layout.enc_in + n_embed, layout.total_y, layout.n_components, layout.latent_dim
     mac = 0
     prev = I
     for h in layout.hidden:

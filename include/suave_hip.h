@@ -72,6 +72,11 @@ typedef struct suave_col_t {
   int32_t w2_off;    /* flat-parameter offset: var_layer (real,pos) / mean_layer (ordinal); -1 otherwise */
   float scale;       /* std (real) / std_log (pos); 1 otherwise */
   float shift;       /* mean (real) / mean_log (pos) / offset (count); 0 otherwise */
+  int32_t enc_embed; /* -1, or (wide categorical column, n_hidden > 0) the flat-parameter offset of the column's
+                      * encoder embedding block [n_classes, ld] (ld = enc[0].n_out rounded up to 4): the n_classes
+                      * columns of encoder.backbone.0.weight that multiply the column's one-hot (model.py:2866-2870),
+                      * stored transposed.  Such a column has no value entries in the dense encoder input (enc_off = -1):
+                      * the first layer adds row `code` of the block instead of multiplying a one-hot. */
 } suave_col_t;
 
 /* One dense layer: weight [n_out, ld] row-major at w_off, bias [n_out] at b_off. */
@@ -87,7 +92,8 @@ typedef struct suave_model_t {
   int32_t n_components; /* K */
   int32_t latent_dim;   /* D */
   int32_t n_hidden;     /* number of hidden layers in encoder and decoder */
-  int32_t enc_in;       /* I: encoder input width */
+  int32_t enc_in;       /* width of the dense encoder input: I of the reference minus the one-hot blocks of the
+                         * columns with enc_embed >= 0 */
   int32_t total_y;      /* Y */
   int32_t behaviour;    /* 0 supervised (trainable prior tensors), 1 unsupervised (PriorMean) */
   int32_t n_params;     /* length of the flat parameter buffer */

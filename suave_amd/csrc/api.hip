@@ -82,6 +82,7 @@ struct Workspace {
   int32_t *perm, *lrank, *blk_cnt, *blk_base, *chunk_comp, *chunk_begin;
   int n_blocks, n_chunks_max;
   float* wideL;  // [rows, ldL] logits / logit gradients of the wide categorical columns
+  int16_t* ecodes;  // [n_embed, rows] codes of the embedded columns (first encoder layer)
   float* slab;
   double* sums_slab;
   size_t slab_floats;
@@ -164,6 +165,7 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
   w->recon_part = c.take<float>((nch + 1) * R);
   w->ds_part = c.take<float>((nch + 1) * R * p->ldK);
   w->wideL = c.take<float>(any_wide ? R * p->ldL : 4);
+  w->ecodes = c.take<int16_t>(std::max<size_t>(p->embed_host.size() * R, 8));
   w->catkl = c.take<float>(R);
   w->gausskl = c.take<float>(R);
   w->recon = c.take<float>(R);
@@ -373,6 +375,55 @@ __global__ void k_sum_chunks(const float* part, int n_chunks, int n_rows, float*
 }
 
 
+// Encoder hidden layers (encoder.py:46-53, :63).  With embedded columns the first layer is
+//   relu/dropout(x_dense @ W1_dense^T + b + sum_j E_j[code_j])   (embed.hip)
+int encoder_trunk_forward(const suave_plan* p, const float* params, const suave_batch_t* batch, const suave_noise_t* nz,
+                          float drop_p, const Workspace& w, bool want_ecodes, const float** act_out, int* ld_out,
+                          hipStream_t s) {
+  const suave_model_t& m = p->model;
+  const float* act = w.x;
+  int ld_act = p->ldI;
+  for (int i = 0; i < m.n_hidden; ++i) {
+    const bool embed = i == 0 && !p->embed_host.empty();
+    if (embed) {
+      EmbedFwdArgs e{};
+      e.cols = p->embed_dev; e.n_embed = (int)p->embed_host.size(); e.n_disc = m.n_disc; e.batch = *batch;
+      e.n_rows = batch->n_rows; e.params = params; e.ld = p->ldH[0]; e.pre = w.he[0];
+      e.ecodes = want_ecodes ? w.ecodes : nullptr;
+      if (int rc = launch_embed_fwd(e, s)) return rc;
+    }
+    GemmArgs g = gemm_base();
+    const suave_layer_t& l = m.enc[i];
+    g.A = act; g.B = params + l.w_off; g.C = w.he[i]; g.bias = params + l.b_off;
+    g.M = batch->n_rows; g.N = l.n_out; g.K = l.n_in;
+    g.lda = ld_act; g.ldb = l.ld; g.ldc = p->ldH[i];
+    g.epi = kEpiReluDrop;
+    g.H = embed ? w.he[0] : nullptr;
+    g.drop_p = drop_p;
+    g.keep = nz ? nz->enc_keep[i] : nullptr;
+    g.row_ids = batch->row_index;
+    g.row_begin = batch->row_begin;
+    g.seed = nz ? nz->seed : 0;
+    g.step = nz ? nz->step : 0;
+    g.stream_id = kStreamEncDrop + i;
+    if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
+    act = w.he[i];
+    ld_act = p->ldH[i];
+  }
+  *act_out = act;
+  *ld_out = ld_act;
+  return 0;
+}
+
+int encoder_embed_backward(const suave_plan* p, const Workspace& w, int rows, float* grads, hipStream_t s) {
+  if (p->embed_host.empty()) return 0;
+  EmbedBwdArgs e{};
+  e.cols = p->embed_dev; e.n_embed = (int)p->embed_host.size(); e.n_rows = rows; e.ecodes = w.ecodes;
+  e.dpre = w.dhe[0]; e.ld = p->ldH[0]; e.grads = grads; e.n_classes_total = p->embed_classes_total;
+  return launch_embed_bwd(e, s);
+}
+
+
 // Unsupervised (expectation-form) ELBO: SUAVE._forward_elbo_batch with behaviour="unsupervised"
 // (model.py:1576-1580, :1619-1654).  The decoder runs on B*K virtual rows (row v = b*K + k uses the
 // latent of component k and the one-hot assignment k); tau <= 0 means "temperature is None".
@@ -408,13 +459,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
   if (int rc = launch_expand(p, *batch, w.x, w.cells, s)) return rc;
   const float* act = w.x;
   int ld_act = p->ldI;
-  for (int i = 0; i < nh; ++i) {
-    if (int rc = fwd_layer(p, params, m.enc[i], act, ld_act, w.he[i], p->ldH[i], B, true, drop_p, nz->enc_keep[i], batch,
-                           nz, kStreamEncDrop + i, 1, s))
-      return rc;
-    act = w.he[i];
-    ld_act = p->ldH[i];
-  }
+  if (int rc = encoder_trunk_forward(p, params, batch, nz, drop_p, w, grad, &act, &ld_act, s)) return rc;
   if (int rc = fwd_layer(p, params, m.enc_head, act, ld_act, w.encout, p->ldE, B, false, 0.f, nullptr, batch, nz, 0, 1, s))
     return rc;
   float* wflat = w.gkl_mu;  // [V]
@@ -520,6 +565,8 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
       lddcur = p->ldH[i];
       lcur = &m.enc[i];
     }
+    if (nh > 0)
+      if (int rc = encoder_embed_backward(p, w, B, grads, s)) return rc;
     // PriorMean gradients: column sums of prior_terms -> linear.weight[d,k] and linear.bias[d]
     {
       const int ncol = K * D + D;
@@ -589,13 +636,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   if (int rc = launch_expand(p, *batch, w.x, w.cells, s)) return rc;
   const float* act = w.x;
   int ld_act = p->ldI;
-  for (int i = 0; i < nh; ++i) {
-    if (int rc = fwd_layer(p, params, m.enc[i], act, ld_act, w.he[i], p->ldH[i], B, true, drop_p, nz->enc_keep[i], batch,
-                           nz, kStreamEncDrop + i, 1, s))
-      return rc;
-    act = w.he[i];
-    ld_act = p->ldH[i];
-  }
+  if (int rc = encoder_trunk_forward(p, params, batch, nz, drop_p, w, grad, &act, &ld_act, s)) return rc;
   // ---- encoder head, selected component only ----
   // Only the logits and the selected component's mu / logvar enter the supervised loss (model.py:1587-1598,
   // losses.py:60-84), so the head is: logits GEMM -> assignment -> stable sort of the rows by component ->
@@ -773,6 +814,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
       } else {
         if (int rc = bwd_weight(p, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, B, w.slab, &slab_off, &red, &max_elems, s))
           return rc;
+        if (int rc = encoder_embed_backward(p, w, B, grads, s)) return rc;
       }
     }
     // ---- prior gradients: (prior_terms^T * [onehot(k) | 1]) via the split GEMM ----
@@ -1027,12 +1069,23 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
   for (int c = 0; c < m.n_cols; ++c) {
     const suave_col_t& col = cols[c];
     const int width = col.type >= SUAVE_TYPE_CAT ? col.n_classes : 1;
-    if (col.enc_off < 0 || col.enc_off + width > m.enc_in || col.enc_mask < 0 || col.enc_mask >= m.enc_in)
-      return fail("plan_create: encoder input offsets out of range");
+    if (col.enc_mask < 0 || col.enc_mask >= m.enc_in) return fail("plan_create: encoder mask offset out of range");
+    enc_src[col.enc_mask] = (int32_t)((1u << 29) | (uint32_t)c);
+    if (col.enc_embed >= 0) {  // embedded column: no entries in the dense input (include/suave_hip.h)
+      const int ldh = m.n_hidden > 0 ? round_up(m.enc[0].n_out, 4) : 0;
+      if (!col_is_wide(col) || m.n_hidden == 0 || col.enc_embed % 4 ||
+          (int64_t)col.enc_embed + (int64_t)col.n_classes * ldh > m.n_params)
+        return fail("plan_create: bad encoder embedding block (wide categorical columns, n_hidden > 0)");
+      suave::EmbedCol ec{};
+      ec.x_index = col.x_index; ec.C = col.n_classes; ec.e_off = col.enc_embed; ec.cls_begin = p->embed_classes_total;
+      p->embed_host.push_back(ec);
+      p->embed_classes_total += col.n_classes;
+      continue;
+    }
+    if (col.enc_off < 0 || col.enc_off + width > m.enc_in) return fail("plan_create: encoder input offsets out of range");
     const uint32_t kind = col.type <= SUAVE_TYPE_COUNT ? 2u : (col.type == SUAVE_TYPE_CAT ? 3u : 4u);
     for (int k = 0; k < width; ++k)
       enc_src[col.enc_off + k] = (int32_t)((kind << 29) | ((uint32_t)k << 14) | (uint32_t)col.x_index);
-    enc_src[col.enc_mask] = (int32_t)((1u << 29) | (uint32_t)c);
   }
   auto dfail = [&](const char* msg) {
     set_error(msg);
@@ -1066,6 +1119,13 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
     return dfail("plan_create: hipMemcpy failed");
   if (p->loss_lds_bytes > 48 * 1024)
     if (loss_set_lds_limit(p->loss_lds_bytes)) { suave_plan_destroy(p); return 2; }
+  if (!p->embed_host.empty()) {
+    const size_t ne = p->embed_host.size();
+    if (hipMalloc(&p->embed_dev, sizeof(suave::EmbedCol) * ne) != hipSuccess ||
+        hipMemcpy(p->embed_dev, p->embed_host.data(), sizeof(suave::EmbedCol) * ne, hipMemcpyHostToDevice) != hipSuccess)
+      return dfail("plan_create: hipMalloc/hipMemcpy of the embedding table failed");
+    if (round_up(m.enc[0].n_out, 4) > 1024) return fail("plan_create: first hidden layer wider than 1024 with embedded columns");
+  }
   *out = p;
   return 0;
 }
@@ -1078,6 +1138,7 @@ extern "C" int suave_plan_destroy(suave_plan* p) {
   if (p->cls_off_dev) (void)hipFree(p->cls_off_dev);
   if (p->xsrc_dev) (void)hipFree(p->xsrc_dev);
   if (p->wide_dev) (void)hipFree(p->wide_dev);
+  if (p->embed_dev) (void)hipFree(p->embed_dev);
   for (int q = 0; q < 3; ++q)
     if (p->wide_cum_dev[q]) (void)hipFree(p->wide_cum_dev[q]);
   delete p;
@@ -1125,12 +1186,7 @@ extern "C" int suave_encode(const suave_plan* p, const float* params, const suav
   if (int rc = launch_expand(p, *batch, w.x, nullptr, s)) return rc;
   const float* act = w.x;
   int ld_act = p->ldI;
-  for (int i = 0; i < m.n_hidden; ++i) {
-    if (int rc = fwd_layer(p, params, m.enc[i], act, ld_act, w.he[i], p->ldH[i], B, true, 0.f, nullptr, batch, nullptr, 0, 1, s))
-      return rc;
-    act = w.he[i];
-    ld_act = p->ldH[i];
-  }
+  if (int rc = encoder_trunk_forward(p, params, batch, nullptr, 0.f, w, false, &act, &ld_act, s)) return rc;
   if (int rc = fwd_layer(p, params, m.enc_head, act, ld_act, w.encout, p->ldE, B, false, 0.f, nullptr, batch, nullptr, 0, 1, s))
     return rc;
   return launch_posterior_stats(w.encout, p->ldE, m.n_components, m.latent_dim, B, inv_temperature, enc_out, post_mean,

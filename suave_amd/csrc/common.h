@@ -57,6 +57,16 @@ struct WideCol {
   int32_t pad;
 };
 
+// Encoder embedding block of one wide categorical column: row `code` of the block [C, ld] at e_off is the
+// column's contribution to the first encoder layer (see suave_col_t::enc_embed).
+struct EmbedCol {
+  int32_t x_index;  // column in codes
+  int32_t C;
+  int32_t e_off;    // flat-parameter offset of the block
+  int32_t cls_begin;  // classes of the embedded columns before this one
+};
+
+
 // A chunk of consecutive schema columns handled by one loss-kernel block column.
 struct ColChunk {
   int32_t col_begin, col_end;
@@ -98,6 +108,10 @@ struct suave_plan {
   int wide_w0 = 0;    // first float of the wide weight region
   int wide_len = 0;   // floats of the wide weight region
   int n_narrow = 0;   // columns handled by the fused likelihood kernel
+  // encoder embedding blocks of the wide categorical columns (first encoder layer)
+  std::vector<suave::EmbedCol> embed_host;
+  suave::EmbedCol* embed_dev = nullptr;
+  int embed_classes_total = 0;
 };
 
 namespace suave {
@@ -177,7 +191,8 @@ struct GemmArgs {
   const float* B;
   float* C;
   const float* bias;      // kEpiBias / kEpiReluDrop (may be null)
-  const float* H;         // kEpiMaskBwd: forward activation, same shape/ld as C
+  const float* H;         // kEpiMaskBwd: forward activation, same shape/ld as C;
+                          // kEpiReluDrop: optional addend of the pre-activation (same shape/ld as C, may be C itself)
   const uint8_t* keep;    // kEpiReluDrop: injected keep mask [M, N] (ld = N) or null
   const int32_t* row_ids; // table row id per output row (RNG key) or null -> row_begin + i
   int64_t row_begin;

@@ -331,6 +331,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += bias4[e];
           } else if (EPI == kEpiReluDrop) {
+            if (a.H != nullptr) {  // first encoder layer of wide schemas: + the embedding rows (embed.hip)
+              if (ncol >= 4) {
+                const float4 hv = *reinterpret_cast<const float4*>(a.H + off);
+                v[0] += hv.x; v[1] += hv.y; v[2] += hv.z; v[3] += hv.w;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (e < ncol) v[e] += a.H[off + e];
+              }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
             if (a.drop_p > 0.f) {
@@ -461,7 +471,7 @@ int check_gemm(const GemmArgs& a) {
   SUAVE_REQUIRE(a.lda % 4 == 0 && a.ldb % 4 == 0, "gemm: leading dimensions must be multiples of 4 floats");
   SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 && a.ldc % 4 == 0 && a.slab_stride % 4 == 0 &&
-                    (a.epi != kEpiMaskBwd || (reinterpret_cast<uintptr_t>(a.H) & 15) == 0),
+                    ((a.epi != kEpiMaskBwd && a.epi != kEpiReluDrop) || (reinterpret_cast<uintptr_t>(a.H) & 15) == 0),
                 "gemm: operands must be 16-byte aligned");
   if (a.grouped == 0) {
     SUAVE_REQUIRE(a.a_kmajor ? a.lda >= a.M : a.lda >= a.K, "gemm: lda too small");

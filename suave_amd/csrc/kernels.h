@@ -215,4 +215,28 @@ int launch_head_params(const suave_plan* p, int col_index, const float* params, 
                        const int32_t* comp, int64_t n, float* out, int width, hipStream_t st);
 int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s);
 
+// First encoder layer, embedded (wide categorical) columns: see embed.hip
+struct EmbedFwdArgs {
+  const EmbedCol* cols;
+  int n_embed, n_disc;
+  suave_batch_t batch;
+  int n_rows;
+  const float* params;
+  int ld;            // row stride of the embedding blocks and of pre (= ldH[0])
+  float* pre;        // [n_rows, ld] sum of the selected embedding rows
+  int16_t* ecodes;   // [n_embed, n_rows] codes of the embedded columns (for the weight gradient) or null
+};
+struct EmbedBwdArgs {
+  const EmbedCol* cols;
+  int n_embed;
+  int n_rows;
+  const int16_t* ecodes;
+  const float* dpre;  // [n_rows, ld] gradient of the first layer's pre-activation
+  int ld;
+  float* grads;       // flat gradient buffer
+  int n_classes_total;  // sum of the embedded columns' class counts = rows of all embedding blocks
+};
+int launch_embed_fwd(const EmbedFwdArgs& a, hipStream_t s);
+int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s);
+
 }  // namespace suave

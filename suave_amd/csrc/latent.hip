@@ -65,21 +65,31 @@ __global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_
       }
     }
     __syncthreads();
-    // lane = input feature (its map entry stays in a register), wave walks the rows: no index division
-    for (int i0 = 0; i0 < ldI; i0 += 64) {
-      const int i = i0 + lane;
-      const uint32_t e = i < ldI ? (uint32_t)enc_map[i] : 0u;
-      const int kind = e >> 29, cls = (e >> 14) & 0x7FFF, src = e & 0x3FFF;
-      if (i < ldI) {
-        for (int lr = wave; lr < nrows; lr += 4) {
-          float v = 0.f;
-          if (kind == 2) v = xn_s[lr * ldn + src];
-          else if (kind == 1) v = mk_s[lr * ldm + src] ? 1.f : 0.f;
-          else if (kind >= 3) {
-            const int code = cd_s[lr * ldd + src];
-            v = kind == 3 ? (code == cls ? 1.f : 0.f) : ((code >= 0 && cls <= code) ? 1.f : 0.f);  // model.py:2890-2891
+    // lane = input feature (its map entry stays in a register), wave walks the rows: no index division.
+    // Four 64-feature chunks per round so that four map loads are in flight (wide schemas: thousands of
+    // features, few rows per block).
+    for (int i0 = 0; i0 < ldI; i0 += 256) {
+      uint32_t e[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q * 64 + lane;
+        e[q] = i < ldI ? (uint32_t)enc_map[i] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q * 64 + lane;
+        const int kind = e[q] >> 29, cls = (e[q] >> 14) & 0x7FFF, src = e[q] & 0x3FFF;
+        if (i < ldI) {
+          for (int lr = wave; lr < nrows; lr += 4) {
+            float v = 0.f;
+            if (kind == 2) v = xn_s[lr * ldn + src];
+            else if (kind == 1) v = mk_s[lr * ldm + src] ? 1.f : 0.f;
+            else if (kind >= 3) {
+              const int code = cd_s[lr * ldd + src];
+              v = kind == 3 ? (code == cls ? 1.f : 0.f) : ((code >= 0 && cls <= code) ? 1.f : 0.f);  // model.py:2890-2891
+            }
+            x[(size_t)(r0 + lr) * ldI + i] = v;
           }
-          x[(size_t)(r0 + lr) * ldI + i] = v;
         }
       }
     }

@@ -31,7 +31,7 @@ WIDE_CAT_MIN_CLASSES = 17  # SUAVE_WIDE_CAT_MIN_CLASSES in include/suave_hip.h
 class ColT(C.Structure):
     _fields_ = [("type", C.c_int32), ("n_classes", C.c_int32), ("y_off", C.c_int32), ("y_dim", C.c_int32),
                 ("x_index", C.c_int32), ("enc_off", C.c_int32), ("enc_mask", C.c_int32), ("w_off", C.c_int32),
-                ("w2_off", C.c_int32), ("scale", C.c_float), ("shift", C.c_float)]
+                ("w2_off", C.c_int32), ("scale", C.c_float), ("shift", C.c_float), ("enc_embed", C.c_int32)]
 
 
 class LayerT(C.Structure):
@@ -79,6 +79,11 @@ class TensorSlot:
     ld: int  # row stride in the flat buffer (== shape[-1] for unpadded tensors)
     row0: int = 0  # first row inside a stacked matrix
     row_index: Optional[np.ndarray] = None  # tensor row i lives at buffer row row_index[i] (y_projection, wide schemas)
+    # first encoder layer of wide schemas: buffer column i of the dense matrix holds tensor column col_index[i];
+    # the remaining tensor columns (one-hot blocks of the wide categoricals) live transposed in embedding blocks
+    # [(tensor column start, n_classes, buffer offset, row stride)]
+    col_index: Optional[np.ndarray] = None
+    embed: Optional[List[Tuple[int, int, int, int]]] = None
 
 
 @dataclass
@@ -95,7 +100,8 @@ class ModelLayout:
     model: Optional[ModelT] = None
 
     # derived
-    enc_in: int = 0
+    enc_in: int = 0      # width of the dense encoder input the first GEMM multiplies
+    enc_in_ref: int = 0  # I of the reference (model.py:2905): enc_in + the one-hot widths of the embedded columns
     total_y: int = 0
     y_rows: int = 0  # rows of the internal y buffer / y_projection matrix (== total_y without wide categoricals)
     y_index: Optional[np.ndarray] = None  # reference y_full column -> internal y column
@@ -123,15 +129,33 @@ class ModelLayout:
         self.numeric_columns = tuple(n for n in names if schema[n].type in NUMERIC_TYPES)
         self.discrete_columns = tuple(n for n in names if schema[n].type in DISCRETE_TYPES)
         self.n_num, self.n_disc = len(self.numeric_columns), len(self.discrete_columns)
-        # encoder-input layout: values by type, then masks by type (model.py:2813-2905)
+        # encoder-input layout: values by type, then masks by type (model.py:2813-2905).  A wide categorical column
+        # (C >= WIDE_CAT_MIN_CLASSES) contributes W1[:, its one-hot block] @ onehot = ONE column of W1 per row, so
+        # its block is not part of the dense input at all: the C weight columns are kept transposed as an embedding
+        # block [C, H1] that the first layer gathers from (forward) and scatters into (weight gradient).
+        def is_wide(spec) -> bool:
+            return spec.type == "cat" and int(spec.n_classes) >= WIDE_CAT_MIN_CLASSES
+
+        embed_cols = [n for n in names if is_wide(schema[n]) and len(self.hidden) > 0 and int(self.hidden[0]) <= 1024]
         by_type = [n for t in TYPE_ORDER for n in names if schema[n].type == t]
         enc_off: Dict[str, int] = {}
-        pos = 0
+        ref_off: Dict[str, int] = {}
+        dense_ref_cols: List[int] = []
+        pos = ref_pos = 0
         for n in by_type:
-            enc_off[n] = pos
-            pos += 1 if schema[n].type in NUMERIC_TYPES else int(schema[n].n_classes)
+            width = 1 if schema[n].type in NUMERIC_TYPES else int(schema[n].n_classes)
+            ref_off[n] = ref_pos
+            if n in embed_cols:
+                enc_off[n] = -1
+            else:
+                enc_off[n] = pos
+                dense_ref_cols.extend(range(ref_pos, ref_pos + width))
+                pos += width
+            ref_pos += width
         enc_mask = {n: pos + i for i, n in enumerate(by_type)}
+        dense_ref_cols.extend(range(ref_pos, ref_pos + len(by_type)))
         self.enc_in = pos + len(by_type)
+        self.enc_in_ref = ref_pos + len(by_type)
         self.total_y = int(sum(ydims.values()))
         step = 3 if self.dropout > 0 else 2  # index step of nn.Sequential(Linear, ReLU[, Dropout])
 
@@ -150,8 +174,19 @@ class ModelLayout:
 
         g0 = off
         prev = self.enc_in
+        enc_embed: Dict[str, int] = {}
         for i, h in enumerate(self.hidden):
             add_layer(m.enc[i], f"encoder.backbone.{i * step}.weight", f"encoder.backbone.{i * step}.bias", h, prev)
+            if i == 0 and embed_cols:
+                sl = self.slots["encoder.backbone.0.weight"]
+                sl.shape = (h, self.enc_in_ref)
+                sl.col_index = np.asarray(dense_ref_cols, np.int64)
+                sl.embed = []
+                for n in embed_cols:
+                    Cn = int(schema[n].n_classes)
+                    enc_embed[n] = off
+                    sl.embed.append((ref_off[n], Cn, off, _r4(h)))
+                    off += Cn * _r4(h)
             prev = h
         # stacked encoder head
         E = K + 2 * K * D
@@ -210,6 +245,7 @@ class ModelLayout:
             col.n_classes = int(spec.n_classes or 0)
             col.y_off, col.y_dim = y_start[n], yd
             col.enc_off, col.enc_mask = enc_off[n], enc_mask[n]
+            col.enc_embed = enc_embed.get(n, -1)
             col.w_off, col.w2_off = off, -1
             col.scale, col.shift = 1.0, 0.0
             stats = self.norm_stats.get(n, {}) if self.norm_stats else {}
@@ -312,6 +348,15 @@ class ModelLayout:
                     flat[slot.offset + slot.row_index] = t
                 else:
                     flat[slot.offset : slot.offset + slot.shape[0]] = t
+            elif slot.col_index is not None:
+                rows = slot.shape[0]
+                view = np.lib.stride_tricks.as_strided(
+                    flat[slot.offset :], shape=(rows, len(slot.col_index)), strides=(slot.ld * 4, 4), writeable=True)
+                view[...] = t[:, slot.col_index]
+                for c0, n_cls, e_off, e_ld in slot.embed or []:
+                    blk = np.lib.stride_tricks.as_strided(
+                        flat[e_off:], shape=(n_cls, rows), strides=(e_ld * 4, 4), writeable=True)
+                    blk[...] = t[:, c0:c0 + n_cls].T
             else:
                 rows, cols = slot.shape
                 n_rows = rows if slot.row_index is None else int(slot.row_index.max()) + 1
@@ -334,6 +379,16 @@ class ModelLayout:
                     out[name] = flat[slot.offset + slot.row_index].copy()
                 else:
                     out[name] = flat[slot.offset : slot.offset + slot.shape[0]].copy()
+            elif slot.col_index is not None:
+                rows = slot.shape[0]
+                t = np.zeros(slot.shape, np.float32)
+                view = np.lib.stride_tricks.as_strided(flat[slot.offset :], shape=(rows, len(slot.col_index)),
+                                                       strides=(slot.ld * 4, 4))
+                t[:, slot.col_index] = view
+                for c0, n_cls, e_off, e_ld in slot.embed or []:
+                    blk = np.lib.stride_tricks.as_strided(flat[e_off:], shape=(n_cls, rows), strides=(e_ld * 4, 4))
+                    t[:, c0:c0 + n_cls] = blk.T
+                out[name] = t
             else:
                 rows, cols = slot.shape
                 n_rows = rows if slot.row_index is None else int(slot.row_index.max()) + 1

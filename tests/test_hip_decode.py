@@ -312,3 +312,31 @@ def test_golden_impute_end_to_end(behaviour, strategy):
         if strategy == "hard":
             assert np.allclose(got, fx[f"{behaviour}/merged_observed/{c.name}"], rtol=1e-6), c.name
         assert np.allclose(got, X[c.name].to_numpy()[obs], rtol=1e-6), c.name
+
+
+def test_encode_with_embedded_wide_columns_matches_oracle():
+    """suave_encode on a schema with wide categorical columns: the first encoder layer gathers embedding rows
+    (embed.hip) instead of multiplying one-hot blocks; rows include missing cells (code -1) and a gathered,
+    ragged batch."""
+
+    import torch
+    from suave_amd.engine import PackedTable
+    from tests.helpers import synth_packed, w1024_columns
+
+    cols = w1024_columns(25, 12, 6, 14, 7)
+    om = orc.OracleModel(cols, n_components=4, latent_dim=8, hidden=(48, 32))
+    P = om.init_params(seed=3)
+    eng = _engine(om, P)
+    assert any(c.enc_embed >= 0 for c in eng.layout.cols)
+    n = 777
+    xnum, codes, mask = synth_packed(cols, n, 0.2, seed=9)
+    table = PackedTable(xnum, codes, mask, eng.device)
+    idx = np.random.default_rng(1).permutation(n)[:515].astype(np.int32)
+    out = eng.encode(table, 0, len(idx), row_index=torch.from_numpy(idx).to(eng.device))
+    x_enc, _, _ = orc.dense_from_packed(om, xnum[idx], codes[idx], mask[idx])
+    lg, mu, lv, _ = orc.encoder_forward(om, P, x_enc)
+    enc = out["enc_out"].cpu().numpy()
+    K, D = om.K, om.D
+    assert rel_err(enc[:, :K], lg) < TOL
+    assert rel_err(enc[:, K:K + K * D], mu.reshape(len(idx), -1)) < TOL
+    assert rel_err(enc[:, K + K * D:], lv.reshape(len(idx), -1)) < TOL

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_struct_sizes_match_header():
     from suave_amd import plan
 
-    assert ctypes.sizeof(plan.ColT) == 44
+    assert ctypes.sizeof(plan.ColT) == 48
     assert ctypes.sizeof(plan.LayerT) == 20
     assert ctypes.sizeof(plan.BatchT) == 56
     assert ctypes.sizeof(plan.NoiseT) == 16 + 16 * 8 + 16
