@@ -141,6 +141,16 @@ def gemm_flops_per_row(layout):
     return 6 * mac
 
 
+def gemm_flops_executed_per_row(layout):
+    """FLOPs the MFMA kernels actually execute per row: the supervised step evaluates only the logits and the
+    selected component's mu / logvar rows of the encoder head (K + 2D of its K + 2KD columns)."""
+
+    K, D = layout.n_components, layout.latent_dim
+    h_last = layout.hidden[-1] if layout.hidden else layout.enc_in
+    skipped = h_last * (2 * K * D - 2 * D) if layout.behaviour == "supervised" else 0
+    return gemm_flops_per_row(layout) - 6 * skipped
+
+
 def cpu_baseline(spec, stats, dropout, budget_s=15.0, batch=4096):
     """The CPU oracle (numpy restatement of the reference path, oracle/) timed on this host's cores."""
 
@@ -418,7 +428,8 @@ def main():
                                 "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                                 "avg_launch_us": 1e3 * ms[0] / cnt[0],
-                                "algorithmic_flops_per_launch": gemm_flops / cnt[0]}
+                                "algorithmic_flops_per_launch": gemm_flops / cnt[0],
+                                "executed_tflops": gemm_flops_executed_per_row(layout) * B * steps / (ms[0] * 1e-3) / 1e12}
             line["kernel_ms_per_step"] = {PROF_CLASSES[i]: ms[i] / steps for i in range(8) if cnt[i] > 0}
             line["kernel_timing"] = ("HIP events around every launch, on the launch stream, " +
                                      ("inside the timed region" if args.profile_timed else
