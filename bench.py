@@ -237,7 +237,7 @@ def generation_rates(eng, table, rows, gen_rows, device, rank, world, dist, fenc
             slib.load().suave_profile_enable(0)
             slib.check(slib.load().suave_profile_read(ms, cnt, 8), "suave_profile_read")
         if dist is not None:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            t = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         res[name] = {"rows_per_s": world * n_rows_done / dt, "rows": world * n_rows_done, "seconds": dt}
@@ -316,11 +316,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # Rehearsal of the multi-rank path on a one-GPU box (SUAVE_BENCH_REHEARSAL=1): every rank uses cuda:0 and
+    # the collectives go through gloo -- same code path, not a measurement.
+    rehearsal = os.environ.get("SUAVE_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("SUAVE_BENCH_WATCHDOG", "120")), exit=True)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
@@ -394,7 +404,7 @@ def main():
         slib.load().suave_profile_enable(0)
         slib.check(slib.load().suave_profile_read(ms, cnt, 8), "suave_profile_read")
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     sums = eng.sums.cpu().numpy()

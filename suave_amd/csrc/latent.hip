@@ -127,14 +127,15 @@ __global__ __launch_bounds__(256) void k_assign(LatentFwdArgs a) {
     float t[SUAVE_MAX_COMPONENTS];
     float best = -INFINITY;
     kb = 0;
+    uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll 1
     for (int j = 0; j < a.K; ++j) {
       float e;
       if (a.exp_noise) {
         e = a.exp_noise[(size_t)r * a.K + j];
       } else {
-        const uint4 w = rng(rid, (uint32_t)(j >> 2), kStreamGumbel, (uint32_t)a.step);
-        const uint32_t word = (j & 3) == 0 ? w.x : (j & 3) == 1 ? w.y : (j & 3) == 2 ? w.z : w.w;
+        if ((j & 3) == 0) w4 = rng(rid, (uint32_t)(j >> 2), kStreamGumbel, (uint32_t)a.step);  // one block = 4 draws
+        const uint32_t word = (j & 3) == 0 ? w4.x : (j & 3) == 1 ? w4.y : (j & 3) == 2 ? w4.z : w4.w;
         e = -__logf(u01(word));
       }
       // Gumbel noise g = -log(e); the assignment path is deterministic binary32

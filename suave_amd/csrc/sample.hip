@@ -124,13 +124,17 @@ __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
       const int yd = col.y_dim;
       const float* w = a.params + col.w_off;
       if (col.type <= SUAVE_TYPE_COUNT) {
+        // one Philox block per (row, column): words x, y -> the normal draw, word z -> the uniform draw
         float nrm, uni = 0.f;
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (!a.noise_normal || (col.type == SUAVE_TYPE_COUNT && !a.noise_uniform))
+          q = rng(rid, (uint32_t)c, kStreamSampleNormal, rid_hi);
         if (a.noise_normal) nrm = a.noise_normal[(size_t)r * a.n_cols + c];
-        else { const uint4 q = rng(rid, (uint32_t)c, kStreamSampleNormal, rid_hi); nrm = normal2(q.x, q.y).x; }
+        else nrm = normal2(q.x, q.y).x;
         float val;
         if (col.type == SUAVE_TYPE_COUNT) {
           if (a.noise_uniform) uni = a.noise_uniform[(size_t)r * a.n_cols + c];
-          else uni = philox_u(rng, rid, (uint32_t)c, kStreamSampleUniform, rid_hi);
+          else uni = u01(q.z);
           const float rho = dot(w, yb, yd);
           const float rate = detm::add(detm::softplus(rho), kEps);
           val = poisson_from_noise(rate, uni, nrm);
@@ -153,10 +157,13 @@ __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
       } else {
         const int C = col.n_classes;
         const int coff = a.cls_off[c];
+        // classes are visited in order: one Philox block serves four consecutive classes
+        uint4 q4 = make_uint4(0u, 0u, 0u, 0u);
         auto draw_e = [&](int cl) {
           if (a.noise_exp) return a.noise_exp[(size_t)r * a.total_classes + coff + cl];
-          const uint4 q = rng(rid, (uint32_t)(coff + cl), kStreamSampleExp, rid_hi);
-          return -__logf(u01(q.x));
+          if ((cl & 3) == 0) q4 = rng(rid, ((uint32_t)c << 13) | (uint32_t)(cl >> 2), kStreamSampleExp, rid_hi);
+          const uint32_t word = (cl & 3) == 0 ? q4.x : (cl & 3) == 1 ? q4.y : (cl & 3) == 2 ? q4.z : q4.w;
+          return -__logf(u01(word));
         };
         int best_i = 0;
         if (col.type == SUAVE_TYPE_CAT) {  // Gumbel-max == exponential race on softmax(logits)
@@ -307,10 +314,14 @@ __global__ __launch_bounds__(256) void k_cond_latents(CondArgs a) {
       const float* pr = a.train_probs + (size_t)row * a.K;
       float best = -1.0f;
       int kb = 0;
+      uint4 q4 = make_uint4(0u, 0u, 0u, 0u);
       for (int j = 0; j < a.K; ++j) {  // Categorical(probs).sample(): argmax(p / e), model.py:3092-3094
         float e;
         if (a.e_comp) e = a.e_comp[(size_t)r * a.K + j];
-        else e = -__logf(philox_u(rng, (uint32_t)gid, (uint32_t)j, kStreamCondExp, (uint32_t)(gid >> 32)));
+        else {  // one Philox block = the draws of four components
+          if ((j & 3) == 0) q4 = rng((uint32_t)gid, (uint32_t)(j >> 2), kStreamCondExp, (uint32_t)(gid >> 32));
+          e = -__logf(u01((j & 3) == 0 ? q4.x : (j & 3) == 1 ? q4.y : (j & 3) == 2 ? q4.z : q4.w));
+        }
         const float sc = detm::dvd(pr[j], e);
         if (sc > best) { best = sc; kb = j; }
       }
@@ -370,10 +381,14 @@ __global__ __launch_bounds__(256) void k_posterior_draws(PostDrawArgs a) {
     const float* row = a.enc_out + (size_t)b * E;
     float best = -INFINITY;
     int kb = 0;
+    uint4 q4 = make_uint4(0u, 0u, 0u, 0u);
     for (int j = 0; j < a.K; ++j) {
       float e;
       if (a.e) e = a.e[(size_t)v * a.K + j];
-      else e = -__logf(philox_u(rng, (uint32_t)gid, (uint32_t)j, kStreamCondExp, (uint32_t)(gid >> 32)));
+      else {
+        if ((j & 3) == 0) q4 = rng((uint32_t)gid, (uint32_t)(j >> 2), kStreamCondExp, (uint32_t)(gid >> 32));
+        e = -__logf(u01((j & 3) == 0 ? q4.x : (j & 3) == 1 ? q4.y : (j & 3) == 2 ? q4.z : q4.w));
+      }
       const float sc = detm::sub(row[j], detm::log(e));
       if (sc > best) { best = sc; kb = j; }
     }

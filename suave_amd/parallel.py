@@ -66,6 +66,13 @@ def allreduce_gradients(flat_grads: torch.Tensor, buckets: Optional[Sequence[Tup
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return []
     handles = []
+    if flat_grads.is_cuda and dist.get_backend(group) == "gloo":
+        # CPU rehearsal of the multi-rank path (tests, one-GPU boxes): gloo reduces host memory
+        for b, e in (buckets or [(0, flat_grads.numel())]):
+            host = flat_grads[b:e].cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat_grads[b:e].copy_(host)
+        return handles
     for b, e in (buckets or [(0, flat_grads.numel())]):
         h = dist.all_reduce(flat_grads[b:e], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         if async_op:
