@@ -54,6 +54,34 @@ __global__ void k_onehot(const int32_t* kidx, int n_rows, int K, int ld, float* 
   }
 }
 
+// Row-major copies W^T [n_in, ldT] of the layer weights W [n_out, ld]: with them the data-gradient GEMM
+// dA = dC * W reads both operands k-contiguous, i.e. it is a forward-type product the split kernels handle.
+struct TransArgs {
+  const float* src[2 * SUAVE_MAX_HIDDEN + 2];
+  float* dst[2 * SUAVE_MAX_HIDDEN + 2];
+  int n_out[2 * SUAVE_MAX_HIDDEN + 2], n_in[2 * SUAVE_MAX_HIDDEN + 2], ld[2 * SUAVE_MAX_HIDDEN + 2], ldT[2 * SUAVE_MAX_HIDDEN + 2];
+};
+__global__ __launch_bounds__(256) void k_transpose(TransArgs a) {
+  __shared__ float tile[32][33];
+  const int m = blockIdx.y;
+  const int n_out = a.n_out[m], n_in = a.n_in[m], ld = a.ld[m], ldT = a.ldT[m];
+  const int tiles_i = (n_in + 31) / 32, tiles_o = (n_out + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int t = blockIdx.x; t < tiles_i * tiles_o; t += gridDim.x) {
+    const int o0 = (t / tiles_i) * 32, i0 = (t % tiles_i) * 32;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int o = o0 + r, i = i0 + tx;
+      tile[r][tx] = (o < n_out && i < n_in) ? a.src[m][(size_t)o * ld + i] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int i = i0 + r, o = o0 + tx;
+      if (i < n_in && o < ldT) a.dst[m][(size_t)i * ldT + o] = tile[tx][r];  // pad columns o >= n_out get zeros
+    }
+  }
+}
+
 int launch_onehot(const int32_t* kidx, int n_rows, int K, int ld, float* out, hipStream_t s) {
   const int64_t n = (int64_t)n_rows * K;
   hipLaunchKernelGGL(k_onehot, dim3((int)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, kidx, n_rows, K, ld, out);
@@ -83,6 +111,7 @@ struct Workspace {
   int n_blocks, n_chunks_max;
   float* wideL;  // [rows, ldL] logits / logit gradients of the wide categorical columns
   int16_t* ecodes;  // [n_embed, rows] codes of the embedded columns (first encoder layer)
+  float* wT[2 * SUAVE_MAX_HIDDEN + 2];  // row-major transposes of the layer weights, in all_layers() order
   float* slab;
   double* sums_slab;
   size_t slab_floats;
@@ -166,6 +195,10 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
   w->ds_part = c.take<float>((nch + 1) * R * p->ldK);
   w->wideL = c.take<float>(any_wide ? R * p->ldL : 4);
   w->ecodes = c.take<int16_t>(std::max<size_t>(p->embed_host.size() * R, 8));
+  {
+    int li = 0;
+    for (const suave_layer_t* l : all_layers(p)) w->wT[li++] = c.take<float>((size_t)l->n_in * round_up(l->n_out, 4) + 4);
+  }
   w->catkl = c.take<float>(R);
   w->gausskl = c.take<float>(R);
   w->recon = c.take<float>(R);
@@ -253,12 +286,15 @@ int fwd_layer(const suave_plan* p, const float* params, const suave_layer_t& l, 
 
 // data gradient: dA = (dC * W) [* relu/dropout mask of H]
 GemmArgs bwd_data_args(const float* params, const suave_layer_t& l, const float* dC, int lddc, float* dA, int ldda, int rows,
-                       const float* H, float drop_p) {
+                       const float* H, float drop_p, const float* wT = nullptr) {
   GemmArgs g = gemm_base();
   g.A = dC; g.B = params + l.w_off; g.C = dA;
   g.M = rows; g.N = l.n_in; g.K = l.n_out;
   g.lda = lddc; g.ldb = l.ld; g.ldc = ldda;
   g.b_kmajor = 1;
+  if (wT != nullptr && gemm_split_mode() != 0) {  // row-major W^T [n_in, ldT]: the split kernels' operand form
+    g.B = wT; g.ldb = round_up(l.n_out, 4); g.b_kmajor = 0;
+  }
   g.epi = H ? kEpiMaskBwd : kEpiBias;
   g.H = H;
   g.drop_p = drop_p;
@@ -295,8 +331,34 @@ int bwd_weight_args(const suave_plan* p, const suave_layer_t& l, const float* dC
 }
 
 int bwd_data(const suave_plan* p, const float* params, const suave_layer_t& l, const float* dC, int lddc, float* dA,
-             int ldda, int rows, const float* H, float drop_p, hipStream_t s) {
-  return launch_gemm(bwd_data_args(params, l, dC, lddc, dA, ldda, rows, H, drop_p), p->n_cu, s);
+             int ldda, int rows, const float* H, float drop_p, hipStream_t s, const float* wT = nullptr) {
+  return launch_gemm(bwd_data_args(params, l, dC, lddc, dA, ldda, rows, H, drop_p, wT), p->n_cu, s);
+}
+
+// index of a layer in all_layers() order (= index of its transposed copy in Workspace::wT)
+int layer_index(const suave_plan* p, const suave_layer_t* l) {
+  int i = 0;
+  for (const suave_layer_t* q : all_layers(p)) {
+    if (q == l) return i;
+    ++i;
+  }
+  return -1;
+}
+
+int transpose_weights(const suave_plan* p, const float* params, const Workspace& w, hipStream_t s) {
+  if (gemm_split_mode() == 0) return 0;
+  TransArgs t{};
+  int n = 0, max_tiles = 1;
+  for (const suave_layer_t* l : all_layers(p)) {
+    t.src[n] = params + l->w_off; t.dst[n] = w.wT[n];
+    t.n_out[n] = l->n_out; t.n_in[n] = l->n_in; t.ld[n] = l->ld; t.ldT[n] = round_up(l->n_out, 4);
+    max_tiles = std::max(max_tiles, ((l->n_in + 31) / 32) * ((l->n_out + 31) / 32));
+    ++n;
+  }
+  ProfScope prof_scope(kProfOther, s);
+  hipLaunchKernelGGL(k_transpose, dim3(std::min(max_tiles, 1024), n), dim3(256), 0, s, t);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 int bwd_weight(const suave_plan* p, const suave_layer_t& l, const float* dC, int lddc, const float* A, int lda,
@@ -309,10 +371,11 @@ int bwd_weight(const suave_plan* p, const suave_layer_t& l, const float* dC, int
 // both backward GEMMs of layer l in one launch: dW (slab) from (dC, A_in) and dA_in from (dC, W)
 int bwd_layer(const suave_plan* p, const float* params, const suave_layer_t& l, const float* dC, int lddc,
               const float* A_in, int lda_in, float* dA_in, int ldda, int rows, const float* H_in, float drop_p,
-              float* slab_base, size_t* slab_off, ReduceArgs* red, int* max_elems, hipStream_t s) {
+              float* slab_base, size_t* slab_off, ReduceArgs* red, int* max_elems, hipStream_t s,
+              const float* wT = nullptr) {
   GemmArgs w;
   if (int rc = bwd_weight_args(p, l, dC, lddc, A_in, lda_in, rows, slab_base, slab_off, red, max_elems, &w)) return rc;
-  return launch_gemm_pair(bwd_data_args(params, l, dC, lddc, dA_in, ldda, rows, H_in, drop_p), w, p->n_cu, s);
+  return launch_gemm_pair(bwd_data_args(params, l, dC, lddc, dA_in, ldda, rows, H_in, drop_p, wT), w, p->n_cu, s);
 }
 
 WideRowArgs wide_row_args(const suave_plan* p, const Workspace& w, int rows) {
@@ -512,6 +575,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
   red.n_segs = 0; red.slab = w.slab; red.dst = grads;
   int max_elems = 256;
   if (grad) {
+    if (int rc = transpose_weights(p, params, w, s)) return rc;
     if (n_wide)
       if (int rc = wide_backward(p, params, w, V, nullptr, &slab_off, &red, &max_elems, s)) return rc;
     const float* hlast = nh ? w.hd[nh - 1] : w.z;
@@ -521,7 +585,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     int lddcur = p->ldY;
     const suave_layer_t* lcur = &m.y_proj;
     for (int i = nh - 1; i >= 0; --i) {
-      if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dhd[i], p->ldH[i], V, w.hd[i], drop_p, s)) return rc;
+      if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dhd[i], p->ldH[i], V, w.hd[i], drop_p, s, w.wT[layer_index(p, lcur)])) return rc;
       const float* ain = i > 0 ? w.hd[i - 1] : w.z;
       const int ldain = i > 0 ? p->ldH[i - 1] : p->ldD;
       if (int rc = bwd_weight(p, m.dec[i], w.dhd[i], p->ldH[i], ain, ldain, V, w.slab, &slab_off, &red, &max_elems, s))
@@ -530,7 +594,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
       lddcur = p->ldH[i];
       lcur = &m.dec[i];
     }
-    if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dz, p->ldD, V, nullptr, 0.f, s)) return rc;
+    if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dz, p->ldD, V, nullptr, 0.f, s, w.wT[layer_index(p, lcur)])) return rc;
   }
   const int fgrid = std::max(1, std::min((B + 63) / 64, 2 * p->n_cu));
   {
@@ -556,7 +620,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     int lddcur = p->ldE;
     const suave_layer_t* lcur = &m.enc_head;
     for (int i = nh - 1; i >= 0; --i) {
-      if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dhe[i], p->ldH[i], B, w.he[i], drop_p, s)) return rc;
+      if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dhe[i], p->ldH[i], B, w.he[i], drop_p, s, w.wT[layer_index(p, lcur)])) return rc;
       const float* ain = i > 0 ? w.he[i - 1] : w.x;
       const int ldain = i > 0 ? p->ldH[i - 1] : p->ldI;
       if (int rc = bwd_weight(p, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, B, w.slab, &slab_off, &red, &max_elems, s))
@@ -745,6 +809,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   int max_elems = 256;
 
   if (grad) {
+    if (int rc = transpose_weights(p, params, w, s)) return rc;
     if (n_wide)
       if (int rc = wide_backward(p, params, w, B, w.ds_part + (size_t)n_chunks * B * p->ldK, &slab_off, &red, &max_elems, s))
         return rc;
@@ -758,7 +823,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
         const int ldain = i >= 0 ? p->ldH[i] : p->ldD;
         float* dain = i >= 0 ? w.dhd[i] : w.dz;
         if (int rc = bwd_layer(p, params, *lcur, dcur, lddcur, ain, ldain, dain, ldain, B, i >= 0 ? w.hd[i] : nullptr,
-                               i >= 0 ? drop_p : 0.f, w.slab, &slab_off, &red, &max_elems, s))
+                               i >= 0 ? drop_p : 0.f, w.slab, &slab_off, &red, &max_elems, s, w.wT[layer_index(p, lcur)]))
           return rc;
         dcur = dain;
         lddcur = ldain;
@@ -809,7 +874,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
       const int ldain = i > 0 ? p->ldH[i - 1] : p->ldI;
       if (i > 0) {
         if (int rc = bwd_layer(p, params, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, w.dhe[i - 1], ldain, B, w.he[i - 1],
-                               drop_p, w.slab, &slab_off, &red, &max_elems, s))
+                               drop_p, w.slab, &slab_off, &red, &max_elems, s, w.wT[layer_index(p, &m.enc[i])]))
           return rc;
       } else {
         if (int rc = bwd_weight(p, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, B, w.slab, &slab_off, &red, &max_elems, s))

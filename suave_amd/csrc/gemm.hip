@@ -13,6 +13,7 @@
 // MFMA tiles, K step 16, LDS tiles stored k-major ([k][i]) so that the MFMA
 // operand fetch (lane l: i = l&31, k = l>>5) is a conflict-free ds_read_b32,
 // double-buffered with the next tile's global loads in flight during the MFMAs.
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -20,8 +21,12 @@
 namespace suave {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+int split_mode();  // defined with the launchers below
 
 constexpr int BK = 16;
 constexpr int PAD = 4;
@@ -39,12 +44,43 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
 // epilogue mixes in the column pair and spends 16 hash bits per element.
 __device__ __forceinline__ uint32_t drop_row_hash(uint32_t key, uint32_t row_id) { return hash32(row_id * 0x9E3779B1u + key); }
 
-template <int WAVES_M, int WAVES_N>
-constexpr int gemm_smem_floats() { return 2 * BK * ((WAVES_M * 64 + PAD) + (WAVES_N * 64 + PAD)); }
+// Split mode (SPLIT = NS > 0, row-major operands only): every fp32 operand element is cut into NS bf16 planes
+// (hi, mid, lo: x = hi + mid + lo up to 2^-24 |x| for NS = 3) when its tile is stored to LDS, and the tile
+// product is the sum of the plane products on v_mfma_f32_32x32x16_bf16, accumulated in fp32:
+//   NS = 3: the six pairs with i + j <= 2  -> the error of an fp32 FMA chain (measured 4e-7 of max|C| at
+//           K = 256, 1.6e-6 at K = 4096; the exact-fp32 MFMA kernel: 3e-6 at K = 4096), at 6/16 of its
+//           matrix-pipe time;
+//   NS = 2: three pairs                    -> ~5e-6 on well-scaled operands, at 3/16 (not dispatched: see
+//           split_mode()).
+// The bf16 MFMA has its own pipe: the split arithmetic (VALU) runs beside it instead of taking its cycles, which
+// the f32 MFMA cannot offer (it executes on the SIMD's FMA lanes).  LDS image per plane: [row][16 k] bf16, 32 B
+// per row: a lane's MFMA fragment (row l & 31, k = 8 (l >> 5) ... + 7) is one ds_read_b128.
+constexpr int kSplitRowBytes = 2 * BK;
+template <int WAVES_M, int WAVES_N, int SPLIT = 0>
+constexpr int gemm_smem_floats() {
+  constexpr int f32 = 2 * BK * ((WAVES_M * 64 + PAD) + (WAVES_N * 64 + PAD));
+  constexpr int spl = 2 * SPLIT * (WAVES_M * 64 + WAVES_N * 64) * kSplitRowBytes / 4;
+  return f32 > spl ? f32 : spl;
+}
+
+template <int NS>
+__device__ __forceinline__ void split4(const float4 v, bf16x4 (&p)[NS > 0 ? NS : 1]) {
+  float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 h = (__bf16)r[e];  // round to nearest even (v_cvt_pk_bf16_f32)
+      p[s][e] = h;
+      r[e] -= (float)h;               // exact in fp32
+    }
+  }
+}
 
 // One block's work: tile `bid` of split `bz`.
-template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int GRP, int EPI>
+template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int GRP, int EPI, int SPLIT = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, const int bz, float* smem, int* perm_s) {
+  static_assert(SPLIT == 0 || (!A_KM && !B_KM), "split mode stages row-major operands only");
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   constexpr int LDAS = BM + PAD, LDBS = BN + PAD;
   constexpr int NA = BM * BK / 4 / 256;  // float4 loads per thread for the A tile
@@ -157,7 +193,33 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
       okm |= ok ? (1u << (8 + p)) : 0u;
     }
   };
+  // split mode: plane s of buffer `buf`, A rows then B rows
+  auto plane = [&](int buf, int s) {
+    return reinterpret_cast<unsigned char*>(smem) + (size_t)((buf * (SPLIT > 0 ? SPLIT : 1) + s) * (BM + BN)) * kSplitRowBytes;
+  };
   auto store_tiles = [&](int k0, int buf, const float4 (&ra)[NA], const float4 (&rb)[NB], uint32_t okm) {
+    if constexpr (SPLIT > 0) {
+#pragma unroll
+      for (int p = 0; p < NA + NB; ++p) {
+        const bool isA = p < NA;
+        const int q = isA ? p : p - NA;
+        const int idx = tid + q * 256;
+        const int row = idx >> 2, kq = idx & 3;
+        int lim = k_end - (k0 + kq * 4);
+        if (!((okm >> (isA ? q : 8 + q)) & 1u)) lim = 0;
+        float4 v = isA ? ra[q] : rb[q];
+        v.x = lim > 0 ? v.x : 0.f;
+        v.y = lim > 1 ? v.y : 0.f;
+        v.z = lim > 2 ? v.z : 0.f;
+        v.w = lim > 3 ? v.w : 0.f;
+        bf16x4 pl[SPLIT > 0 ? SPLIT : 1];
+        split4<SPLIT>(v, pl);
+#pragma unroll
+        for (int s = 0; s < SPLIT; ++s)
+          *reinterpret_cast<bf16x4*>(plane(buf, s) + (size_t)((isA ? 0 : BM) + row) * kSplitRowBytes + kq * 8) = pl[s];
+      }
+      return;
+    }
     float* Ab = As + buf * BK * LDAS;
     float* Bb = Bs + buf * BK * LDBS;
 #pragma unroll
@@ -222,6 +284,33 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
 
   // One K step on LDS buffer `buf`; operand fragments of step kk+1 are fetched before the MFMAs of kk.
   auto compute = [&](int buf) {
+    if constexpr (SPLIT > 0) {
+      if (act) {
+        bf16x8 fa[SPLIT > 0 ? SPLIT : 1][2], fb[SPLIT > 0 ? SPLIT : 1][2];
+        // fragments are fetched plane by plane and the plane products run in the order hi*hi, hi*mid, mid*hi,
+        // mid*mid, hi*lo, lo*hi: the first MFMAs wait for four ds_read_b128 only, the rest of the fetch lands
+        // behind them
+#pragma unroll
+        for (int s = 0; s < SPLIT; ++s)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            fa[s][i] = *reinterpret_cast<const bf16x8*>(plane(buf, s) + (size_t)(wm * 64 + i * 32 + l31) * kSplitRowBytes + kh * 16);
+            fb[s][i] = *reinterpret_cast<const bf16x8*>(plane(buf, s) + (size_t)(BM + wn * 64 + i * 32 + l31) * kSplitRowBytes + kh * 16);
+          }
+        constexpr int kPairs = SPLIT == 3 ? 6 : 3;
+        constexpr int pa_[6] = {0, 0, 1, 1, 0, 2}, pb_[6] = {0, 1, 0, 1, 2, 0};
+        constexpr int qa_[3] = {0, 0, 1}, qb_[3] = {0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < kPairs; ++q) {
+          const int sa = SPLIT == 3 ? pa_[q] : qa_[q], sb = SPLIT == 3 ? pb_[q] : qb_[q];
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sa][0], fb[sb][0], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sa][0], fb[sb][1], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sa][1], fb[sb][0], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sa][1], fb[sb][1], acc[1][1], 0, 0, 0);
+        }
+      }
+      return;
+    }
     if (act) {
       const float* Ab = As + buf * BK * LDAS + wm * 64 + l31;
       const float* Bb = Bs + buf * BK * LDBS + wn * 64 + l31;
@@ -385,32 +474,33 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   }
 }
 
-template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int GRP, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<WAVES_M, WAVES_N>()];
+template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int GRP, int EPI, int SPLIT = 0>
+__global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<WAVES_M, WAVES_N, SPLIT>()];
   __shared__ int perm_s[GRP == 2 ? kGroupRows : 1];
-  gemm_body<WAVES_M, WAVES_N, A_KM, B_KM, GRP, EPI>(a, blockIdx.x, blockIdx.z, smem, perm_s);
+  gemm_body<WAVES_M, WAVES_N, A_KM, B_KM, GRP, EPI, SPLIT>(a, blockIdx.x, blockIdx.z, smem, perm_s);
 }
 
 // The two backward GEMMs of one layer in one launch: they read the same dC and do not depend on each
 // other.  The weight-gradient blocks (few and long: one per CU) are dispatched first, the data-gradient
 // blocks fill the rest of each CU.
-template <int DM, int DN, int D_GRP, int D_EPI, int WM, int WN, int W_GRP>
+template <int DM, int DN, int D_GRP, int D_EPI, int WM, int WN, int W_GRP, int D_SPLIT = 0>
 __global__ __launch_bounds__(256) void gemm_pair_kernel(GemmArgs d, GemmArgs w, int w_blocks, int w_tiles) {
-  constexpr int kSmem = gemm_smem_floats<DM, DN>() > gemm_smem_floats<WM, WN>() ? gemm_smem_floats<DM, DN>()
-                                                                                : gemm_smem_floats<WM, WN>();
+  constexpr int kSmem = gemm_smem_floats<DM, DN, D_SPLIT>() > gemm_smem_floats<WM, WN>() ? gemm_smem_floats<DM, DN, D_SPLIT>()
+                                                                                         : gemm_smem_floats<WM, WN>();
   __shared__ __attribute__((aligned(16))) float smem[kSmem];
   __shared__ int perm_s[W_GRP == 2 ? kGroupRows : 1];
   const int b = blockIdx.x;
   if (b < w_blocks) gemm_body<WM, WN, true, true, W_GRP, kEpiSlab>(w, b % w_tiles, b / w_tiles, smem, perm_s);
-  else gemm_body<DM, DN, false, true, D_GRP, D_EPI>(d, b - w_blocks, 0, smem, perm_s);
+  else gemm_body<DM, DN, false, D_SPLIT == 0, D_GRP, D_EPI, D_SPLIT>(d, b - w_blocks, 0, smem, perm_s);  // split: row-major W^T
 }
 
 // All wide categorical columns in one launch: a block looks up its column in the tile prefix table and runs
 // the ordinary tile body on that column's operands.
-template <int MODE>
-__global__ __launch_bounds__(256) void gemm_wide_kernel(WideGemmArgs w) {
-  __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<2, 2>()];
+template <int MODE, int SPLIT = 0>
+__global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_wide_kernel(WideGemmArgs w) {
+  static_assert(SPLIT == 0 || MODE == 0, "only the logits product has row-major operands");
+  __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<2, 2, SPLIT>()];
   __shared__ int perm_s[1];
   const int tiles_m = MODE == 2 ? 1 : (w.rows + 127) / 128;
   const int q = blockIdx.x / tiles_m;
@@ -432,7 +522,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(WideGemmArgs w) {
   if (MODE == 0) {
     g.A = slot; g.B = wt; g.C = logit; g.M = w.rows; g.N = wc.C - 1; g.K = wc.yd + w.K;
     g.lda = w.ldY; g.ldb = wc.ldw; g.ldc = w.ldL; g.a_kmajor = 0; g.b_kmajor = 0; g.epi = kEpiBias;
-    gemm_body<2, 2, false, false, 0, kEpiBias>(g, local, 0, smem, perm_s);
+    gemm_body<2, 2, false, false, 0, kEpiBias, SPLIT>(g, local, 0, smem, perm_s);
   } else if (MODE == 1) {
     g.A = logit; g.B = wt; g.C = slot; g.M = w.rows; g.N = wc.ldw; g.K = wc.C - 1;
     g.lda = w.ldL; g.ldb = wc.ldw; g.ldc = w.ldY; g.a_kmajor = 0; g.b_kmajor = 1; g.epi = kEpiBias;
@@ -459,7 +549,8 @@ int launch_gemm_wide(const WideGemmArgs& a, int mode, hipStream_t stream) {
   const int64_t blocks = (int64_t)a.cum_total * tiles_m;
   SUAVE_REQUIRE(blocks > 0 && blocks < (int64_t(1) << 31), "wide gemm: grid out of range");
   const dim3 grid((unsigned)blocks, 1, mode == 2 ? a.splits : 1), block(256);
-  if (mode == 0) hipLaunchKernelGGL(gemm_wide_kernel<0>, grid, block, 0, stream, a);
+  if (mode == 0 && split_mode() == 3) hipLaunchKernelGGL((gemm_wide_kernel<0, 3>), grid, block, 0, stream, a);
+  else if (mode == 0) hipLaunchKernelGGL(gemm_wide_kernel<0>, grid, block, 0, stream, a);
   else if (mode == 1) hipLaunchKernelGGL(gemm_wide_kernel<1>, grid, block, 0, stream, a);
   else hipLaunchKernelGGL(gemm_wide_kernel<2>, grid, block, 0, stream, a);
   SUAVE_CHECK_HIP(hipGetLastError());
@@ -488,10 +579,23 @@ int check_gemm(const GemmArgs& a) {
   return 0;
 }
 inline bool gemm_narrow(const GemmArgs& a) { return a.N <= 64; }
+// SUAVE_GEMM_SPLIT = 3 (default: fp32-accurate three-plane split on the bf16 MFMA) or 0 (exact-fp32 MFMA
+// everywhere).  Only the row-major forms have a split kernel.  A two-plane split (three products, 14 % faster on
+// the whole step) was measured and dropped: 5e-6 per GEMM on well-scaled data, but 5e-2 on the decoder weight
+// gradients of the std = 12 real columns, whose dY spans three decades within a row (scripts/split_accuracy.py).
+int split_mode() {
+  static const int mode = [] {
+    const char* e = getenv("SUAVE_GEMM_SPLIT");
+    return (e && atoi(e) == 0) ? 0 : 3;
+  }();
+  return mode;
+}
 inline int gemm_tiles(const GemmArgs& a) {
   return gemm_narrow(a) ? ((a.M + 255) / 256) * ((a.N + 63) / 64) : ((a.M + 127) / 128) * ((a.N + 127) / 128);
 }
 }  // namespace
+
+int gemm_split_mode() { return split_mode(); }
 
 int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   (void)n_cu;
@@ -509,18 +613,28 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
     if (narrow) hipLaunchKernelGGL((gemm_kernel<4, 1, AKM, BKM, GRP, EPI>), grid, block, 0, stream, args); \
     else hipLaunchKernelGGL((gemm_kernel<2, 2, AKM, BKM, GRP, EPI>), grid, block, 0, stream, args);        \
   } while (0)
+#define SUAVE_GEMM_LAUNCH_RM(GRP, EPI) /* row-major operands: exact fp32 or split bf16 */                       \
+  do {                                                                                                          \
+    if (sp == 3) {                                                                                              \
+      if (narrow) hipLaunchKernelGGL((gemm_kernel<4, 1, false, false, GRP, EPI, 3>), grid, block, 0, stream, args); \
+      else hipLaunchKernelGGL((gemm_kernel<2, 2, false, false, GRP, EPI, 3>), grid, block, 0, stream, args);    \
+    } else SUAVE_GEMM_LAUNCH(false, false, GRP, EPI);                                                           \
+  } while (0)
   const int e = a.epi;
-  if (a.grouped == 1 && !a.b_kmajor && e == kEpiBias) SUAVE_GEMM_LAUNCH(false, false, 1, kEpiBias);
+  const int sp = split_mode();
+  if (a.grouped == 1 && !a.b_kmajor && e == kEpiBias) SUAVE_GEMM_LAUNCH_RM(1, kEpiBias);
   else if (a.grouped == 1 && a.b_kmajor && e == kEpiMaskBwd) SUAVE_GEMM_LAUNCH(false, true, 1, kEpiMaskBwd);
   else if (a.grouped == 1 && a.b_kmajor && e == kEpiBias) SUAVE_GEMM_LAUNCH(false, true, 1, kEpiBias);
   else if (a.grouped == 2) SUAVE_GEMM_LAUNCH(true, true, 2, kEpiSlab);
   else if (a.grouped != 0) SUAVE_REQUIRE(false, "gemm: unsupported grouped form");
-  else if (!a.a_kmajor && !a.b_kmajor && e == kEpiBias) SUAVE_GEMM_LAUNCH(false, false, 0, kEpiBias);
-  else if (!a.a_kmajor && !a.b_kmajor && e == kEpiReluDrop) SUAVE_GEMM_LAUNCH(false, false, 0, kEpiReluDrop);
+  else if (!a.a_kmajor && !a.b_kmajor && e == kEpiBias) SUAVE_GEMM_LAUNCH_RM(0, kEpiBias);
+  else if (!a.a_kmajor && !a.b_kmajor && e == kEpiReluDrop) SUAVE_GEMM_LAUNCH_RM(0, kEpiReluDrop);
+  else if (!a.a_kmajor && !a.b_kmajor && e == kEpiMaskBwd) SUAVE_GEMM_LAUNCH_RM(0, kEpiMaskBwd);
   else if (!a.a_kmajor && a.b_kmajor && e == kEpiBias) SUAVE_GEMM_LAUNCH(false, true, 0, kEpiBias);
   else if (!a.a_kmajor && a.b_kmajor && e == kEpiMaskBwd) SUAVE_GEMM_LAUNCH(false, true, 0, kEpiMaskBwd);
   else if (a.a_kmajor && a.b_kmajor && e == kEpiSlab) SUAVE_GEMM_LAUNCH(true, true, 0, kEpiSlab);
   else SUAVE_REQUIRE(false, "gemm: unsupported operand layout / epilogue combination");
+#undef SUAVE_GEMM_LAUNCH_RM
 #undef SUAVE_GEMM_LAUNCH
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
@@ -529,7 +643,8 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
 // d: data-gradient GEMM (A k-contiguous, B k-major, kEpiMaskBwd or kEpiBias); w: weight-gradient GEMM of the
 // same layer (both k-major, kEpiSlab).  Combinations without a fused instantiation run as two launches.
 int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t stream) {
-  const bool fusable = d.M > 0 && d.N > 0 && w.M > 0 && w.N > 0 && !d.a_kmajor && d.b_kmajor && w.a_kmajor && w.b_kmajor &&
+  const bool d_rm = !d.a_kmajor && !d.b_kmajor && d.grouped == 0;  // data gradient on a transposed (row-major) weight
+  const bool fusable = d.M > 0 && d.N > 0 && w.M > 0 && w.N > 0 && !d.a_kmajor && (d.b_kmajor || d_rm) && w.a_kmajor && w.b_kmajor &&
                        w.epi == kEpiSlab && (d.epi == kEpiMaskBwd || d.epi == kEpiBias) &&
                        ((d.grouped == 0 && w.grouped == 0) || (d.grouped == 1 && w.grouped == 2 && d.epi == kEpiMaskBwd));
   if (!fusable) {
@@ -542,20 +657,27 @@ int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t
   da.splits = 1;
   const int w_tiles = gemm_tiles(w), w_blocks = w_tiles * w.splits, d_tiles = gemm_tiles(d);
   const bool dn = gemm_narrow(d), wn = gemm_narrow(w);
+  const int sp = d_rm ? split_mode() : 0;
+  SUAVE_REQUIRE(!d_rm || sp != 0, "gemm: a row-major data-gradient operand needs the split kernels (SUAVE_GEMM_SPLIT)");
   ProfScope prof_scope(kProfGemm, stream);
   const dim3 grid(w_blocks + d_tiles), block(256);
-#define SUAVE_PAIR(DM, DN, DG, DE, WM, WN, WG) \
-  hipLaunchKernelGGL((gemm_pair_kernel<DM, DN, DG, DE, WM, WN, WG>), grid, block, 0, stream, da, wa, w_blocks, w_tiles)
-#define SUAVE_PAIR_SHAPES(DG, DE, WG)                  \
-  do {                                                 \
-    if (!dn && !wn) SUAVE_PAIR(2, 2, DG, DE, 2, 2, WG); \
-    else if (!dn && wn) SUAVE_PAIR(2, 2, DG, DE, 4, 1, WG); \
-    else if (dn && !wn) SUAVE_PAIR(4, 1, DG, DE, 2, 2, WG); \
-    else SUAVE_PAIR(4, 1, DG, DE, 4, 1, WG);            \
+#define SUAVE_PAIR(DM, DN, DG, DE, WM, WN, WG, DS) \
+  hipLaunchKernelGGL((gemm_pair_kernel<DM, DN, DG, DE, WM, WN, WG, DS>), grid, block, 0, stream, da, wa, w_blocks, w_tiles)
+#define SUAVE_PAIR_SHAPES(DG, DE, WG, DS)                  \
+  do {                                                     \
+    if (!dn && !wn) SUAVE_PAIR(2, 2, DG, DE, 2, 2, WG, DS); \
+    else if (!dn && wn) SUAVE_PAIR(2, 2, DG, DE, 4, 1, WG, DS); \
+    else if (dn && !wn) SUAVE_PAIR(4, 1, DG, DE, 2, 2, WG, DS); \
+    else SUAVE_PAIR(4, 1, DG, DE, 4, 1, WG, DS);            \
   } while (0)
-  if (d.grouped == 1) SUAVE_PAIR_SHAPES(1, kEpiMaskBwd, 2);
-  else if (d.epi == kEpiMaskBwd) SUAVE_PAIR_SHAPES(0, kEpiMaskBwd, 0);
-  else SUAVE_PAIR_SHAPES(0, kEpiBias, 0);
+  if (d.grouped == 1) SUAVE_PAIR_SHAPES(1, kEpiMaskBwd, 2, 0);
+  else if (d.epi == kEpiMaskBwd) {
+    if (sp == 3) SUAVE_PAIR_SHAPES(0, kEpiMaskBwd, 0, 3);
+    else SUAVE_PAIR_SHAPES(0, kEpiMaskBwd, 0, 0);
+  } else {
+    if (sp == 3) SUAVE_PAIR_SHAPES(0, kEpiBias, 0, 3);
+    else SUAVE_PAIR_SHAPES(0, kEpiBias, 0, 0);
+  }
 #undef SUAVE_PAIR_SHAPES
 #undef SUAVE_PAIR
   SUAVE_CHECK_HIP(hipGetLastError());
