@@ -434,7 +434,9 @@ def main():
         if prof and cnt[0] > 0:
             gemm_flops = gemm_flops_per_row(layout) * B * steps
             achieved = gemm_flops / (ms[0] * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (fp32 MFMA, all %d launches/step)" % (cnt[0] // steps),
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel / gemm_pair_kernel, all %d launches/step: k-major forms (weight "
+                                "gradients) on the exact-fp32 MFMA, row-major forms on the bf16 MFMA with a three-plane fp32 split "
+                                "(fp32-grade error); priced against the fp32 matrix peak" % (cnt[0] // steps),
                                 "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                                 "avg_launch_us": 1e3 * ms[0] / cnt[0],
