@@ -55,11 +55,17 @@ __device__ __forceinline__ uint32_t drop_row_hash(uint32_t key, uint32_t row_id)
 // The bf16 MFMA has its own pipe: the split arithmetic (VALU) runs beside it instead of taking its cycles, which
 // the f32 MFMA cannot offer (it executes on the SIMD's FMA lanes).  LDS image per plane: [row][16 k] bf16, 32 B
 // per row: a lane's MFMA fragment (row l & 31, k = 8 (l >> 5) ... + 7) is one ds_read_b128.
-constexpr int kSplitRowBytes = 2 * BK;
-template <int WAVES_M, int WAVES_N, int SPLIT = 0>
+//
+// k-major operands (weight gradients: element (i, k) at X[k * ld + i]) join through a register transpose: a
+// thread loads the float4 of rows k = 2g and 2g + 1 of one 4-feature group, so it owns a 4 x 2 block and writes,
+// per feature and plane, ONE 32-bit word (the two k's) at [feature][k pair].  Those kernels use 40-byte LDS rows:
+// the 32 lanes of a store then spread over 16 banks (2-way) instead of hitting one, and the fragment is two
+// conflict-free ds_read_b64 (40 is not a multiple of 16).
+constexpr int split_row_bytes(bool any_km) { return any_km ? 2 * BK + 8 : 2 * BK; }
+template <int WAVES_M, int WAVES_N, int SPLIT = 0, bool KM = false>
 constexpr int gemm_smem_floats() {
   constexpr int f32 = 2 * BK * ((WAVES_M * 64 + PAD) + (WAVES_N * 64 + PAD));
-  constexpr int spl = 2 * SPLIT * (WAVES_M * 64 + WAVES_N * 64) * kSplitRowBytes / 4;
+  constexpr int spl = 2 * SPLIT * (WAVES_M * 64 + WAVES_N * 64) * split_row_bytes(KM) / 4;
   return f32 > spl ? f32 : spl;
 }
 
@@ -80,7 +86,10 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4 (&p)[NS > 0 ? NS :
 // One block's work: tile `bid` of split `bz`.
 template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int GRP, int EPI, int SPLIT = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, const int bz, float* smem, int* perm_s) {
-  static_assert(SPLIT == 0 || (!A_KM && !B_KM), "split mode stages row-major operands only");
+  static_assert(SPLIT == 0 || (A_KM == B_KM && GRP != 2 && !(A_KM && (WAVES_M != 2 || WAVES_N != 2))),
+                "split mode: both operands row-major, or both k-major on the 128x128 tile");
+  constexpr int kSplitRowBytes = split_row_bytes(A_KM);
+  constexpr bool KM_SPLIT = SPLIT > 0 && A_KM;
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   constexpr int LDAS = BM + PAD, LDBS = BN + PAD;
   constexpr int NA = BM * BK / 4 / 256;  // float4 loads per thread for the A tile
@@ -155,7 +164,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
         if (GRP == 1) { ok = arow[p] >= 0 && gk < k_end; off = (size_t)arow[p] * a.lda + gk; }
         else { ok = gi < a.M && gk < k_end; off = (size_t)gi * a.lda + gk; }
       } else {
-        const int krow = idx / (BM / 4), iq = idx % (BM / 4);
+        // split mode: a thread takes k rows 2g, 2g + 1 of one feature group (its 4 x 2 register block)
+        const int krow = KM_SPLIT ? ((tid >> 5) * 2 + p) : idx / (BM / 4), iq = KM_SPLIT ? (tid & 31) : idx % (BM / 4);
         const int gk = k0 + krow, gi = m0 + iq * 4;
         if (GRP == 2) {
           const int sr = perm_s[min(gk - k_begin, kGroupRows - 1)];
@@ -177,7 +187,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
         if (GRP == 1) { ok = brow[p] >= 0 && gj < a.N && gk < k_end; off = (size_t)brow[p] * a.ldb + gk; }
         else { ok = gj < a.N && gk < k_end; off = (size_t)gj * a.ldb + gk; }
       } else {
-        const int krow = idx / (BN / 4), jq = idx % (BN / 4);
+        const int krow = KM_SPLIT ? ((tid >> 5) * 2 + p) : idx / (BN / 4), jq = KM_SPLIT ? (tid & 31) : idx % (BN / 4);
         const int gk = k0 + krow, gj = n0 + jq * 4;
         if (GRP == 1) {
           const int br = head_row(a.q0 + gk, comp, a.hK, a.hD, a.hldK, a.hldD);
@@ -198,7 +208,34 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
     return reinterpret_cast<unsigned char*>(smem) + (size_t)((buf * (SPLIT > 0 ? SPLIT : 1) + s) * (BM + BN)) * kSplitRowBytes;
   };
   auto store_tiles = [&](int k0, int buf, const float4 (&ra)[NA], const float4 (&rb)[NB], uint32_t okm) {
-    if constexpr (SPLIT > 0) {
+    if constexpr (KM_SPLIT) {
+      static_assert(!KM_SPLIT || (NA == 2 && NB == 2), "4 x 2 register blocks");
+      const int g = tid >> 5, fq = tid & 31;
+#pragma unroll
+      for (int op = 0; op < 2; ++op) {  // 0: A tile, 1: B tile
+        float4 v0 = op == 0 ? ra[0] : rb[0], v1 = op == 0 ? ra[1] : rb[1];
+        const bool ok0 = (okm >> (op == 0 ? 0 : 8)) & 1u, ok1 = (okm >> (op == 0 ? 1 : 9)) & 1u;  // k row inside [k0, k_end)
+        const int lim = op == 0 ? a.M - (m0 + fq * 4) : a.N - (n0 + fq * 4);                       // features inside the matrix
+        v0.x = (ok0 && lim > 0) ? v0.x : 0.f; v0.y = (ok0 && lim > 1) ? v0.y : 0.f;
+        v0.z = (ok0 && lim > 2) ? v0.z : 0.f; v0.w = (ok0 && lim > 3) ? v0.w : 0.f;
+        v1.x = (ok1 && lim > 0) ? v1.x : 0.f; v1.y = (ok1 && lim > 1) ? v1.y : 0.f;
+        v1.z = (ok1 && lim > 2) ? v1.z : 0.f; v1.w = (ok1 && lim > 3) ? v1.w : 0.f;
+        bf16x4 p0[SPLIT > 0 ? SPLIT : 1], p1[SPLIT > 0 ? SPLIT : 1];
+        split4<SPLIT>(v0, p0);
+        split4<SPLIT>(v1, p1);
+#pragma unroll
+        for (int s = 0; s < SPLIT; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            bf16x2 w2;
+            w2[0] = p0[s][e];
+            w2[1] = p1[s][e];
+            *reinterpret_cast<bf16x2*>(plane(buf, s) + (size_t)((op == 0 ? 0 : BM) + fq * 4 + e) * kSplitRowBytes + g * 4) = w2;
+          }
+      }
+      return;
+    } else if constexpr (SPLIT > 0) {
 #pragma unroll
       for (int p = 0; p < NA + NB; ++p) {
         const bool isA = p < NA;
@@ -294,8 +331,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
         for (int s = 0; s < SPLIT; ++s)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            fa[s][i] = *reinterpret_cast<const bf16x8*>(plane(buf, s) + (size_t)(wm * 64 + i * 32 + l31) * kSplitRowBytes + kh * 16);
-            fb[s][i] = *reinterpret_cast<const bf16x8*>(plane(buf, s) + (size_t)(BM + wn * 64 + i * 32 + l31) * kSplitRowBytes + kh * 16);
+            const unsigned char* pa = plane(buf, s) + (size_t)(wm * 64 + i * 32 + l31) * kSplitRowBytes + kh * 16;
+            const unsigned char* pb = plane(buf, s) + (size_t)(BM + wn * 64 + i * 32 + l31) * kSplitRowBytes + kh * 16;
+            if constexpr (KM_SPLIT) {  // 40-byte rows: two 8-byte reads
+              const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(pa), a1 = *reinterpret_cast<const bf16x4*>(pa + 8);
+              const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(pb), b1 = *reinterpret_cast<const bf16x4*>(pb + 8);
+              fa[s][i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+              fb[s][i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            } else {
+              fa[s][i] = *reinterpret_cast<const bf16x8*>(pa);
+              fb[s][i] = *reinterpret_cast<const bf16x8*>(pb);
+            }
           }
         constexpr int kPairs = SPLIT == 3 ? 6 : 3;
         constexpr int pa_[6] = {0, 0, 1, 1, 0, 2}, pb_[6] = {0, 1, 0, 1, 2, 0};
@@ -308,6 +354,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
           acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sa][1], fb[sb][0], acc[1][0], 0, 0, 0);
           acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sa][1], fb[sb][1], acc[1][1], 0, 0, 0);
         }
+      }
+      if (do_bias) {  // bias gradient = row sums of the A tile (dC^T): the three planes add back to the fp32 values
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < SPLIT; ++s) {
+          const unsigned char* pr = plane(buf, s) + (size_t)tid * kSplitRowBytes;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bf16x4 v = *reinterpret_cast<const bf16x4*>(pr + q * 8);
+            t += ((float)v[0] + (float)v[1]) + ((float)v[2] + (float)v[3]);
+          }
+        }
+        bias_acc += t;
       }
       return;
     }
@@ -476,7 +535,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
 
 template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int GRP, int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_kernel(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<WAVES_M, WAVES_N, SPLIT>()];
+  __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<WAVES_M, WAVES_N, SPLIT, A_KM>()];
   __shared__ int perm_s[GRP == 2 ? kGroupRows : 1];
   gemm_body<WAVES_M, WAVES_N, A_KM, B_KM, GRP, EPI, SPLIT>(a, blockIdx.x, blockIdx.z, smem, perm_s);
 }
@@ -486,12 +545,14 @@ __global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_kernel(GemmArgs a
 // blocks fill the rest of each CU.
 template <int DM, int DN, int D_GRP, int D_EPI, int WM, int WN, int W_GRP, int D_SPLIT = 0>
 __global__ __launch_bounds__(256) void gemm_pair_kernel(GemmArgs d, GemmArgs w, int w_blocks, int w_tiles) {
-  constexpr int kSmem = gemm_smem_floats<DM, DN, D_SPLIT>() > gemm_smem_floats<WM, WN>() ? gemm_smem_floats<DM, DN, D_SPLIT>()
-                                                                                         : gemm_smem_floats<WM, WN>();
+  // the weight-gradient half joins the split path on the 128x128 tile (ungrouped); otherwise exact fp32
+  constexpr int W_SPLIT = (D_SPLIT > 0 && WM == 2 && WN == 2 && W_GRP == 0) ? D_SPLIT : 0;
+  constexpr int kSmemW = gemm_smem_floats<WM, WN, W_SPLIT, true>();
+  constexpr int kSmem = gemm_smem_floats<DM, DN, D_SPLIT>() > kSmemW ? gemm_smem_floats<DM, DN, D_SPLIT>() : kSmemW;
   __shared__ __attribute__((aligned(16))) float smem[kSmem];
   __shared__ int perm_s[W_GRP == 2 ? kGroupRows : 1];
   const int b = blockIdx.x;
-  if (b < w_blocks) gemm_body<WM, WN, true, true, W_GRP, kEpiSlab>(w, b % w_tiles, b / w_tiles, smem, perm_s);
+  if (b < w_blocks) gemm_body<WM, WN, true, true, W_GRP, kEpiSlab, W_SPLIT>(w, b % w_tiles, b / w_tiles, smem, perm_s);
   else gemm_body<DM, DN, false, D_SPLIT == 0, D_GRP, D_EPI, D_SPLIT>(d, b - w_blocks, 0, smem, perm_s);  // split: row-major W^T
 }
 
@@ -499,8 +560,8 @@ __global__ __launch_bounds__(256) void gemm_pair_kernel(GemmArgs d, GemmArgs w, 
 // the ordinary tile body on that column's operands.
 template <int MODE, int SPLIT = 0>
 __global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_wide_kernel(WideGemmArgs w) {
-  static_assert(SPLIT == 0 || MODE == 0, "only the logits product has row-major operands");
-  __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<2, 2, SPLIT>()];
+  static_assert(SPLIT == 0 || MODE != 1, "the data gradient of the wide heads reads W k-major and A row-major: exact path");
+  __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<2, 2, SPLIT, MODE == 2>()];
   __shared__ int perm_s[1];
   const int tiles_m = MODE == 2 ? 1 : (w.rows + 127) / 128;
   const int q = blockIdx.x / tiles_m;
@@ -531,7 +592,7 @@ __global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_wide_kernel(WideG
     g.A = logit; g.B = slot; g.C = w.slab + (wc.w_off - w.wide_w0); g.M = wc.C - 1; g.N = wc.ldw; g.K = w.rows;
     g.lda = w.ldL; g.ldb = w.ldY; g.ldc = wc.ldw; g.a_kmajor = 1; g.b_kmajor = 1; g.epi = kEpiSlab;
     g.splits = w.splits; g.slab_stride = w.slab_stride;
-    gemm_body<2, 2, true, true, 0, kEpiSlab>(g, local, blockIdx.z, smem, perm_s);
+    gemm_body<2, 2, true, true, 0, kEpiSlab, SPLIT>(g, local, blockIdx.z, smem, perm_s);
   }
 }
 
@@ -552,6 +613,7 @@ int launch_gemm_wide(const WideGemmArgs& a, int mode, hipStream_t stream) {
   if (mode == 0 && split_mode() == 3) hipLaunchKernelGGL((gemm_wide_kernel<0, 3>), grid, block, 0, stream, a);
   else if (mode == 0) hipLaunchKernelGGL(gemm_wide_kernel<0>, grid, block, 0, stream, a);
   else if (mode == 1) hipLaunchKernelGGL(gemm_wide_kernel<1>, grid, block, 0, stream, a);
+  else if (split_mode() == 3) hipLaunchKernelGGL((gemm_wide_kernel<2, 3>), grid, block, 0, stream, a);
   else hipLaunchKernelGGL(gemm_wide_kernel<2>, grid, block, 0, stream, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
@@ -632,8 +694,10 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   else if (!a.a_kmajor && !a.b_kmajor && e == kEpiMaskBwd) SUAVE_GEMM_LAUNCH_RM(0, kEpiMaskBwd);
   else if (!a.a_kmajor && a.b_kmajor && e == kEpiBias) SUAVE_GEMM_LAUNCH(false, true, 0, kEpiBias);
   else if (!a.a_kmajor && a.b_kmajor && e == kEpiMaskBwd) SUAVE_GEMM_LAUNCH(false, true, 0, kEpiMaskBwd);
-  else if (a.a_kmajor && a.b_kmajor && e == kEpiSlab) SUAVE_GEMM_LAUNCH(true, true, 0, kEpiSlab);
-  else SUAVE_REQUIRE(false, "gemm: unsupported operand layout / epilogue combination");
+  else if (a.a_kmajor && a.b_kmajor && e == kEpiSlab) {
+    if (sp == 3 && !narrow) hipLaunchKernelGGL((gemm_kernel<2, 2, true, true, 0, kEpiSlab, 3>), grid, block, 0, stream, args);
+    else SUAVE_GEMM_LAUNCH(true, true, 0, kEpiSlab);
+  } else SUAVE_REQUIRE(false, "gemm: unsupported operand layout / epilogue combination");
 #undef SUAVE_GEMM_LAUNCH_RM
 #undef SUAVE_GEMM_LAUNCH
   SUAVE_CHECK_HIP(hipGetLastError());
