@@ -258,6 +258,17 @@ int suave_decode_params(const suave_plan* plan, const float* params, const float
                         const int32_t* component, int64_t n, int32_t col_index, void* workspace,
                         size_t workspace_bytes, void* stream, float* out_params);
 
+/* Arithmetic of the matrix products (no counterpart in the reference, which
+ * multiplies in fp32 through torch: suave/modules/encoder.py:49-53,
+ * decoder.py:300-318).  Mode 3 (default): every fp32 operand is cut into three
+ * bf16 planes and six plane products accumulate in fp32 on the bf16 MFMA --
+ * fp32-grade results.  Mode 0: the exact-fp32 MFMA
+ * everywhere.  Process-wide; the environment variable SUAVE_GEMM_SPLIT gives
+ * the initial value.  Do not switch while a call of this library is running on
+ * another thread. */
+int suave_gemm_arithmetic_set(int mode);
+int suave_gemm_arithmetic_get(int* mode);
+
 /* Measurement aid (no counterpart in the reference): when enabled, every kernel
  * launch of the library is bracketed by HIP events on its stream;
  * suave_profile_read synchronises and returns the summed device time (ms) and

@@ -1298,6 +1298,14 @@ extern "C" int suave_decode_sample(const suave_plan* p, const float* params, con
                              noise_exp, seed, row_offset, out_num, ld_num, out_codes, ld_disc, st);
 }
 
+extern "C" int suave_gemm_arithmetic_set(int mode) { return gemm_split_mode_set(mode); }
+
+extern "C" int suave_gemm_arithmetic_get(int* mode) {
+  SUAVE_REQUIRE(mode != nullptr, "gemm_arithmetic_get: null argument");
+  *mode = gemm_split_mode();
+  return 0;
+}
+
 extern "C" int suave_profile_enable(int on) {
   g_prof.enabled = on != 0;
   return 0;

@@ -253,6 +253,7 @@ struct WideGemmArgs {
 };
 int launch_gemm_wide(const WideGemmArgs& a, int mode, hipStream_t stream);
 int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t stream);
+int gemm_split_mode_set(int mode);  // 0 on success (suave_gemm_arithmetic)
 int gemm_split_mode();  // 0 exact-fp32 MFMA, 3 bf16 planes per operand on the row-major forms (gemm.hip)
 
 // ----- optional per-kernel-class timing with HIP events (suave_profile_*) -----

@@ -13,6 +13,7 @@
 // MFMA tiles, K step 16, LDS tiles stored k-major ([k][i]) so that the MFMA
 // operand fetch (lane l: i = l&31, k = l>>5) is a conflict-free ds_read_b32,
 // double-buffered with the next tile's global loads in flight during the MFMAs.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -645,19 +646,25 @@ inline bool gemm_narrow(const GemmArgs& a) { return a.N <= 64; }
 // everywhere).  Only the row-major forms have a split kernel.  A two-plane split (three products, 14 % faster on
 // the whole step) was measured and dropped: 5e-6 per GEMM on well-scaled data, but 5e-2 on the decoder weight
 // gradients of the std = 12 real columns, whose dY spans three decades within a row (scripts/split_accuracy.py).
-int split_mode() {
-  static const int mode = [] {
+std::atomic<int>& split_mode_cell() {
+  static std::atomic<int> mode{[] {
     const char* e = getenv("SUAVE_GEMM_SPLIT");
     return (e && atoi(e) == 0) ? 0 : 3;
-  }();
+  }()};
   return mode;
 }
+int split_mode() { return split_mode_cell().load(std::memory_order_relaxed); }
 inline int gemm_tiles(const GemmArgs& a) {
   return gemm_narrow(a) ? ((a.M + 255) / 256) * ((a.N + 63) / 64) : ((a.M + 127) / 128) * ((a.N + 127) / 128);
 }
 }  // namespace
 
 int gemm_split_mode() { return split_mode(); }
+int gemm_split_mode_set(int mode) {
+  SUAVE_REQUIRE(mode == 0 || mode == 3, "gemm: the arithmetic mode is 0 (exact-fp32 MFMA) or 3 (three bf16 planes)");
+  split_mode_cell().store(mode, std::memory_order_relaxed);
+  return 0;
+}
 
 int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   (void)n_cu;

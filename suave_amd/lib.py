@@ -29,6 +29,8 @@ EXPORTS = (
     "suave_posterior_draws",
     "suave_head_params_width",
     "suave_decode_params",
+    "suave_gemm_arithmetic_set",
+    "suave_gemm_arithmetic_get",
     "suave_profile_enable",
     "suave_profile_read",
 )
@@ -75,6 +77,8 @@ def load():
     lib.suave_posterior_draws.argtypes = [vp, vp, i64, i32, vp, vp, u64, i64, vp, vp, vp]
     lib.suave_head_params_width.argtypes = [vp, i32, C.POINTER(i32)]
     lib.suave_decode_params.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, sz, vp, vp]
+    lib.suave_gemm_arithmetic_set.argtypes = [C.c_int]
+    lib.suave_gemm_arithmetic_get.argtypes = [C.POINTER(C.c_int)]
     lib.suave_profile_enable.argtypes = [C.c_int]
     lib.suave_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i64), i32]
     for name in EXPORTS:

@@ -284,3 +284,31 @@ def test_forward_only_matches_backward_outputs():
     assert rel_err(res["reconstruction"].cpu().numpy(), fx["out/reconstruction"]) < TOL
     assert rel_err(res["categorical_kl"].cpu().numpy(), fx["out/categorical_kl"]) < TOL
     assert rel_err(res["gaussian_kl"].cpu().numpy(), fx["out/gaussian_kl"]) < TOL
+
+
+@pytest.mark.parametrize("case", ["s64", "golden_sup", "golden_unsup", "w1024_mini"])
+def test_exact_fp32_arithmetic_matches_oracle(case):
+    """Same parity checks with the matrix products on the exact-fp32 MFMA (suave_gemm_arithmetic_set(0));
+    every other test of this suite runs the default three-plane bf16 split (mode 3)."""
+
+    import ctypes as C
+
+    from suave_amd import lib as slib
+
+    L = slib.load()
+    before = C.c_int(-1)
+    slib.check(L.suave_gemm_arithmetic_get(C.byref(before)), "suave_gemm_arithmetic_get")
+    assert before.value == 3
+    assert L.suave_gemm_arithmetic_set(2) != 0  # only 0 and 3 exist
+    slib.check(L.suave_gemm_arithmetic_set(0), "suave_gemm_arithmetic_set")
+    try:
+        if case == "s64":
+            test_s64_step_matches_oracle(4096, 0.1)
+        elif case == "golden_sup":
+            test_golden_supervised_step("elbo_sup_mixed12_drop")
+        elif case == "golden_unsup":
+            test_golden_unsupervised_step(UNSUP[0])
+        else:
+            test_w1024_miniature_step_matches_oracle("supervised")
+    finally:
+        slib.check(L.suave_gemm_arithmetic_set(before.value), "suave_gemm_arithmetic_set")
