@@ -4,6 +4,8 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from suave_amd import lib as _lib
+if os.environ.get("SUAVE_LIB"):  # ablation builds (tuning only)
+    _lib._LIB_PATH = os.environ["SUAVE_LIB"]
 L = _lib.load()
 f = L.suave_debug_gemm
 vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
@@ -25,7 +27,7 @@ def run(name, M, N, K, akm, bkm, epi, splits=1, drop=0.0, check=False):
     H = torch.randn(M, ldc, device=dev)
     s = torch.cuda.current_stream().cuda_stream
     def call():
-        rc = f(A.data_ptr(), Bm.data_ptr(), C.data_ptr(), bias.data_ptr(), H.data_ptr(), M, N, K, lda, ldb, ldc,
+        rc = f(A.data_ptr(), Bm.data_ptr(), C.data_ptr(), bias.data_ptr(), H.data_ptr() if epi == 2 else None, M, N, K, lda, ldb, ldc,
                int(akm), int(bkm), epi, splits, drop, s)
         assert rc == 0, L.suave_last_error()
     for _ in range(3):

@@ -16,6 +16,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 
@@ -208,7 +209,26 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   auto plane = [&](int buf, int s) {
     return reinterpret_cast<unsigned char*>(smem) + (size_t)((buf * (SPLIT > 0 ? SPLIT : 1) + s) * (BM + BN)) * kSplitRowBytes;
   };
-  auto store_tiles = [&](int k0, int buf, const float4 (&ra)[NA], const float4 (&rb)[NB], uint32_t okm) {
+  // `masked` (std::true_type / std::false_type, split paths only): false skips the zero-fill selects.  Zeros are only
+  // owed past k_end (both operands: garbage there would reach every output) and, in the grouped form, in the rows of
+  // absent heads; a tile row or feature outside the matrix only feeds outputs the epilogue never writes.  The main
+  // loop stores its full K steps unmasked (40 of 146 VALU per step less).
+  auto store_tiles = [&](int k0, int buf, float4 (&ra)[NA], float4 (&rb)[NB], uint32_t okm, auto masked) {
+    constexpr bool kMasked = decltype(masked)::value;
+    if constexpr (SPLIT > 0) {
+      // Keep every loaded float4 one whole register tuple until this point: without it the compiler copies single
+      // elements out right behind the loads (before the barrier and the MFMAs) and waits for the loads there.
+      auto pin = [](float4& v) {
+        typedef float f32x4n __attribute__((ext_vector_type(4)));
+        f32x4n t = {v.x, v.y, v.z, v.w};
+        asm volatile("" : "+v"(t));
+        v = make_float4(t[0], t[1], t[2], t[3]);
+      };
+#pragma unroll
+      for (int p = 0; p < NA; ++p) pin(ra[p]);
+#pragma unroll
+      for (int p = 0; p < NB; ++p) pin(rb[p]);
+    }
     if constexpr (KM_SPLIT) {
       static_assert(!KM_SPLIT || (NA == 2 && NB == 2), "4 x 2 register blocks");
       const int g = tid >> 5, fq = tid & 31;
@@ -217,10 +237,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
         float4 v0 = op == 0 ? ra[0] : rb[0], v1 = op == 0 ? ra[1] : rb[1];
         const bool ok0 = (okm >> (op == 0 ? 0 : 8)) & 1u, ok1 = (okm >> (op == 0 ? 1 : 9)) & 1u;  // k row inside [k0, k_end)
         const int lim = op == 0 ? a.M - (m0 + fq * 4) : a.N - (n0 + fq * 4);                       // features inside the matrix
-        v0.x = (ok0 && lim > 0) ? v0.x : 0.f; v0.y = (ok0 && lim > 1) ? v0.y : 0.f;
-        v0.z = (ok0 && lim > 2) ? v0.z : 0.f; v0.w = (ok0 && lim > 3) ? v0.w : 0.f;
-        v1.x = (ok1 && lim > 0) ? v1.x : 0.f; v1.y = (ok1 && lim > 1) ? v1.y : 0.f;
-        v1.z = (ok1 && lim > 2) ? v1.z : 0.f; v1.w = (ok1 && lim > 3) ? v1.w : 0.f;
+        if constexpr (kMasked) {
+          v0.x = (ok0 && lim > 0) ? v0.x : 0.f; v0.y = (ok0 && lim > 1) ? v0.y : 0.f;
+          v0.z = (ok0 && lim > 2) ? v0.z : 0.f; v0.w = (ok0 && lim > 3) ? v0.w : 0.f;
+          v1.x = (ok1 && lim > 0) ? v1.x : 0.f; v1.y = (ok1 && lim > 1) ? v1.y : 0.f;
+          v1.z = (ok1 && lim > 2) ? v1.z : 0.f; v1.w = (ok1 && lim > 3) ? v1.w : 0.f;
+        }
         bf16x4 p0[SPLIT > 0 ? SPLIT : 1], p1[SPLIT > 0 ? SPLIT : 1];
         split4<SPLIT>(v0, p0);
         split4<SPLIT>(v1, p1);
@@ -237,24 +259,31 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
       }
       return;
     } else if constexpr (SPLIT > 0) {
+      {
 #pragma unroll
-      for (int p = 0; p < NA + NB; ++p) {
-        const bool isA = p < NA;
-        const int q = isA ? p : p - NA;
-        const int idx = tid + q * 256;
-        const int row = idx >> 2, kq = idx & 3;
-        int lim = k_end - (k0 + kq * 4);
-        if (!((okm >> (isA ? q : 8 + q)) & 1u)) lim = 0;
-        float4 v = isA ? ra[q] : rb[q];
-        v.x = lim > 0 ? v.x : 0.f;
-        v.y = lim > 1 ? v.y : 0.f;
-        v.z = lim > 2 ? v.z : 0.f;
-        v.w = lim > 3 ? v.w : 0.f;
-        bf16x4 pl[SPLIT > 0 ? SPLIT : 1];
-        split4<SPLIT>(v, pl);
+        for (int p = 0; p < NA + NB; ++p) {
+          const bool isA = p < NA;
+          const int q = isA ? p : p - NA;
+          const int idx = tid + q * 256;
+          const int row = idx >> 2, kq = idx & 3;
+          float4 v = isA ? ra[q] : rb[q];
+          if constexpr (kMasked) {
+            int lim = k_end - (k0 + kq * 4);
+            if (!((okm >> (isA ? q : 8 + q)) & 1u)) lim = 0;
+            v.x = lim > 0 ? v.x : 0.f;
+            v.y = lim > 1 ? v.y : 0.f;
+            v.z = lim > 2 ? v.z : 0.f;
+            v.w = lim > 3 ? v.w : 0.f;
+          }
+          bf16x4 pl[SPLIT > 0 ? SPLIT : 1];
+          split4<SPLIT>(v, pl);
+          // the 16-byte halves of a row swap places in every second group of 8 rows: the 16 lanes one ds_read_b128
+          // cycle serves (rows 0-3, 12-15, 20-27 / 4-11, 16-19, 28-31) then cover all 64 banks
+          const int kbyte = (((kq >> 1) ^ ((row >> 3) & 1)) << 4) | ((kq & 1) << 3);
 #pragma unroll
-        for (int s = 0; s < SPLIT; ++s)
-          *reinterpret_cast<bf16x4*>(plane(buf, s) + (size_t)((isA ? 0 : BM) + row) * kSplitRowBytes + kq * 8) = pl[s];
+          for (int s = 0; s < SPLIT; ++s)
+            *reinterpret_cast<bf16x4*>(plane(buf, s) + (size_t)((isA ? 0 : BM) + row) * kSplitRowBytes + kbyte) = pl[s];
+        }
       }
       return;
     }
@@ -323,7 +352,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   // One K step on LDS buffer `buf`; operand fragments of step kk+1 are fetched before the MFMAs of kk.
   auto compute = [&](int buf) {
     if constexpr (SPLIT > 0) {
-      if (act) {
+      {  // (no `act` test here: a wave outside the matrix multiplies tiles nobody stores; its block waits at the
+         // barrier for the other waves anyway, and the K step stays one basic block the scheduler can interleave)
         bf16x8 fa[SPLIT > 0 ? SPLIT : 1][2], fb[SPLIT > 0 ? SPLIT : 1][2];
         // fragments are fetched plane by plane and the plane products run in the order hi*hi, hi*mid, mid*hi,
         // mid*mid, hi*lo, lo*hi: the first MFMAs wait for four ds_read_b128 only, the rest of the fetch lands
@@ -332,8 +362,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
         for (int s = 0; s < SPLIT; ++s)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const unsigned char* pa = plane(buf, s) + (size_t)(wm * 64 + i * 32 + l31) * kSplitRowBytes + kh * 16;
-            const unsigned char* pb = plane(buf, s) + (size_t)(BM + wn * 64 + i * 32 + l31) * kSplitRowBytes + kh * 16;
+            // row-major tiles: halves swapped per 8-row group (store_tiles); l31 >> 3 is the row's group parity
+            const int hoff = (KM_SPLIT ? kh : (kh ^ ((l31 >> 3) & 1))) * 16;
+            const unsigned char* pa = plane(buf, s) + (size_t)(wm * 64 + i * 32 + l31) * kSplitRowBytes + hoff;
+            const unsigned char* pb = plane(buf, s) + (size_t)(BM + wn * 64 + i * 32 + l31) * kSplitRowBytes + hoff;
             if constexpr (KM_SPLIT) {  // 40-byte rows: two 8-byte reads
               const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(pa), a1 = *reinterpret_cast<const bf16x4*>(pa + 8);
               const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(pb), b1 = *reinterpret_cast<const bf16x4*>(pb + 8);
@@ -405,23 +437,60 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   // Tiles past the end load nothing real and store zeros into a buffer nobody multiplies.
   float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
   uint32_t ok0 = 0, ok1 = 0;
+  if constexpr (SPLIT > 0) {
+    // Split path: LDS ping-pong, two register sets (while tile t is multiplied out of LDS, the loads of tiles t+1
+    // and t+2 are in flight).  The main loop only stores full K steps, unmasked; each half of its body is one
+    // basic block (ds_read, 24 MFMAs, the plane split of the next tile, ds_write, global loads, barrier).  The
+    // tail (partial last step, grouped form) runs the same pipeline with masked stores.
+    constexpr std::true_type kMask{};
+    constexpr std::false_type kNoMask{};
+    const int nfull = GRP != 0 ? 0 : (k_end - k_begin) / BK;  // tiles 0 .. nfull-1 lie entirely inside [k_begin, k_end)
+    load_tiles(k_begin, ra0, rb0, ok0);
+    store_tiles(k_begin, 0, ra0, rb0, ok0, kMask);
+    load_tiles(k_begin + BK, ra0, rb0, ok0);
+    load_tiles(k_begin + 2 * BK, ra1, rb1, ok1);
+    __syncthreads();
+    int t = 0;
+    for (; t + 2 < nfull; t += 2) {
+      compute(0);
+      store_tiles(k_begin + (t + 1) * BK, 1, ra0, rb0, ok0, kNoMask);
+      load_tiles(k_begin + (t + 3) * BK, ra0, rb0, ok0);
+      __syncthreads();
+      compute(1);
+      store_tiles(k_begin + (t + 2) * BK, 0, ra1, rb1, ok1, kNoMask);
+      load_tiles(k_begin + (t + 4) * BK, ra1, rb1, ok1);
+      __syncthreads();
+    }
+    for (; t + 1 < nk; t += 2) {
+      compute(0);
+      store_tiles(k_begin + (t + 1) * BK, 1, ra0, rb0, ok0, kMask);
+      load_tiles(k_begin + (t + 3) * BK, ra0, rb0, ok0);
+      __syncthreads();
+      compute(1);
+      store_tiles(k_begin + (t + 2) * BK, 0, ra1, rb1, ok1, kMask);
+      load_tiles(k_begin + (t + 4) * BK, ra1, rb1, ok1);
+      __syncthreads();
+    }
+    if (t < nk) compute(0);
+  } else {
   load_tiles(k_begin, ra0, rb0, ok0);
-  store_tiles(k_begin, 0, ra0, rb0, ok0);
+  store_tiles(k_begin, 0, ra0, rb0, ok0, std::true_type{});
   load_tiles(k_begin + BK, ra0, rb0, ok0);
   load_tiles(k_begin + 2 * BK, ra1, rb1, ok1);
   __syncthreads();
   int t = 0;
   for (; t + 1 < nk; t += 2) {
     compute(0);
-    store_tiles(k_begin + (t + 1) * BK, 1, ra0, rb0, ok0);
+    store_tiles(k_begin + (t + 1) * BK, 1, ra0, rb0, ok0, std::true_type{});
     load_tiles(k_begin + (t + 3) * BK, ra0, rb0, ok0);
     __syncthreads();
     compute(1);
-    store_tiles(k_begin + (t + 2) * BK, 0, ra1, rb1, ok1);
+    store_tiles(k_begin + (t + 2) * BK, 0, ra1, rb1, ok1, std::true_type{});
     load_tiles(k_begin + (t + 4) * BK, ra1, rb1, ok1);
     __syncthreads();
   }
   if (t < nk) compute(0);
+  }
 
   // ---- epilogue -------------------------------------------------------------
   // The accumulators (lane = column, 4 consecutive rows per register group) go through a per-wave LDS
