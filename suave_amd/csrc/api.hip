@@ -134,7 +134,8 @@ struct Carver {
 int tn_splits(const suave_plan* p, int n_out, int n_in1, int64_t rows) {
   const bool narrow = n_in1 <= 64;
   const int tiles = narrow ? ((n_out + 255) / 256) * ((n_in1 + 63) / 64) : ((n_out + 127) / 128) * ((n_in1 + 127) / 128);
-  int64_t s = ((int64_t)p->n_cu + tiles - 1) / tiles;
+  static const int factor = [] { const char* e = getenv("SUAVE_TN_FACTOR"); return e ? std::max(1, atoi(e)) : 1; }();
+  int64_t s = (factor * (int64_t)p->n_cu + tiles - 1) / tiles;
   s = std::min<int64_t>(s, std::max<int64_t>(1, rows / 256));
   return (int)std::max<int64_t>(1, std::min<int64_t>(s, 512));
 }
