@@ -953,6 +953,7 @@ using namespace suave;
 extern "C" const char* suave_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* cols, suave_plan** out) {
+  suave::drop_stale_hip_error();
   SUAVE_REQUIRE(model && cols && out, "plan_create: null argument");
   const suave_model_t& m = *model;
   SUAVE_REQUIRE(m.n_cols > 0 && m.n_cols < 16384, "plan_create: 1..16383 columns");
@@ -1224,6 +1225,7 @@ extern "C" int suave_elbo_forward(const suave_plan* plan, const float* params, c
                                   const suave_noise_t* noise, float beta_scale, float tau, int training,
                                   void* workspace, size_t workspace_bytes, void* stream,
                                   const suave_elbo_out_t* out) {
+  suave::drop_stale_hip_error();
   return elbo_impl(plan, params, batch, noise, beta_scale, tau, training, batch ? std::max(batch->n_rows, 1) : 1,
                    workspace, workspace_bytes, static_cast<hipStream_t>(stream), out, nullptr, nullptr);
 }
@@ -1232,6 +1234,7 @@ extern "C" int suave_elbo_backward(const suave_plan* plan, const float* params, 
                                    const suave_noise_t* noise, float beta_scale, float tau, int64_t global_rows,
                                    void* workspace, size_t workspace_bytes, void* stream,
                                    const suave_elbo_out_t* out, float* grads, const float* dlatent) {
+  suave::drop_stale_hip_error();
   SUAVE_REQUIRE(grads != nullptr, "elbo_backward: grads is null");
   return elbo_impl(plan, params, batch, noise, beta_scale, tau, 1, global_rows, workspace, workspace_bytes,
                    static_cast<hipStream_t>(stream), out, grads, dlatent);
@@ -1240,6 +1243,7 @@ extern "C" int suave_elbo_backward(const suave_plan* plan, const float* params, 
 extern "C" int suave_encode(const suave_plan* p, const float* params, const suave_batch_t* batch,
                             float inv_temperature, void* workspace, size_t workspace_bytes, void* stream,
                             float* enc_out, float* post_mean, float* post_logvar, float* probs) {
+  suave::drop_stale_hip_error();
   SUAVE_REQUIRE(p != nullptr && params != nullptr, "plan/params is null");
   if (int rc = check_batch(p, batch)) return rc;
   const suave_model_t& m = p->model;
@@ -1265,6 +1269,7 @@ extern "C" int suave_decode_sample(const suave_plan* p, const float* params, con
                                    int64_t row_offset, void* workspace, size_t workspace_bytes, void* stream,
                                    float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc,
                                    float* y_full_out) {
+  suave::drop_stale_hip_error();
   SUAVE_REQUIRE(p && params, "decode_sample: null plan/params");
   const suave_model_t& m = p->model;
   SUAVE_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "decode_sample: row count out of range");
@@ -1344,6 +1349,7 @@ extern "C" int suave_head_params_width(const suave_plan* p, int32_t col_index, i
 extern "C" int suave_decode_params(const suave_plan* p, const float* params, const float* z, const float* s_dense,
                                    const int32_t* component, int64_t n, int32_t col_index, void* workspace,
                                    size_t workspace_bytes, void* stream, float* out_params) {
+  suave::drop_stale_hip_error();
   SUAVE_REQUIRE(p && params, "decode_params: null plan/params");
   SUAVE_REQUIRE(col_index >= 0 && col_index < p->model.n_cols, "decode_params: column out of range");
   SUAVE_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "decode_params: row count out of range");

@@ -11,6 +11,11 @@ namespace suave {
 
 void set_error(const std::string& msg);
 
+// hipGetLastError() is sticky per thread: an error left behind by the caller's own earlier HIP calls (seen with a
+// freshly initialised torch: hipErrorNoDevice from a probe) would otherwise fail this library's first launch check.
+// Every compute entry point drops it on entry.
+inline void drop_stale_hip_error() { (void)hipGetLastError(); }
+
 #define SUAVE_CHECK_HIP(expr)                                                              \
   do {                                                                                     \
     hipError_t _e = (expr);                                                                \

@@ -830,6 +830,7 @@ int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t
 extern "C" int suave_debug_gemm(const float* A, const float* B, float* C, const float* bias, const float* H, int M, int N,
                                 int K, int lda, int ldb, int ldc, int a_kmajor, int b_kmajor, int epi, int splits,
                                 float drop_p, void* stream) {
+  suave::drop_stale_hip_error();
   suave::GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.H = H;

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
 extern "C" int suave_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                const int32_t* group_begin_host, const float* lr_host, int32_t n_groups,
                                int64_t step_t, float beta1, float beta2, float eps, void* stream) {
+  suave::drop_stale_hip_error();
   using namespace suave;
   SUAVE_REQUIRE(n_groups >= 1 && n_groups <= kMaxGroups, "adam: 1..8 learning-rate groups");
   SUAVE_REQUIRE(step_t >= 1, "adam: step count is 1-based");

@@ -529,6 +529,7 @@ using namespace suave;
 extern "C" int suave_prior_latents(const suave_plan* p, const float* params, const float* cdf, const float* u,
                                    const float* eps, uint64_t seed, int64_t row_offset, int64_t n, void* stream,
                                    float* z, int32_t* component) {
+  suave::drop_stale_hip_error();
   SUAVE_REQUIRE(p && params, "prior_latents: null plan/params");
   if (n <= 0) return 0;  // empty request: nothing to read or write, buffers may be null
   SUAVE_REQUIRE(cdf && z && component, "prior_latents: null argument");
@@ -549,6 +550,7 @@ extern "C" int suave_conditional_latents(const suave_plan* p, const int64_t* cla
                                          const float* train_logvar, const float* u_row, const float* e_comp,
                                          const float* eps, uint64_t seed, int64_t row_offset, int64_t n, void* stream,
                                          float* z, int32_t* component) {
+  suave::drop_stale_hip_error();
   SUAVE_REQUIRE(p, "conditional_latents: null plan");
   if (n <= 0) return 0;  // empty request: buffers may be null
   SUAVE_REQUIRE(class_offsets && class_rows && labels && train_probs && train_mu && train_logvar && z && component,
@@ -567,6 +569,7 @@ extern "C" int suave_conditional_latents(const suave_plan* p, const int64_t* cla
 extern "C" int suave_posterior_draws(const suave_plan* p, const float* enc_out, int64_t n_rows, int32_t n_draws,
                                      const float* e, const float* eps, uint64_t seed, int64_t row_offset, void* stream,
                                      float* z, int32_t* component) {
+  suave::drop_stale_hip_error();
   SUAVE_REQUIRE(p, "posterior_draws: null plan");
   SUAVE_REQUIRE(n_draws >= 1, "posterior_draws: L must be a positive integer");  // model.py:3313-3314
   SUAVE_REQUIRE(n_rows >= 0 && n_rows * (int64_t)n_draws < (int64_t(1) << 31), "posterior_draws: too many rows");

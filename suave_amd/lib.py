@@ -55,6 +55,12 @@ def load():
             f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or suave_amd/csrc/build.sh). There is no CPU fallback."
         )
+    # PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so).  The device pointers and streams this library
+    # is handed come from torch, so both must bind to the SAME runtime: import torch first, then the soname of
+    # libsuave_hip.so's dependency resolves to the copy already in the process.  Loaded the other way round the
+    # process holds two runtimes and every launch here fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
+
     lib = C.CDLL(_LIB_PATH)
     missing = [name for name in EXPORTS if not hasattr(lib, name)]
     if missing:
