@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from suave_amd import lib as _lib
+if os.environ.get("SUAVE_LIB"):
+    _lib._LIB_PATH = os.environ["SUAVE_LIB"]
 L = _lib.load()
 sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-profile"]
 out = (ctypes.c_ulonglong * 16)()

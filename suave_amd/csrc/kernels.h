@@ -21,7 +21,7 @@ struct LossArgs {
   int K, D, ldY, ldy, ldK, ldD, ldE, ldT;
   int max_classes;
   float* recon_part;   // [n_chunks, n_rows]
-  float* ds_part;      // [n_chunks, n_rows, ldK]
+  float* ds_part;      // [n_chunks, ldK, n_rows]  (plane-major)
   int do_kl;
   const float* encout;  // KL phase: compact head buffer sel[n_rows, ldE] (see LatentFwdArgs), ldE = ldK + 2*ldD
   int prior_logits_off, prior_mu_off, prior_logvar_off;
@@ -104,7 +104,7 @@ struct LatentBwdArgs {
   const int32_t* kidx;
   const float* eps_buf;
   const float* dz;         // [B, ldD]
-  const float* ds_part;    // [n_chunks, B, ldK]
+  const float* ds_part;    // [n_chunks, ldK, B]  (plane-major)
   const float* gkl_logit;  // [B, ldK]  d loss/d logits from the categorical KL
   const float* gkl_mu;     // [B, ldD]
   const float* gkl_lv;     // [B, ldD]
@@ -182,7 +182,7 @@ struct WideRowArgs {
   const int32_t* cells; // tile-transposed packed cells (k_expand)
   int n_cols;
   float* recon_out;     // [n_rows]
-  float* ds_out;        // [n_rows, ldK] or null
+  float* ds_out;        // [ldK, n_rows] (plane-major) or null
   double* sums_slab;    // [grid, 4] or null
 };
 int launch_wide_fill(const WideRowArgs& a, hipStream_t s);

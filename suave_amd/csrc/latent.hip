@@ -358,26 +358,32 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
 // Straight-through Gumbel path + the selected component's mu / logvar gradients in the compact head
 // layout: every other entry of d(enc_out) is zero and is never materialised.
 __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
-  __shared__ float ds_s[64 * SUAVE_MAX_COMPONENTS];
-  __shared__ float ys_s[64 * SUAVE_MAX_COMPONENTS];
+  constexpr int kDsStride = SUAVE_MAX_COMPONENTS + 1;  // odd stride: lane = row accesses hit distinct banks
+  __shared__ float ds_s[64 * kDsStride];
+  __shared__ float ys_s[64 * kDsStride];
   __shared__ float inner_s[64];
   const int tid = threadIdx.x;
   const int K = a.K;
   for (int r0 = blockIdx.x * 64; r0 < a.n_rows; r0 += gridDim.x * 64) {
     const int nrows = min(64, a.n_rows - r0);
     __syncthreads();
+    // ds_part is plane-major [chunk][j][row]: lane = row within a plane (coalesced), chunks summed in fixed order
+    for (int idx = tid; idx < 64 * K; idx += 256) {
+      const int j = idx >> 6, lr = idx & 63;
+      if (lr < nrows) {
+        float v = 0.f;
+        for (int c = 0; c < a.n_chunks; ++c) v += a.ds_part[((size_t)c * a.ldK + j) * a.n_rows + r0 + lr];
+        ds_s[lr * kDsStride + j] = v;
+      }
+    }
     for (int idx = tid; idx < nrows * K; idx += 256) {
       const int lr = idx / K, j = idx - lr * K;
-      const int r = r0 + lr;
-      float v = 0.f;
-      for (int c = 0; c < a.n_chunks; ++c) v += a.ds_part[((size_t)c * a.n_rows + r) * a.ldK + j];
-      ds_s[lr * SUAVE_MAX_COMPONENTS + j] = v;
-      ys_s[lr * SUAVE_MAX_COMPONENTS + j] = a.ysoft[(size_t)r * a.ldK + j];
+      ys_s[lr * kDsStride + j] = a.ysoft[(size_t)(r0 + lr) * a.ldK + j];
     }
     __syncthreads();
     if (tid < nrows) {
       float inner = 0.f;
-      for (int j = 0; j < K; ++j) inner += ys_s[tid * SUAVE_MAX_COMPONENTS + j] * ds_s[tid * SUAVE_MAX_COMPONENTS + j];
+      for (int j = 0; j < K; ++j) inner += ys_s[tid * kDsStride + j] * ds_s[tid * kDsStride + j];
       inner_s[tid] = inner;
     }
     __syncthreads();
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (q + e < K)
-            v[e] = ys_s[lr * SUAVE_MAX_COMPONENTS + q + e] * (ds_s[lr * SUAVE_MAX_COMPONENTS + q + e] - inner_s[lr]) * inv_tau + g4[e];
+            v[e] = ys_s[lr * kDsStride + q + e] * (ds_s[lr * kDsStride + q + e] - inner_s[lr]) * inv_tau + g4[e];
       } else {
         const int c = q - a.ldK;
         const bool is_lv = c >= a.ldD;

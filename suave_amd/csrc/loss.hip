@@ -380,10 +380,12 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
     LOSS_ACC(15, t2a - t2);
 #endif
     if (GRAD && a.ds_part && valid) {
-      float* dst = a.ds_part + ((size_t)chunk_id * a.n_rows + r0 + lane) * a.ldK;
+      // plane-major [chunk][j][row]: lane = row, so every store instruction writes 256 contiguous bytes (the
+      // row-major layout scattered 64 x 4 bytes at a 48-byte stride, 15 % of the kernel's time)
+      float* dst = a.ds_part + (size_t)chunk_id * a.ldK * a.n_rows + r0 + lane;
 #pragma unroll
       for (int j = 0; j < KMAX; ++j)
-        if (j < K) dst[j] = ds[j];
+        if (j < K) dst[(size_t)j * a.n_rows] = ds[j];
     }
 #ifdef SUAVE_LOSS_TIMING
     LOSS_T(t2b);

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_wide_ds(WideRowArgs a) {
       t += *p;
       *p = 0.f;
     }
-    if (a.ds_out) a.ds_out[(size_t)r * a.ldK + j] = t;
+    if (a.ds_out) a.ds_out[(size_t)j * a.n_rows + r] = t;  // plane-major [j][row], as the likelihood kernel's chunks
   }
 }
 

@@ -11,7 +11,8 @@ import os
 
 from .plan import BatchT, ColT, ElboOutT, ModelT, NoiseT
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsuave_hip.so")
+# SUAVE_HIP_LIB points at another build of the same library (tuning builds under build/); default: the in-tree one
+_LIB_PATH = os.environ.get("SUAVE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsuave_hip.so")
 _lib = None
 
 EXPORTS = (
