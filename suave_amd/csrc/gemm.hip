@@ -71,6 +71,16 @@ constexpr int gemm_smem_floats() {
   return f32 > spl ? f32 : spl;
 }
 
+// ds_read_b64_tr_b16: per 16-lane group a block of 4 rows x 16 columns of 16-bit elements comes back column-major:
+// lane 4q+p supplies the address of row q, columns 4p..4p+3; lane i receives column i, row q in element q.
+// (Needs EXEC all ones and an 8-byte aligned address.)
+__device__ __forceinline__ bf16x4 lds_read_tr16(const unsigned char* p) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  // the low 32 bits of a generic pointer into LDS are the LDS offset
+  return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(uint32_t)(uintptr_t)p));
+}
+
 template <int NS>
 __device__ __forceinline__ void split4(const float4 v, bf16x4 (&p)[NS > 0 ? NS : 1]) {
   float r[4] = {v.x, v.y, v.z, v.w};
@@ -93,6 +103,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   constexpr int kSplitRowBytes = split_row_bytes(A_KM);
   constexpr bool KM_SPLIT = SPLIT > 0 && A_KM;
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+  constexpr int kKmRowBytes = 2 * BM + 64;  // k-major split tiles: one k row of BM bf16 features + 64 bytes
+  static_assert(!KM_SPLIT || 2 * BK * kKmRowBytes == (BM + BN) * kSplitRowBytes, "plane size of the k-major image");
   constexpr int LDAS = BM + PAD, LDBS = BN + PAD;
   constexpr int NA = BM * BK / 4 / 256;  // float4 loads per thread for the A tile
   constexpr int NB = BN * BK / 4 / 256;
@@ -167,7 +179,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
         else { ok = gi < a.M && gk < k_end; off = (size_t)gi * a.lda + gk; }
       } else {
         // split mode: a thread takes k rows 2g, 2g + 1 of one feature group (its 4 x 2 register block)
-        const int krow = KM_SPLIT ? ((tid >> 5) * 2 + p) : idx / (BM / 4), iq = KM_SPLIT ? (tid & 31) : idx % (BM / 4);
+        const int krow = idx / (BM / 4), iq = idx % (BM / 4);
         const int gk = k0 + krow, gi = m0 + iq * 4;
         if (GRP == 2) {
           const int sr = perm_s[min(gk - k_begin, kGroupRows - 1)];
@@ -189,7 +201,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
         if (GRP == 1) { ok = brow[p] >= 0 && gj < a.N && gk < k_end; off = (size_t)brow[p] * a.ldb + gk; }
         else { ok = gj < a.N && gk < k_end; off = (size_t)gj * a.ldb + gk; }
       } else {
-        const int krow = KM_SPLIT ? ((tid >> 5) * 2 + p) : idx / (BN / 4), jq = KM_SPLIT ? (tid & 31) : idx % (BN / 4);
+        const int krow = idx / (BN / 4), jq = idx % (BN / 4);
         const int gk = k0 + krow, gj = n0 + jq * 4;
         if (GRP == 1) {
           const int br = head_row(a.q0 + gk, comp, a.hK, a.hD, a.hldK, a.hldD);
@@ -230,32 +242,31 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
       for (int p = 0; p < NB; ++p) pin(rb[p]);
     }
     if constexpr (KM_SPLIT) {
-      static_assert(!KM_SPLIT || (NA == 2 && NB == 2), "4 x 2 register blocks");
-      const int g = tid >> 5, fq = tid & 31;
+      // k-major tiles stay k-major in LDS: plane image [16 k][128 features] bf16, rows 320 bytes apart (256 + 64:
+      // the four k rows one transposed read touches land on disjoint 16-bank windows); a thread stores the 4
+      // features of its float4 with one ds_write_b64 per plane, and compute() transposes on the way out with
+      // ds_read_b64_tr_b16.
+      static_assert(!KM_SPLIT || (NA == 2 && NB == 2 && BM == 128 && BN == 128), "128 x 128 tile");
+      const int kr = tid >> 5, fq = tid & 31;  // load_tiles: slot p holds k row kr + 8 p, features 4 fq .. 4 fq + 3
 #pragma unroll
       for (int op = 0; op < 2; ++op) {  // 0: A tile, 1: B tile
-        float4 v0 = op == 0 ? ra[0] : rb[0], v1 = op == 0 ? ra[1] : rb[1];
-        const bool ok0 = (okm >> (op == 0 ? 0 : 8)) & 1u, ok1 = (okm >> (op == 0 ? 1 : 9)) & 1u;  // k row inside [k0, k_end)
-        const int lim = op == 0 ? a.M - (m0 + fq * 4) : a.N - (n0 + fq * 4);                       // features inside the matrix
-        if constexpr (kMasked) {
-          v0.x = (ok0 && lim > 0) ? v0.x : 0.f; v0.y = (ok0 && lim > 1) ? v0.y : 0.f;
-          v0.z = (ok0 && lim > 2) ? v0.z : 0.f; v0.w = (ok0 && lim > 3) ? v0.w : 0.f;
-          v1.x = (ok1 && lim > 0) ? v1.x : 0.f; v1.y = (ok1 && lim > 1) ? v1.y : 0.f;
-          v1.z = (ok1 && lim > 2) ? v1.z : 0.f; v1.w = (ok1 && lim > 3) ? v1.w : 0.f;
-        }
-        bf16x4 p0[SPLIT > 0 ? SPLIT : 1], p1[SPLIT > 0 ? SPLIT : 1];
-        split4<SPLIT>(v0, p0);
-        split4<SPLIT>(v1, p1);
 #pragma unroll
-        for (int s = 0; s < SPLIT; ++s)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-            bf16x2 w2;
-            w2[0] = p0[s][e];
-            w2[1] = p1[s][e];
-            *reinterpret_cast<bf16x2*>(plane(buf, s) + (size_t)((op == 0 ? 0 : BM) + fq * 4 + e) * kSplitRowBytes + g * 4) = w2;
+        for (int p = 0; p < 2; ++p) {
+          float4 v = op == 0 ? ra[p] : rb[p];
+          if constexpr (kMasked) {
+            const bool okp = (okm >> (op == 0 ? p : 8 + p)) & 1u;                              // k row inside [k0, k_end)
+            const int lim = okp ? (op == 0 ? a.M - (m0 + fq * 4) : a.N - (n0 + fq * 4)) : 0;  // features inside the matrix
+            v.x = lim > 0 ? v.x : 0.f;
+            v.y = lim > 1 ? v.y : 0.f;
+            v.z = lim > 2 ? v.z : 0.f;
+            v.w = lim > 3 ? v.w : 0.f;
           }
+          bf16x4 pl[SPLIT > 0 ? SPLIT : 1];
+          split4<SPLIT>(v, pl);
+#pragma unroll
+          for (int s = 0; s < SPLIT; ++s)
+            *reinterpret_cast<bf16x4*>(plane(buf, s) + (size_t)(op * BK + kr + 8 * p) * kKmRowBytes + fq * 8) = pl[s];
+        }
       }
       return;
     } else if constexpr (SPLIT > 0) {
@@ -347,6 +358,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   const int kh = lane >> 5, l31 = lane & 31;
   // bias gradient (weight-gradient form): column sums of the A operand, taken from the LDS tile
   float bias_acc = 0.f;
+  float4 kbias4 = make_float4(0.f, 0.f, 0.f, 0.f);                                   // k-major split path
+  const bool bias_blk = EPI == kEpiSlab && a.ones_col >= 0 && n0 == 0;  // block-uniform
   const bool do_bias = EPI == kEpiSlab && a.ones_col >= 0 && n0 == 0 && tid < BM;
 
   // One K step on LDS buffer `buf`; operand fragments of step kk+1 are fetched before the MFMAs of kk.
@@ -362,16 +375,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
         for (int s = 0; s < SPLIT; ++s)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            // row-major tiles: halves swapped per 8-row group (store_tiles); l31 >> 3 is the row's group parity
-            const int hoff = (KM_SPLIT ? kh : (kh ^ ((l31 >> 3) & 1))) * 16;
-            const unsigned char* pa = plane(buf, s) + (size_t)(wm * 64 + i * 32 + l31) * kSplitRowBytes + hoff;
-            const unsigned char* pb = plane(buf, s) + (size_t)(BM + wn * 64 + i * 32 + l31) * kSplitRowBytes + hoff;
-            if constexpr (KM_SPLIT) {  // 40-byte rows: two 8-byte reads
-              const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(pa), a1 = *reinterpret_cast<const bf16x4*>(pa + 8);
-              const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(pb), b1 = *reinterpret_cast<const bf16x4*>(pb + 8);
+            if constexpr (KM_SPLIT) {
+              // lane 16 g + 4 q + p of a 32-lane half addresses k row 8 kh + q (+4 for the second read), features
+              // 16 g + 4 p ..; it receives feature l31 with k = 8 kh + 0..3 (+4): the MFMA fragment order
+              const int q4 = (lane >> 2) & 3, fcol = (lane & 16) + 4 * (lane & 3);
+              const unsigned char* pa = plane(buf, s) + (size_t)(8 * kh + q4) * kKmRowBytes + (wm * 64 + i * 32 + fcol) * 2;
+              const unsigned char* pb = plane(buf, s) + (size_t)(BK + 8 * kh + q4) * kKmRowBytes + (wn * 64 + i * 32 + fcol) * 2;
+              const bf16x4 a0 = lds_read_tr16(pa), a1 = lds_read_tr16(pa + 4 * kKmRowBytes);
+              const bf16x4 b0 = lds_read_tr16(pb), b1 = lds_read_tr16(pb + 4 * kKmRowBytes);
               fa[s][i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
               fb[s][i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
             } else {
+              // row-major tiles: halves swapped per 8-row group (store_tiles); l31 >> 3 is the row's group parity
+              const int hoff = (kh ^ ((l31 >> 3) & 1)) * 16;
+              const unsigned char* pa = plane(buf, s) + (size_t)(wm * 64 + i * 32 + l31) * kSplitRowBytes + hoff;
+              const unsigned char* pb = plane(buf, s) + (size_t)(BM + wn * 64 + i * 32 + l31) * kSplitRowBytes + hoff;
               fa[s][i] = *reinterpret_cast<const bf16x8*>(pa);
               fb[s][i] = *reinterpret_cast<const bf16x8*>(pb);
             }
@@ -388,18 +406,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
           acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sa][1], fb[sb][1], acc[1][1], 0, 0, 0);
         }
       }
-      if (do_bias) {  // bias gradient = row sums of the A tile (dC^T): the three planes add back to the fp32 values
-        float t = 0.f;
+      if constexpr (KM_SPLIT) {
+        // bias gradient = sums over k of the A tile (dC^T): thread (k group kg, feature quad fq) adds its 4 k rows of
+        // the three planes (they add back to the fp32 values); the four k groups are combined after the K loop
+        if (bias_blk && tid < 128) {
+          const int fq = tid & 31, kg = tid >> 5;
 #pragma unroll
-        for (int s = 0; s < SPLIT; ++s) {
-          const unsigned char* pr = plane(buf, s) + (size_t)tid * kSplitRowBytes;
+          for (int s = 0; s < SPLIT; ++s)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const bf16x4 v = *reinterpret_cast<const bf16x4*>(pr + q * 8);
-            t += ((float)v[0] + (float)v[1]) + ((float)v[2] + (float)v[3]);
-          }
+            for (int r = 0; r < 4; ++r) {
+              const bf16x4 v = *reinterpret_cast<const bf16x4*>(plane(buf, s) + (size_t)(kg * 4 + r) * kKmRowBytes + fq * 8);
+              kbias4.x += (float)v[0]; kbias4.y += (float)v[1]; kbias4.z += (float)v[2]; kbias4.w += (float)v[3];
+            }
         }
-        bias_acc += t;
       }
       return;
     }
@@ -497,7 +516,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   // patch of 8 rows x 64 columns and come back as float4 along the row, so that C is written (and the
   // activation mask read) with 16-byte accesses: a wave store covers 4 rows x 256 contiguous bytes.
   float* Cout = a.C + (EPI == kEpiSlab ? (size_t)bz * a.slab_stride : 0);
-  if (do_bias && m0 + tid < a.M) Cout[(size_t)(m0 + tid) * a.ldc + a.ones_col] = bias_acc;
+  if constexpr (KM_SPLIT) {
+    if (bias_blk) {  // combine the four k groups in a fixed order, through the tile memory
+      float4* comb = reinterpret_cast<float4*>(smem);
+      __syncthreads();  // the last K step's fragment reads are done
+      if (tid < 128) comb[tid] = kbias4;
+      __syncthreads();
+      if (tid < 32) {
+        const float4 c0 = comb[tid], c1 = comb[32 + tid], c2 = comb[64 + tid], c3 = comb[96 + tid];
+        const float r[4] = {((c0.x + c1.x) + c2.x) + c3.x, ((c0.y + c1.y) + c2.y) + c3.y, ((c0.z + c1.z) + c2.z) + c3.z,
+                            ((c0.w + c1.w) + c2.w) + c3.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (m0 + tid * 4 + e < a.M) Cout[(size_t)(m0 + tid * 4 + e) * a.ldc + a.ones_col] = r[e];
+      }
+    }
+  } else {
+    if (do_bias && m0 + tid < a.M) Cout[(size_t)(m0 + tid) * a.ldc + a.ones_col] = bias_acc;
+  }
   const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   // keep decision: 16 bits of a per-(row, column pair) hash against round(p * 65536)
   const uint32_t thr16 = a.drop_p > 0.f ? min(65535u, static_cast<uint32_t>(a.drop_p * 65536.0f + 0.5f)) : 0u;
@@ -614,7 +650,7 @@ __global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_kernel(GemmArgs a
 // other.  The weight-gradient blocks (few and long: one per CU) are dispatched first, the data-gradient
 // blocks fill the rest of each CU.
 template <int DM, int DN, int D_GRP, int D_EPI, int WM, int WN, int W_GRP, int D_SPLIT = 0>
-__global__ __launch_bounds__(256) void gemm_pair_kernel(GemmArgs d, GemmArgs w, int w_blocks, int w_tiles) {
+__global__ __launch_bounds__(256, D_SPLIT > 0 ? 2 : 1) void gemm_pair_kernel(GemmArgs d, GemmArgs w, int w_blocks, int w_tiles) {
   // the weight-gradient half joins the split path on the 128x128 tile (ungrouped); otherwise exact fp32
   constexpr int W_SPLIT = (D_SPLIT > 0 && WM == 2 && WN == 2 && W_GRP == 0) ? D_SPLIT : 0;
   constexpr int kSmemW = gemm_smem_floats<WM, WN, W_SPLIT, true>();
