@@ -98,7 +98,7 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4 (&p)[NS > 0 ? NS :
 // One block's work: tile `bid` of split `bz`.
 template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int GRP, int EPI, int SPLIT = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, const int bz, float* smem, int* perm_s) {
-  static_assert(SPLIT == 0 || (A_KM == B_KM && GRP != 2 && !(A_KM && (WAVES_M != 2 || WAVES_N != 2))),
+  static_assert(SPLIT == 0 || (A_KM == B_KM && (GRP != 2 || A_KM) && !(A_KM && (WAVES_M != 2 || WAVES_N != 2))),
                 "split mode: both operands row-major, or both k-major on the 128x128 tile");
   constexpr int kSplitRowBytes = split_row_bytes(A_KM);
   constexpr bool KM_SPLIT = SPLIT > 0 && A_KM;
@@ -649,10 +649,11 @@ __global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_kernel(GemmArgs a
 // The two backward GEMMs of one layer in one launch: they read the same dC and do not depend on each
 // other.  The weight-gradient blocks (few and long: one per CU) are dispatched first, the data-gradient
 // blocks fill the rest of each CU.
-template <int DM, int DN, int D_GRP, int D_EPI, int WM, int WN, int W_GRP, int D_SPLIT = 0>
-__global__ __launch_bounds__(256, D_SPLIT > 0 ? 2 : 1) void gemm_pair_kernel(GemmArgs d, GemmArgs w, int w_blocks, int w_tiles) {
-  // the weight-gradient half joins the split path on the 128x128 tile (ungrouped); otherwise exact fp32
-  constexpr int W_SPLIT = (D_SPLIT > 0 && WM == 2 && WN == 2 && W_GRP == 0) ? D_SPLIT : 0;
+template <int DM, int DN, int D_GRP, int D_EPI, int WM, int WN, int W_GRP, int D_SPLIT = 0, int WG_SPLIT = 0>
+__global__ __launch_bounds__(256, (D_SPLIT > 0 || WG_SPLIT > 0) ? 2 : 1) void gemm_pair_kernel(GemmArgs d, GemmArgs w, int w_blocks, int w_tiles) {
+  // the weight-gradient half joins the split path on the 128x128 tile (D_SPLIT: ungrouped, WG_SPLIT: grouped by
+  // component -- its data-gradient partner gathers W rows and stays exact); otherwise exact fp32
+  constexpr int W_SPLIT = (WM == 2 && WN == 2) ? (W_GRP == 0 ? D_SPLIT : WG_SPLIT) : 0;
   constexpr int kSmemW = gemm_smem_floats<WM, WN, W_SPLIT, true>();
   constexpr int kSmem = gemm_smem_floats<DM, DN, D_SPLIT>() > kSmemW ? gemm_smem_floats<DM, DN, D_SPLIT>() : kSmemW;
   __shared__ __attribute__((aligned(16))) float smem[kSmem];
@@ -838,7 +839,8 @@ int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t
   ProfScope prof_scope(kProfGemm, stream);
   const dim3 grid(w_blocks + d_tiles), block(256);
 #define SUAVE_PAIR(DM, DN, DG, DE, WM, WN, WG, DS) \
-  hipLaunchKernelGGL((gemm_pair_kernel<DM, DN, DG, DE, WM, WN, WG, DS>), grid, block, 0, stream, da, wa, w_blocks, w_tiles)
+  hipLaunchKernelGGL((gemm_pair_kernel<DM, DN, DG, DE, WM, WN, WG, (WG == 0 ? DS : 0), (WG == 0 ? 0 : DS)>), grid, block, 0, stream, da, wa, \
+                     w_blocks, w_tiles)
 #define SUAVE_PAIR_SHAPES(DG, DE, WG, DS)                  \
   do {                                                     \
     if (!dn && !wn) SUAVE_PAIR(2, 2, DG, DE, 2, 2, WG, DS); \
@@ -846,7 +848,10 @@ int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t
     else if (dn && !wn) SUAVE_PAIR(4, 1, DG, DE, 2, 2, WG, DS); \
     else SUAVE_PAIR(4, 1, DG, DE, 4, 1, WG, DS);            \
   } while (0)
-  if (d.grouped == 1) SUAVE_PAIR_SHAPES(1, kEpiMaskBwd, 2, 0);
+  if (d.grouped == 1) {
+    if (split_mode() == 3) SUAVE_PAIR_SHAPES(1, kEpiMaskBwd, 2, 3);
+    else SUAVE_PAIR_SHAPES(1, kEpiMaskBwd, 2, 0);
+  }
   else if (d.epi == kEpiMaskBwd) {
     if (sp == 3) SUAVE_PAIR_SHAPES(0, kEpiMaskBwd, 0, 3);
     else SUAVE_PAIR_SHAPES(0, kEpiMaskBwd, 0, 0);
