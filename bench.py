@@ -438,8 +438,8 @@ def main():
             executed = gemm_flops_executed_per_row(layout) * B * steps / (ms[0] * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel / gemm_pair_kernel, all %d launches/step.  fp32 GEMMs; every "
                                 "fp32 operand is cut into three bf16 planes in the kernel and six plane products accumulate in fp32 on "
-                                "v_mfma_f32_32x32x16_bf16 (fp32-grade error; the grouped per-component forms stay on the exact-fp32 "
-                                "MFMA).  Priced as what it computes, fp32 matrix products, against the fp32 matrix peak; "
+                                "v_mfma_f32_32x32x16_bf16 (fp32-grade error; the data gradient of the grouped per-component head and the "
+                                "narrow weight-gradient tiles stay on the exact-fp32 MFMA).  Priced as what it computes, fp32 matrix products, against the fp32 matrix peak; "
                                 "bf16_pipe_frac is the same time priced as 6 x executed flops against the dense bf16 peak"
                                 % (cnt[0] // steps),
                                 "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
