@@ -171,45 +171,84 @@ __global__ __launch_bounds__(256) void k_assign(LatentFwdArgs a) {
 // a chunk boundary) and the first sorted position of each (block, component) run.
 __global__ __launch_bounds__(256) void k_group_scan(GroupArgs a) {
   __shared__ int tot[SUAVE_MAX_COMPONENTS], seg[SUAVE_MAX_COMPONENTS];
-  __shared__ int wtot[4];
+  __shared__ int wtot[8][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // exclusive prefix over the blocks, one component at a time, 256 blocks per round
-  for (int c = 0; c < a.K; ++c) {
-    int carry = 0;
+  // exclusive prefix over the blocks, 8 components at a time (their count loads are independent: one memory round
+  // trip per 8 components instead of one per component), 256 blocks per round
+  for (int c0 = 0; c0 < a.K; c0 += 8) {
+    int carry[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) carry[u] = 0;
     for (int b0 = 0; b0 < a.n_blocks; b0 += 256) {
       const int b = b0 + tid;
-      const int v = b < a.n_blocks ? a.blk_cnt[(size_t)b * a.K + c] : 0;
-      int incl = v;
+      int v[8], incl[8];
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
+      for (int u = 0; u < 8; ++u) v[u] = (c0 + u < a.K && b < a.n_blocks) ? a.blk_cnt[(size_t)b * a.K + c0 + u] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int x = v[u];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int t = __shfl_up(x, off, 64);
+          if (lane >= off) x += t;
+        }
+        incl[u] = x;
+        if (lane == 63) wtot[u][wave] = x;
       }
-      if (lane == 63) wtot[wave] = incl;
       __syncthreads();
-      int woff = 0;
-      for (int w = 0; w < wave; ++w) woff += wtot[w];
-      const int total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-      if (b < a.n_blocks) a.blk_base[(size_t)b * a.K + c] = carry + woff + incl - v;
-      carry += total;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wtot[u][w];
+        if (c0 + u < a.K && b < a.n_blocks) a.blk_base[(size_t)b * a.K + c0 + u] = carry[u] + woff + incl[u] - v[u];
+        carry[u] += wtot[u][0] + wtot[u][1] + wtot[u][2] + wtot[u][3];
+      }
       __syncthreads();
     }
-    if (tid == 0) tot[c] = carry;
+    if (tid == 0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c0 + u < a.K) tot[c0 + u] = carry[u];
+    }
   }
   __syncthreads();
+  __shared__ int cb[SUAVE_MAX_COMPONENTS + 1];
   if (tid == 0) {
     int ch = 0;
     for (int c = 0; c < a.K; ++c) {
+      cb[c] = ch;
       a.chunk_begin[c] = ch;
       seg[c] = ch * kGroupRows;
-      const int n = (tot[c] + kGroupRows - 1) / kGroupRows;
-      for (int i = 0; i < n && ch < a.n_chunks_max; ++i) a.chunk_comp[ch++] = c;
+      ch = min(ch + (tot[c] + kGroupRows - 1) / kGroupRows, a.n_chunks_max);
     }
+    cb[a.K] = ch;
     a.chunk_begin[a.K] = ch;
-    for (; ch < a.n_chunks_max; ++ch) a.chunk_comp[ch] = -1;
   }
   __syncthreads();
-  for (int i = tid; i < a.n_blocks * a.K; i += 256) a.blk_base[i] += seg[i % a.K];
+  // chunk -> component table, one chunk per thread (a single thread writing it entry by entry was most of this
+  // kernel's time)
+  for (int ch = tid; ch < a.n_chunks_max; ch += 256) {
+    int comp = -1;
+    for (int c = 0; c < a.K; ++c)
+      if (ch >= cb[c] && ch < cb[c + 1]) comp = c;
+    a.chunk_comp[ch] = comp;
+  }
+  // 16 independent read-modify-writes per thread and pass (a plain loop waits for every load before its store:
+  // one memory round trip per 256 entries)
+  const int total = a.n_blocks * a.K;
+  for (int base = 0; base < total; base += 256 * 16) {
+    int v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = base + q * 256 + tid;
+      v[q] = i < total ? a.blk_base[i] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = base + q * 256 + tid;
+      if (i < total) a.blk_base[i] = v[q] + seg[i % a.K];
+    }
+  }
 }
 
 // Counting sort, pass 3: sorted position of every row.
