@@ -140,12 +140,13 @@ int tn_splits(const suave_plan* p, int n_out, int n_in1, int64_t rows) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(s, 512));
 }
 
-// blocks per column chunk of the likelihood kernel: about 16 independent wave workers per CU over all chunks
+// blocks per column chunk of the likelihood kernel: about 28 independent wave workers per CU over all chunks
 int loss_grid(const suave_plan* p, int64_t rows) {
   const int64_t tiles = (rows + 63) / 64;
   const int64_t nch = std::max<size_t>(1, p->chunks_host.size());
   const int wpb = loss_workers_per_block();
-  const int64_t workers = std::min<int64_t>(tiles, (16 * (int64_t)p->n_cu + nch - 1) / nch);
+  static const int wpc = [] { const char* e = getenv("SUAVE_LOSS_WPC"); return e ? std::max(1, atoi(e)) : 28; }();  // tuning knob (swept with SUAVE_LOSS_CHUNK_Y: scripts/sweep_loss.sh)
+  const int64_t workers = std::min<int64_t>(tiles, (wpc * (int64_t)p->n_cu + nch - 1) / nch);
   return (int)std::max<int64_t>(1, (workers + wpb - 1) / wpb);
 }
 int loss_workers(const suave_plan* p, int64_t rows) { return loss_grid(p, rows) * loss_workers_per_block(); }
@@ -1083,9 +1084,9 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
   p->max_classes = max_classes;
   // chunking of the narrow columns for the likelihood kernel (LDS budget); a chunk never spans a wide column
   {
-    // chunks of about equal y width, ~20 floats of y per tile row: a wave worker's private LDS slice stays near
-    // 10 KB (16 workers per CU) and its y tile fits the 8 float4 per lane of the register prefetch
-    const int kChunkY = 20;
+    // chunks of about equal y width, ~24 floats of y per tile row (swept together with the workers per CU: S64
+    // 20/16 -> 24/28 takes 5 % off the kernel, W1024 2 %); its y tile fits the float4 slots of the register prefetch
+    static const int kChunkY = [] { const char* e = getenv("SUAVE_LOSS_CHUNK_Y"); return e ? std::max(4, atoi(e)) : 24; }();  // tuning knob
     const int n_target = std::max(1, (y + kChunkY - 1) / kChunkY);
     const int y_target = (y + n_target - 1) / n_target;
     ColChunk cur{0, 0, 0, 0};
