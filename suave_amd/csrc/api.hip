@@ -110,6 +110,7 @@ struct Workspace {
   int32_t *perm, *lrank, *blk_cnt, *blk_base, *chunk_comp, *chunk_begin;
   int n_blocks, n_chunks_max;
   float* wideL;  // [rows, ldL] logits / logit gradients of the wide categorical columns
+  float* wideT;  // row-major transposed copies of the wide heads' weights (WideCol::t_off), rewritten every backward
   int16_t* ecodes;  // [n_embed, rows] codes of the embedded columns (first encoder layer)
   float* wT[2 * SUAVE_MAX_HIDDEN + 2];  // row-major transposes of the layer weights, in all_layers() order
   float* slab;
@@ -196,6 +197,7 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
   w->recon_part = c.take<float>((nch + 1) * R);
   w->ds_part = c.take<float>((nch + 1) * R * p->ldK);
   w->wideL = c.take<float>(any_wide ? R * p->ldL : 4);
+  w->wideT = c.take<float>(any_wide ? (size_t)p->wide_t_len + 4 : 4);
   w->ecodes = c.take<int16_t>(std::max<size_t>(p->embed_host.size() * R, 8));
   {
     int li = 0;
@@ -425,7 +427,12 @@ int wide_backward(const suave_plan* p, const float* params, const Workspace& w, 
   red->segs[red->n_segs++] = sg;
   *max_elems = std::max(*max_elems, p->wide_len);
   *slab_off += (size_t)g.splits * p->wide_len;
-  if (int rc = launch_gemm_wide(wide_gemm_args(p, params, w, rows, 1), 1, s)) return rc;
+  WideGemmArgs gd = wide_gemm_args(p, params, w, rows, 1);
+  if (gemm_split_mode() != 0) {  // row-major W^T for the split kernels
+    if (int rc = launch_wide_transpose(p->wide_dev, (int)p->wide_host.size(), params, w.wideT, s)) return rc;
+    gd.wT = w.wideT;
+  }
+  if (int rc = launch_gemm_wide(gd, 1, s)) return rc;
   WideRowArgs a = wide_row_args(p, w, rows);
   a.ds_out = ds_out;
   return launch_wide_ds(a, s);
@@ -1043,6 +1050,8 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
       if (col.w_off != ww || col.w2_off != -1) return fail("plan_create: wide categorical weights must follow the narrow heads, 16-byte aligned");
       suave::WideCol wc{};
       wc.col = c; wc.C = col.n_classes; wc.yd = col.y_dim; wc.y_off = yw; wc.l_off = l_off; wc.w_off = ww; wc.ldw = ldw;
+      wc.t_off = p->wide_t_len;
+      p->wide_t_len += ldw * round_up(col.n_classes - 1, 4);
       p->wide_host.push_back(wc);
       for (int q = 0; q < 3; ++q) cum_host[q].push_back(cum[q]);
       cum[0] += (col.n_classes - 1 + 127) / 128;

@@ -59,7 +59,8 @@ struct WideCol {
   int32_t l_off;   // logits of classes 1..C-1 at columns l_off .. l_off + C - 2 of the wide logits buffer (multiple of 4)
   int32_t w_off;   // logits_layer weight [C-1, ldw]
   int32_t ldw;     // round_up(yd + K, 4)
-  int32_t pad;
+  int32_t t_off;   // transposed copy [ldw, round_up(C-1, 4)] in the workspace's wideT buffer (row-major W^T: the split
+                   // data-gradient GEMM's operand form)
 };
 
 // Encoder embedding block of one wide categorical column: row `code` of the block [C, ld] at e_off is the
@@ -112,6 +113,7 @@ struct suave_plan {
   int ldL = 0;        // columns of the wide logits buffer
   int wide_w0 = 0;    // first float of the wide weight region
   int wide_len = 0;   // floats of the wide weight region
+  int wide_t_len = 0; // floats of its transposed copy (WideCol::t_off)
   int n_narrow = 0;   // columns handled by the fused likelihood kernel
   // encoder embedding blocks of the wide categorical columns (first encoder layer)
   std::vector<suave::EmbedCol> embed_host;
@@ -255,6 +257,7 @@ struct WideGemmArgs {
   int64_t slab_stride;  // wide_len
   int splits;
   int wide_w0;
+  const float* wT;      // mode 1, split arithmetic: transposed weights (WideCol::t_off)
 };
 int launch_gemm_wide(const WideGemmArgs& a, int mode, hipStream_t stream);
 int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t stream);

@@ -667,7 +667,6 @@ __global__ __launch_bounds__(256, (D_SPLIT > 0 || WG_SPLIT > 0) ? 2 : 1) void ge
 // the ordinary tile body on that column's operands.
 template <int MODE, int SPLIT = 0>
 __global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_wide_kernel(WideGemmArgs w) {
-  static_assert(SPLIT == 0 || MODE != 1, "the data gradient of the wide heads reads W k-major and A row-major: exact path");
   __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<2, 2, SPLIT, MODE == 2>()];
   __shared__ int perm_s[1];
   const int tiles_m = MODE == 2 ? 1 : (w.rows + 127) / 128;
@@ -693,8 +692,14 @@ __global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_wide_kernel(WideG
     gemm_body<2, 2, false, false, 0, kEpiBias, SPLIT>(g, local, 0, smem, perm_s);
   } else if (MODE == 1) {
     g.A = logit; g.B = wt; g.C = slot; g.M = w.rows; g.N = wc.ldw; g.K = wc.C - 1;
-    g.lda = w.ldL; g.ldb = wc.ldw; g.ldc = w.ldY; g.a_kmajor = 0; g.b_kmajor = 1; g.epi = kEpiBias;
-    gemm_body<2, 2, false, true, 0, kEpiBias>(g, local, 0, smem, perm_s);
+    g.lda = w.ldL; g.ldc = w.ldY; g.a_kmajor = 0; g.epi = kEpiBias;
+    if constexpr (SPLIT > 0) {  // row-major W^T from the workspace (k_wide_transpose)
+      g.B = w.wT + wc.t_off; g.ldb = (wc.C - 1 + 3) & ~3; g.b_kmajor = 0;
+      gemm_body<2, 2, false, false, 0, kEpiBias, SPLIT>(g, local, 0, smem, perm_s);
+    } else {
+      g.ldb = wc.ldw; g.b_kmajor = 1;
+      gemm_body<2, 2, false, true, 0, kEpiBias>(g, local, 0, smem, perm_s);
+    }
   } else {
     g.A = logit; g.B = slot; g.C = w.slab + (wc.w_off - w.wide_w0); g.M = wc.C - 1; g.N = wc.ldw; g.K = w.rows;
     g.lda = w.ldL; g.ldb = w.ldY; g.ldc = wc.ldw; g.a_kmajor = 1; g.b_kmajor = 1; g.epi = kEpiSlab;
@@ -719,6 +724,7 @@ int launch_gemm_wide(const WideGemmArgs& a, int mode, hipStream_t stream) {
   const dim3 grid((unsigned)blocks, 1, mode == 2 ? a.splits : 1), block(256);
   if (mode == 0 && split_mode() == 3) hipLaunchKernelGGL((gemm_wide_kernel<0, 3>), grid, block, 0, stream, a);
   else if (mode == 0) hipLaunchKernelGGL(gemm_wide_kernel<0>, grid, block, 0, stream, a);
+  else if (mode == 1 && split_mode() == 3 && a.wT != nullptr) hipLaunchKernelGGL((gemm_wide_kernel<1, 3>), grid, block, 0, stream, a);
   else if (mode == 1) hipLaunchKernelGGL(gemm_wide_kernel<1>, grid, block, 0, stream, a);
   else if (split_mode() == 3) hipLaunchKernelGGL((gemm_wide_kernel<2, 3>), grid, block, 0, stream, a);
   else hipLaunchKernelGGL(gemm_wide_kernel<2>, grid, block, 0, stream, a);

@@ -189,6 +189,8 @@ int launch_wide_fill(const WideRowArgs& a, hipStream_t s);
 int wide_softmax_grid(int n_rows);
 int launch_wide_softmax(const WideRowArgs& a, bool grad, hipStream_t s);
 int launch_wide_ds(const WideRowArgs& a, hipStream_t s);
+// wT[t_off + n * round_up(C-1, 4) + k] = W[k][n] for every wide column (pad columns zero)
+int launch_wide_transpose(const WideCol* cols, int n_wide, const float* params, float* wT, hipStream_t s);
 
 int launch_mix_fwd(const MixFwdArgs& a, hipStream_t s);
 int launch_mix_finalize(const MixFinArgs& a, bool grad, int grid, hipStream_t s);

@@ -101,6 +101,20 @@ __global__ __launch_bounds__(256) void k_wide_ds(WideRowArgs a) {
   }
 }
 
+// Row-major transposed copy of every wide column's logits_layer weight (the split data-gradient GEMM multiplies
+// dL [rows, C-1] by W^T stored [ldw, round_up(C-1, 4)]).  blockIdx.y = wide column; reads are coalesced.
+__global__ __launch_bounds__(256) void k_wide_transpose(const WideCol* __restrict__ cols, const float* __restrict__ params,
+                                                        float* __restrict__ wT) {
+  const WideCol wc = cols[blockIdx.y];
+  const int kc = wc.C - 1, ldt = (kc + 3) & ~3;
+  float* dst = wT + wc.t_off;
+  const int total = ldt * wc.ldw;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int k = e / wc.ldw, n = e - k * wc.ldw;
+    dst[(size_t)n * ldt + k] = k < kc ? params[wc.w_off + (size_t)k * wc.ldw + n] : 0.f;
+  }
+}
+
 static int wide_grid(int64_t work, int per_block, int cap) {
   return (int)std::max<int64_t>(1, std::min<int64_t>((work + per_block - 1) / per_block, cap));
 }
@@ -121,6 +135,14 @@ int launch_wide_softmax(const WideRowArgs& a, bool grad, hipStream_t s) {
   const dim3 grid(wide_softmax_grid(a.n_rows)), block(256);
   if (grad) hipLaunchKernelGGL(k_wide_softmax<true>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(k_wide_softmax<false>, grid, block, 0, s, a);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_wide_transpose(const WideCol* cols, int n_wide, const float* params, float* wT, hipStream_t s) {
+  if (n_wide <= 0) return 0;
+  ProfScope prof_scope(kProfGemm, s);
+  hipLaunchKernelGGL(k_wide_transpose, dim3(32, n_wide), dim3(256), 0, s, cols, params, wT);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }
