@@ -58,11 +58,11 @@ __device__ __forceinline__ uint32_t drop_row_hash(uint32_t key, uint32_t row_id)
 // the f32 MFMA cannot offer (it executes on the SIMD's FMA lanes).  LDS image per plane: [row][16 k] bf16, 32 B
 // per row: a lane's MFMA fragment (row l & 31, k = 8 (l >> 5) ... + 7) is one ds_read_b128.
 //
-// k-major operands (weight gradients: element (i, k) at X[k * ld + i]) join through a register transpose: a
-// thread loads the float4 of rows k = 2g and 2g + 1 of one 4-feature group, so it owns a 4 x 2 block and writes,
-// per feature and plane, ONE 32-bit word (the two k's) at [feature][k pair].  Those kernels use 40-byte LDS rows:
-// the 32 lanes of a store then spread over 16 banks (2-way) instead of hitting one, and the fragment is two
-// conflict-free ds_read_b64 (40 is not a multiple of 16).
+// k-major operands (weight gradients: element (i, k) at X[k * ld + i], 128 x 128 tile only) stay k-major in LDS:
+// plane image [16 k][128 features] bf16 with 320-byte k rows (store_tiles), transposed on the way out by
+// ds_read_b64_tr_b16 (compute()).  split_row_bytes sizes that image: (128 + 128) x 40 = 2 x 16 x 320 bytes a plane.
+// (Tried and dropped: an unpadded, XOR-swizzled image -- 48 KB, three blocks per CU -- needs the 168-register
+// budget, where these kernels spill 108 bytes per lane.)
 constexpr int split_row_bytes(bool any_km) { return any_km ? 2 * BK + 8 : 2 * BK; }
 template <int WAVES_M, int WAVES_N, int SPLIT = 0, bool KM = false>
 constexpr int gemm_smem_floats() {
