@@ -656,7 +656,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
       slab_off += (size_t)nb * ncol;
     }
     ReduceSeg sh{};
-    sh.src_off = 0; sh.slab_stride = m.head_len; sh.n_slabs = lworkers; sh.rows = 1; sh.cols = m.head_len;
+    sh.src_off = 0; sh.slab_stride = m.head_len; sh.n_slabs = lworkers / loss_workers_per_block(); sh.rows = 1; sh.cols = m.head_len;  // one row per block
     sh.src_ld = m.head_len; sh.dst_off = m.head_off; sh.dst_si = 0; sh.dst_sj = 1;
     red.segs[red.n_segs++] = sh;
     max_elems = std::max(max_elems, m.head_len);
@@ -923,7 +923,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     // ---- likelihood-head weights ----
     {
       ReduceSeg sh{};
-      sh.src_off = 0; sh.slab_stride = m.head_len; sh.n_slabs = lworkers; sh.rows = 1; sh.cols = m.head_len;
+      sh.src_off = 0; sh.slab_stride = m.head_len; sh.n_slabs = lworkers / loss_workers_per_block(); sh.rows = 1; sh.cols = m.head_len;  // one row per block
       sh.src_ld = m.head_len; sh.dst_off = m.head_off; sh.dst_si = 0; sh.dst_sj = 1;
       red.segs[red.n_segs++] = sh;
       max_elems = std::max(max_elems, m.head_len);

@@ -419,8 +419,14 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
   }
 #endif
   if (GRAD && a.head_slab) {
-    float* dst = a.head_slab + (size_t)worker * a.head_len + (hw_begin - a.head_off);
-    for (int i = lane; i < hw_len; i += 64) dst[i] = hw_acc[i];
+    // One slab row per BLOCK: the four wave workers' accumulators are added in a fixed order (the only block
+    // barrier of the kernel, after every wave has left its tile loop).  A row per worker made the slab reduction
+    // four times deeper -- it was that launch's critical path.
+    __syncthreads();
+    const float* h0 = lds + 64 * a.ldy;
+    float* dst = a.head_slab + (size_t)blockIdx.x * a.head_len + (hw_begin - a.head_off);
+    for (int i = tid; i < hw_len; i += kLossThreads)
+      dst[i] = ((h0[i] + h0[(size_t)wave_floats + i]) + h0[2 * (size_t)wave_floats + i]) + h0[3 * (size_t)wave_floats + i];
   }
   if (lane == 0 && a.sums_slab) {
     double* s = a.sums_slab + ((size_t)blockIdx.y * n_workers + worker) * 4;
