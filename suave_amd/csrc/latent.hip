@@ -23,7 +23,9 @@ __global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_
                                                 int rows_per_block, float* __restrict__ x, int32_t* __restrict__ cells) {
   extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ldn = n_num, ldd = (n_disc + 1) & ~1, ldm = (n_cols + 3) & ~3;
+  // row strides: odd word counts for the lane = row reads of the cell phase (a 64-byte mask row put all 64 lanes on
+  // two banks)
+  const int ldn = n_num | 1, ldd = (n_disc + 1) & ~1, ldm = ((n_cols + 3) & ~3) + 4;
   float* xn_s = reinterpret_cast<float*>(stage);                                   // [R][ldn]
   int16_t* cd_s = reinterpret_cast<int16_t*>(xn_s + (size_t)rows_per_block * ldn);  // [R][ldd]
   uint8_t* mk_s = reinterpret_cast<uint8_t*>(cd_s + (size_t)rows_per_block * ldd);  // [R][ldm]
@@ -31,30 +33,31 @@ __global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_
     const int nrows = min(rows_per_block, b.n_rows - r0);
     __syncthreads();
     // each wave stages a contiguous quarter of the block's rows: one load of their table row ids, then
-    // 8 rows of cell loads in flight at a time (lane = element)
+    // kStage rows of cell loads in flight at a time (lane = element)
     const int rows_w = (rows_per_block + 3) / 4;
     const int lw0 = wave * rows_w;
     int64_t my_tr = -1;
     if (lane < rows_w && lw0 + lane < nrows) my_tr = b.row_index ? (int64_t)b.row_index[r0 + lw0 + lane] : b.row_begin + r0 + lw0 + lane;
     const int n_max = max(n_num, max(n_disc, n_cols));
-    for (int j0 = 0; j0 < rows_w; j0 += 8) {
-      int64_t tr[8];
+    constexpr int kStage = 8;  // rows of cell loads in flight per wave (16 per round was slower: 0.049 -> 0.080 ms)
+    for (int j0 = 0; j0 < rows_w; j0 += kStage) {
+      int64_t tr[kStage];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) tr[u] = __shfl(my_tr, (j0 + u) & 63, 64);
+      for (int u = 0; u < kStage; ++u) tr[u] = __shfl(my_tr, (j0 + u) & 63, 64);
       for (int i0 = 0; i0 < n_max; i0 += 64) {
         const int i = i0 + lane;
-        float xv[8];
-        int16_t cv[8];
-        uint8_t mv[8];
+        float xv[kStage];
+        int16_t cv[kStage];
+        uint8_t mv[kStage];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kStage; ++u) {
           const bool ok = j0 + u < rows_w && tr[u] >= 0;
           xv[u] = (ok && i < n_num) ? b.xnum[tr[u] * b.ld_num + i] : 0.f;
           cv[u] = (ok && i < n_disc) ? b.codes[tr[u] * b.ld_disc + i] : (int16_t)0;
           mv[u] = (ok && i < n_cols) ? b.mask[tr[u] * b.ld_mask + i] : (uint8_t)0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kStage; ++u) {
           const int lr = lw0 + j0 + u;
           if (j0 + u < rows_w && tr[u] >= 0) {
             if (i < n_num) xn_s[lr * ldn + i] = xv[u];
@@ -80,15 +83,27 @@ __global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_
         const int i = i0 + q * 64 + lane;
         const int kind = e[q] >> 29, cls = (e[q] >> 14) & 0x7FFF, src = e[q] & 0x3FFF;
         if (i < ldI) {
-          for (int lr = wave; lr < nrows; lr += 4) {
-            float v = 0.f;
-            if (kind == 2) v = xn_s[lr * ldn + src];
-            else if (kind == 1) v = mk_s[lr * ldm + src] ? 1.f : 0.f;
-            else if (kind >= 3) {
-              const int code = cd_s[lr * ldd + src];
-              v = kind == 3 ? (code == cls ? 1.f : 0.f) : ((code >= 0 && cls <= code) ? 1.f : 0.f);  // model.py:2890-2891
+          // Branch-free: the three staged arrays are read unconditionally (index 0 when the feature is of another
+          // kind -- always inside the block's LDS) and the value is selected afterwards, four rows per round, so
+          // twelve independent LDS reads are in flight instead of one read per divergent branch.
+          const int sx = kind == 2 ? src : 0, sm = kind == 1 ? src : 0, sc = kind >= 3 ? src : 0;
+          for (int lr0 = wave; lr0 < nrows; lr0 += 16) {
+            float xv[4];
+            int cv[4], mv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int lr = min(lr0 + 4 * u, nrows - 1);
+              xv[u] = xn_s[lr * ldn + sx];
+              mv[u] = mk_s[lr * ldm + sm];
+              cv[u] = cd_s[lr * ldd + sc];
             }
-            x[(size_t)(r0 + lr) * ldI + i] = v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int lr = lr0 + 4 * u;
+              const float oh = kind == 3 ? (cv[u] == cls ? 1.f : 0.f) : ((cv[u] >= 0 && cls <= cv[u]) ? 1.f : 0.f);  // model.py:2890-2891
+              const float v = kind == 2 ? xv[u] : kind == 1 ? (mv[u] ? 1.f : 0.f) : kind >= 3 ? oh : 0.f;
+              if (lr < nrows) x[(size_t)(r0 + lr) * ldI + i] = v;
+            }
           }
         }
       }
@@ -99,11 +114,23 @@ __global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_
       for (int lr = lane; lr < nrows; lr += 64) {
         const int r = r0 + lr;
         int32_t* dst = cells + ((size_t)(r >> 6) * n_cols) * 64 + (r & 63);
-        for (int c = wave; c < n_cols; c += 4) {
-          const int sx = xsrc[c];
-          const int src = sx & 0xFFFFFF;
-          const int v = (sx & (1 << 30)) ? (int)cd_s[lr * ldd + src] : __float_as_int(xn_s[lr * ldn + src]);
-          dst[(size_t)c * 64] = mk_s[lr * ldm + c] ? v : kCellMissing;
+        for (int c0 = wave; c0 < n_cols; c0 += 16) {  // four columns per round: their table entries and LDS reads overlap
+          int sx[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sx[u] = xsrc[min(c0 + 4 * u, n_cols - 1)];
+          int v[4], mk[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = min(c0 + 4 * u, n_cols - 1);
+            const int src = sx[u] & 0xFFFFFF;
+            v[u] = (sx[u] & (1 << 30)) ? (int)cd_s[lr * ldd + src] : __float_as_int(xn_s[lr * ldn + src]);
+            mk[u] = mk_s[lr * ldm + c];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 4 * u;
+            if (c < n_cols) dst[(size_t)c * 64] = mk[u] ? v[u] : kCellMissing;
+          }
         }
       }
     }
@@ -797,7 +824,7 @@ int launch_expand(const suave_plan* p, const suave_batch_t& b, float* x, int32_t
   if (b.n_rows <= 0) return 0;
   ProfScope prof_scope(kProfExpand, s);
   const suave_model_t& m = p->model;
-  const int row_bytes = m.n_num * 4 + ((m.n_disc + 1) & ~1) * 2 + ((m.n_cols + 3) & ~3);
+  const int row_bytes = (m.n_num | 1) * 4 + ((m.n_disc + 1) & ~1) * 2 + ((m.n_cols + 3) & ~3) + 4;  // k_expand's ldn, ldd, ldm
   int rows_per_block = std::max(4, std::min(64, (48 * 1024) / std::max(row_bytes, 1)) & ~3);
   SUAVE_REQUIRE((size_t)rows_per_block * row_bytes <= 48 * 1024, "expand: schema too wide for the staging buffer");
   const int grid = std::min((b.n_rows + rows_per_block - 1) / rows_per_block, 4096);
