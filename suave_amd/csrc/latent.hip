@@ -316,7 +316,19 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
     const uint32_t rid = a.row_index ? (uint32_t)a.row_index[r] : (uint32_t)(a.row_begin + r);
     float gk = 0.f;
     if (v4) {
+      // the head row's next float4 pair is loaded before this one's arithmetic and stores (the stores would
+      // otherwise fence the loads of the next trip: the compiler cannot prove they do not alias)
+      float4 mu_nx = make_float4(0.f, 0.f, 0.f, 0.f), lv_nx = mu_nx;
+      if (qd < dq) {
+        mu_nx = *reinterpret_cast<const float4*>(mu + qd * 4);
+        lv_nx = *reinterpret_cast<const float4*>(lv + qd * 4);
+      }
       for (int q = qd; q < dq; q += 4) {
+        const float4 mu4 = mu_nx, lv4 = lv_nx;
+        if (q + 4 < dq) {
+          mu_nx = *reinterpret_cast<const float4*>(mu + (q + 4) * 4);
+          lv_nx = *reinterpret_cast<const float4*>(lv + (q + 4) * 4);
+        }
         float ev[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.eps_in == nullptr) {
           const uint4 w = rng(rid, (uint32_t)q, kStreamEps, (uint32_t)a.step);
@@ -327,8 +339,6 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
           for (int e = 0; e < 4; ++e)
             if (q * 4 + e < D) ev[e] = a.eps_in[(size_t)r * D + q * 4 + e];
         }
-        const float4 mu4 = *reinterpret_cast<const float4*>(mu + q * 4);
-        const float4 lv4 = *reinterpret_cast<const float4*>(lv + q * 4);
         const float mv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, lvv[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
         float zz[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {0.f, 0.f, 0.f, 0.f}, gl[4] = {0.f, 0.f, 0.f, 0.f}, pl2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
