@@ -464,43 +464,49 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
     }
     __syncthreads();
     const float inv_tau = 1.0f / a.tau;
-    // one float4 of one row per step (ldK and ldD are multiples of 4, so a float4 never straddles regions)
-    const int nq = a.ldS >> 2;
-    for (int idx = tid; idx < nrows * nq; idx += 256) {
-      const int lr = idx / nq, q = (idx - lr * nq) * 4;
+    // One float4 of one row per step (ldK and ldD are multiples of 4, so a float4 never straddles regions), one
+    // REGION per pass -- logits, mu, logvar -- so that a wave never diverges between the three load patterns (in a
+    // single pass over the 19 quads of a row the three branches ran one after the other, each waiting for its own
+    // global loads).
+    const int nqk = a.ldK >> 2, nqd = a.ldD >> 2;
+    for (int idx = tid; idx < nrows * nqk; idx += 256) {  // ---- component logits: straight-through softmax + KL
+      const int lr = idx / nqk, q = (idx - lr * nqk) * 4;
       const int r = r0 + lr;
+      const float4 gl = *reinterpret_cast<const float4*>(a.gkl_logit + (size_t)r * a.ldK + q);
+      const float g4[4] = {gl.x, gl.y, gl.z, gl.w};
       float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (q < a.ldK) {
-        const float4 gl = *reinterpret_cast<const float4*>(a.gkl_logit + (size_t)r * a.ldK + q);
-        const float g4[4] = {gl.x, gl.y, gl.z, gl.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (q + e < K)
-            v[e] = ys_s[lr * kDsStride + q + e] * (ds_s[lr * kDsStride + q + e] - inner_s[lr]) * inv_tau + g4[e];
-      } else {
-        const int c = q - a.ldK;
-        const bool is_lv = c >= a.ldD;
-        const int d = is_lv ? c - a.ldD : c;
-        const float4 g4 = *reinterpret_cast<const float4*>(a.dz + (size_t)r * a.ldD + d);
-        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
-        if (!is_lv) {
-          const float4 m4 = *reinterpret_cast<const float4*>(a.gkl_mu + (size_t)r * a.ldD + d);
-          const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+      for (int e = 0; e < 4; ++e)
+        if (q + e < K) v[e] = ys_s[lr * kDsStride + q + e] * (ds_s[lr * kDsStride + q + e] - inner_s[lr]) * inv_tau + g4[e];
+      *reinterpret_cast<float4*>(a.dsel + (size_t)r * a.ldS + q) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    for (int idx = tid; idx < nrows * nqd; idx += 256) {  // ---- selected mu: dz + KL
+      const int lr = idx / nqd, d = (idx - lr * nqd) * 4;
+      const int r = r0 + lr;
+      const float4 g4 = *reinterpret_cast<const float4*>(a.dz + (size_t)r * a.ldD + d);
+      const float4 m4 = *reinterpret_cast<const float4*>(a.gkl_mu + (size_t)r * a.ldD + d);
+      const float g[4] = {g4.x, g4.y, g4.z, g4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (d + e < a.D) v[e] = g[e] + mm[e];
-        } else {
-          const float4 raw4 = *reinterpret_cast<const float4*>(a.sel + (size_t)r * a.ldS + q);
-          const float4 eps4 = *reinterpret_cast<const float4*>(a.eps_buf + (size_t)r * a.ldD + d);
-          const float4 l4 = *reinterpret_cast<const float4*>(a.gkl_lv + (size_t)r * a.ldD + d);
-          const float raw[4] = {raw4.x, raw4.y, raw4.z, raw4.w}, eps[4] = {eps4.x, eps4.y, eps4.z, eps4.w};
-          const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
+      for (int e = 0; e < 4; ++e)
+        if (d + e < a.D) v[e] = g[e] + mm[e];
+      *reinterpret_cast<float4*>(a.dsel + (size_t)r * a.ldS + a.ldK + d) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    for (int idx = tid; idx < nrows * nqd; idx += 256) {  // ---- selected logvar: dz * eps * exp(lv / 2) / 2 + KL
+      const int lr = idx / nqd, d = (idx - lr * nqd) * 4;
+      const int r = r0 + lr;
+      const int q = a.ldK + a.ldD + d;
+      const float4 g4 = *reinterpret_cast<const float4*>(a.dz + (size_t)r * a.ldD + d);
+      const float4 raw4 = *reinterpret_cast<const float4*>(a.sel + (size_t)r * a.ldS + q);
+      const float4 eps4 = *reinterpret_cast<const float4*>(a.eps_buf + (size_t)r * a.ldD + d);
+      const float4 l4 = *reinterpret_cast<const float4*>(a.gkl_lv + (size_t)r * a.ldD + d);
+      const float g[4] = {g4.x, g4.y, g4.z, g4.w}, raw[4] = {raw4.x, raw4.y, raw4.z, raw4.w};
+      const float eps[4] = {eps4.x, eps4.y, eps4.z, eps4.w}, ll[4] = {l4.x, l4.y, l4.z, l4.w};
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int e = 0; e < 4; ++e)  // clamp passes gradient inside its range only
-            if (d + e < a.D && raw[e] >= kLogvarMin && raw[e] <= kLogvarMax)
-              v[e] = g[e] * eps[e] * 0.5f * __expf(0.5f * raw[e]) + ll[e];
-        }
-      }
+      for (int e = 0; e < 4; ++e)  // clamp passes gradient inside its range only
+        if (d + e < a.D && raw[e] >= kLogvarMin && raw[e] <= kLogvarMax)
+          v[e] = g[e] * eps[e] * 0.5f * __expf(0.5f * raw[e]) + ll[e];
       *reinterpret_cast<float4*>(a.dsel + (size_t)r * a.ldS + q) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
