@@ -830,7 +830,8 @@ int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t
   const bool fusable = d.M > 0 && d.N > 0 && w.M > 0 && w.N > 0 && !d.a_kmajor && (d.b_kmajor || d_rm) && w.a_kmajor && w.b_kmajor &&
                        w.epi == kEpiSlab && (d.epi == kEpiMaskBwd || d.epi == kEpiBias) &&
                        ((d.grouped == 0 && w.grouped == 0) || (d.grouped == 1 && w.grouped == 2 && d.epi == kEpiMaskBwd));
-  if (!fusable) {
+  static const bool no_pair = getenv("SUAVE_NO_PAIR") != nullptr;  // tuning knob: run the two GEMMs as two launches
+  if (!fusable || (no_pair && d.grouped == 0)) {
     if (int rc = launch_gemm(w, n_cu, stream)) return rc;
     return launch_gemm(d, n_cu, stream);
   }
