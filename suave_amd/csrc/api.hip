@@ -240,7 +240,7 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
   slab += (size_t)lg * m.head_len + 4;
   {
     const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components;
-    slab += (size_t)tn_splits(p, Mt, Nt, rows) * Mt * round_up(Nt + 1, 4);
+    slab += (size_t)prior_colsum_blocks((int)rows) * Mt * round_up(Nt + 1, 4);
   }
   if (m.behaviour == 1) slab += (size_t)lg * (m.n_components * m.latent_dim + m.latent_dim);
   if (any_wide) slab += (size_t)wide_splits(p, rows) * p->wide_len + 4;
@@ -891,24 +891,15 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
         if (int rc = encoder_embed_backward(p, w, B, grads, s)) return rc;
       }
     }
-    // ---- prior gradients: (prior_terms^T * [onehot(k) | 1]) via the split GEMM ----
+    // ---- prior gradients: per-component column sums of prior_terms, out[c][k] (k_prior_colsum) ----
     {
       const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components;
       const int ldc = round_up(Nt + 1, 4);
-      const int splits = tn_splits(p, Mt, Nt, B);
-      float* onehot = w.onehot;  // [B, ldK] one-hot of the selected component
-      const int ld1 = p->ldK;
-      if (int rc = launch_onehot(w.kidx, B, m.n_components, ld1, onehot, s)) return rc;
-      GemmArgs g = gemm_base();
-      g.A = w.prior_terms; g.B = onehot; g.C = w.slab + slab_off;
-      g.M = Mt; g.N = Nt; g.K = B;
-      g.lda = ldT; g.ldb = ld1; g.ldc = ldc;
-      g.a_kmajor = 1; g.b_kmajor = 1; g.epi = kEpiSlab; g.splits = splits;
-      g.slab_stride = (int64_t)Mt * ldc; g.ones_col = m.n_components;
-      if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
+      const int splits = prior_colsum_blocks(B);
+      if (int rc = launch_prior_colsum(w.prior_terms, ldT, w.kidx, B, Mt, Nt, ldc, w.slab + slab_off, s)) return rc;
       SUAVE_REQUIRE(red.n_segs + 4 <= kMaxReduceSegs, "too many reduction segments");
       ReduceSeg sm{};  // prior.mu[k][d] = out[d][k]
-      sm.src_off = (int64_t)slab_off; sm.slab_stride = g.slab_stride; sm.n_slabs = splits;
+      sm.src_off = (int64_t)slab_off; sm.slab_stride = (int64_t)Mt * ldc; sm.n_slabs = splits;
       sm.rows = D; sm.cols = K; sm.src_ld = ldc; sm.dst_off = m.prior_mu_off; sm.dst_si = 1; sm.dst_sj = D;
       red.segs[red.n_segs++] = sm;
       ReduceSeg sv = sm;  // prior.logvar[k][d] = out[D + d][k]

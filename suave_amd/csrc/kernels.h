@@ -195,6 +195,9 @@ int launch_wide_transpose(const WideCol* cols, int n_wide, const float* params, 
 int launch_mix_fwd(const MixFwdArgs& a, hipStream_t s);
 int launch_mix_finalize(const MixFinArgs& a, bool grad, int grid, hipStream_t s);
 int launch_colsum(const float* src, int ld, int n_rows, int n_cols, float* slab, int n_blocks, hipStream_t s);
+int prior_colsum_blocks(int n_rows);
+int launch_prior_colsum(const float* terms, int ldT, const int32_t* kidx, int n_rows, int n_cols, int K, int ldc, float* slab,
+                        hipStream_t s);  // per-component column sums, slabs [blocks][n_cols][ldc]
 
 size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes, int ldx, int ldm);
 int loss_set_lds_limit(size_t lds_bytes);
