@@ -865,7 +865,7 @@ __global__ __launch_bounds__(256) void k_prior_colsum(const float* __restrict__ 
 }
 
 // ---- host launchers -----------------------------------------------------------
-int prior_colsum_blocks(int n_rows) { return std::max(1, std::min((n_rows + 63) / 64, 1024)); }  // ~21 rows per thread: three load rounds
+int prior_colsum_blocks(int n_rows) { return std::max(1, std::min((n_rows + 63) / 64, 1024)); }  // ~21 rows per thread: three load rounds (512 blocks: no better)
 
 int launch_prior_colsum(const float* terms, int ldT, const int32_t* kidx, int n_rows, int n_cols, int K, int ldc, float* slab,
                         hipStream_t s) {
