@@ -52,7 +52,8 @@ def arithmetic(request):
 
 
 SHAPES = [(1, 1, 1), (5, 3, 7), (128, 128, 16), (129, 127, 17), (1000, 141, 128), (257, 65, 33), (300, 650, 260),
-          (4096, 256, 205), (2048, 64, 32), (513, 40, 96)]
+          (4096, 256, 205), (2048, 64, 32), (513, 40, 96),
+          (4096, 10, 128), (2048, 16, 33), (1500, 3, 260), (65536, 10, 128)]  # skinny outputs (component logits, class heads): N <= 16 on long batches
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
