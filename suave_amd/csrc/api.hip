@@ -686,6 +686,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   if (int rc = check_batch(p, batch)) return rc;
   const suave_model_t& m = p->model;
   SUAVE_REQUIRE(dlatent == nullptr || m.behaviour == 0, "dlatent is only defined for the supervised branch (model.py:1987-1991)");
+  SUAVE_REQUIRE(global_rows >= 1, "global_rows must be positive");
   if (m.behaviour == 1)
     return elbo_unsup_impl(p, params, batch, noise, beta_scale, tau, training, global_rows, workspace, workspace_bytes, s,
                            out, grads);
@@ -697,7 +698,6 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   Workspace w;
   carve(p, B, workspace, &w);
   SUAVE_REQUIRE(workspace_bytes >= w.total_bytes, "workspace too small (see suave_workspace_bytes)");
-  SUAVE_REQUIRE(global_rows >= 1, "global_rows must be positive");
   const float tau_c = std::max(tau, 1e-6f);  // model.py:1587
   const float drop_p = training ? m.dropout : 0.f;
   const int nh = m.n_hidden;
@@ -804,6 +804,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   if (n_parts > 1) {
     hipLaunchKernelGGL(k_sum_chunks, dim3(std::min((B + 255) / 256, 1024)), dim3(256), 0, s, w.recon_part, n_parts, B,
                        w.recon);
+    SUAVE_CHECK_HIP(hipGetLastError());
     recon_final = w.recon;
   }
 

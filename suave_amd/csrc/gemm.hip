@@ -7,12 +7,17 @@
 //   forward      C[B,N]   = A[B,K]   * W[N,K]^T   (A row-major, B operand k-contiguous)
 //   data grad    dA[B,K]  = dC[B,N]  * W[N,K]     (B operand k-major)
 //   weight grad  dW[N,K]  = dC[B,N]^T * A[B,K]    (both operands k-major, split over B)
-// Arithmetic is v_mfma_f32_32x32x2_f32: exact binary32 products accumulated in
-// binary32 (the parity bar is 1e-4 on gradients, which bf16 inputs do not hold).
-// Block tile 128x128 (2x2 waves) or 256x64 (4x1 waves), wave tile 64x64 = 2x2
-// MFMA tiles, K step 16, LDS tiles stored k-major ([k][i]) so that the MFMA
-// operand fetch (lane l: i = l&31, k = l>>5) is a conflict-free ds_read_b32,
-// double-buffered with the next tile's global loads in flight during the MFMAs.
+// Arithmetic (suave_gemm_arithmetic_set), fp32 in / fp32 accumulate / fp32 out either way:
+//   mode 3 (default): every fp32 operand element is cut into three bf16 planes when its tile is stored to LDS and
+//           the six plane products with i + j <= 2 run on v_mfma_f32_32x32x16_bf16 -- the error of an fp32 FMA
+//           chain (the parity bar is 1e-4 on gradients, which plain bf16 inputs do not hold) at 6/16 of the fp32
+//           MFMA's matrix-pipe time; row-major forms read [row][16 k] plane images with one ds_read_b128 per
+//           fragment, k-major forms (weight gradients) keep [16 k][128 features] images and transpose on the way
+//           out with ds_read_b64_tr_b16;
+//   mode 0: v_mfma_f32_32x32x2_f32 everywhere (exact binary32 products), LDS tiles k-major ([k][i]) so that the
+//           operand fetch (lane l: i = l&31, k = l>>5) is a conflict-free ds_read_b32.
+// Block tile 128x128 (2x2 waves) or 256x64 (4x1 waves, N <= 64), wave tile 64x64 = 2x2 MFMA tiles, K step 16,
+// double-buffered LDS with the next two tiles' global loads in flight during the MFMAs.
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
