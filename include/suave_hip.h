@@ -238,6 +238,24 @@ int suave_decode_sample(const suave_plan* plan, const float* params, const float
                         float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc,
                         float* y_full_out);
 
+/* suave_decode_sample for callers that cannot allocate -- no counterpart in the reference.  It is for code under
+ * HIP graph capture, tight serving loops and harnesses that forbid hipMalloc: same arguments and results as
+ * suave_decode_sample minus the workspace.  The decoder's activations and y_full (device memory beyond the inputs
+ * and outputs) live in a file-scope device array of SUAVE_STATIC_SCRATCH_BYTES inside the library, one copy per
+ * GPU, resolved once per device by suave_plan_create (hipGetSymbolAddress) and held until the process ends.  The
+ * call makes no hipMalloc / hipFree and calls no allocating routine (with suave_profile_enable(1) the event pool may
+ * grow: leave profiling off).  Rows are limited by the buffer: n * 4 * (ldD + sum of hidden widths + y_rows, each
+ * rounded up to 4 floats and every array to 256 bytes) <= SUAVE_STATIC_SCRATCH_BYTES -- 14 979 rows for the
+ * 64-column benchmark model; a larger n fails with an error that names the limit.  Every call on one GPU shares
+ * that GPU's array, so calls that overlap on one GPU (two streams, two threads) race: serialise them.  The array
+ * keeps the previous call's contents; no kernel of this path needs it cleared. */
+#define SUAVE_STATIC_SCRATCH_BYTES (32u << 20)
+int suave_decode_sample_static(const suave_plan* plan, const float* params, const float* z, const float* s,
+                               const int32_t* component, int64_t n, const float* noise_normal,
+                               const float* noise_uniform, const float* noise_exp, uint64_t seed,
+                               int64_t row_offset, void* stream, float* out_num, int32_t ld_num,
+                               int16_t* out_codes, int32_t ld_disc, float* y_full_out);
+
 /* Posterior draws for the Monte-Carlo predictive: SUAVE._posterior_draws
  * (model.py:3304-3336).  enc_out [n_rows, K+2KD] as written by suave_encode;
  * n_draws = L; e [L, n_rows, K] Exp(1) and eps [L, n_rows, D] N(0,1) inject the

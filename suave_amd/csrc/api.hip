@@ -10,6 +10,7 @@ namespace suave {
 
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
+int resolve_static_scratch(suave_plan* p);  // defined beside the static scratch array below
 
 // ---------------------------------------------------------------------------
 // per-kernel-class timing (off by default; bench.py turns it on)
@@ -1195,6 +1196,7 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
       return dfail("plan_create: hipMalloc/hipMemcpy of the embedding table failed");
     if (round_up(m.enc[0].n_out, 4) > 1024) return fail("plan_create: first hidden layer wider than 1024 with embedded columns");
   }
+  if (int rc = resolve_static_scratch(p)) { suave_plan_destroy(p); return rc; }
   *out = p;
   return 0;
 }
@@ -1265,26 +1267,31 @@ extern "C" int suave_encode(const suave_plan* p, const float* params, const suav
                                 post_logvar, probs, s);
 }
 
-extern "C" int suave_decode_sample(const suave_plan* p, const float* params, const float* z, const float* s_dense,
-                                   const int32_t* component, int64_t n, const float* noise_normal,
-                                   const float* noise_uniform, const float* noise_exp, uint64_t seed,
-                                   int64_t row_offset, void* workspace, size_t workspace_bytes, void* stream,
-                                   float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc,
-                                   float* y_full_out) {
-  suave::drop_stale_hip_error();
-  SUAVE_REQUIRE(p && params, "decode_sample: null plan/params");
+namespace {
+
+// Scratch of the decode path: z with padded rows, the decoder's hidden activations, y_full.
+struct DecodeScratch {
+  float* z;
+  float* hd[SUAVE_MAX_HIDDEN];
+  float* y;
+};
+
+size_t carve_decode(const suave_plan* p, int64_t rows, void* base, DecodeScratch* d) {
+  Carver c{static_cast<char*>(base)};
+  const size_t R = (size_t)std::max<int64_t>(rows, 1);
+  d->z = c.take<float>(R * p->ldD);
+  for (int i = 0; i < p->model.n_hidden; ++i) d->hd[i] = c.take<float>(R * p->ldH[i]);
+  d->y = c.take<float>(R * p->ldY);
+  return (c.off + 255) & ~size_t(255);
+}
+
+// Decoder trunk + y_projection + per-column sample draw on caller-validated arguments.  None of the kernels
+// below needs its scratch to start at any value: pad columns are masked when the tiles are staged.
+int decode_sample_impl(const suave_plan* p, const float* params, const float* z, const float* s_dense,
+                       const int32_t* component, int B, const float* noise_normal, const float* noise_uniform,
+                       const float* noise_exp, uint64_t seed, int64_t row_offset, const DecodeScratch& w, hipStream_t st,
+                       float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc, float* y_full_out) {
   const suave_model_t& m = p->model;
-  SUAVE_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "decode_sample: row count out of range");
-  if (n == 0) return 0;  // empty request: nothing to read or write, buffers may be null
-  SUAVE_REQUIRE(z != nullptr, "decode_sample: z is null");
-  SUAVE_REQUIRE(s_dense != nullptr || component != nullptr, "decode_sample: need dense assignments or component indices");
-  SUAVE_REQUIRE((m.n_num == 0 || (out_num && ld_num >= m.n_num)) && (m.n_disc == 0 || (out_codes && ld_disc >= m.n_disc)),
-                "decode_sample: output buffers missing or too narrow");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  Workspace w;
-  carve(p, n, workspace, &w);
-  SUAVE_REQUIRE(workspace_bytes >= w.total_bytes, "workspace too small (see suave_workspace_bytes)");
-  const int B = (int)n;
   SUAVE_CHECK_HIP(hipMemcpy2DAsync(w.z, sizeof(float) * p->ldD, z, sizeof(float) * m.latent_dim,
                                    sizeof(float) * m.latent_dim, B, hipMemcpyDeviceToDevice, st));
   suave_batch_t dummy;
@@ -1302,8 +1309,85 @@ extern "C" int suave_decode_sample(const suave_plan* p, const float* params, con
   if (y_full_out)
     SUAVE_CHECK_HIP(hipMemcpy2DAsync(y_full_out, sizeof(float) * m.y_rows, w.y, sizeof(float) * p->ldY,
                                      sizeof(float) * m.y_rows, B, hipMemcpyDeviceToDevice, st));
-  return launch_sample_heads(p, p->cls_off_dev, params, w.y, s_dense, component, n, noise_normal, noise_uniform,
+  return launch_sample_heads(p, p->cls_off_dev, params, w.y, s_dense, component, B, noise_normal, noise_uniform,
                              noise_exp, seed, row_offset, out_num, ld_num, out_codes, ld_disc, st);
+}
+
+int check_decode_args(const suave_plan* p, const float* params, const float* z, const float* s_dense,
+                      const int32_t* component, int64_t n, const float* out_num, int32_t ld_num, const int16_t* out_codes,
+                      int32_t ld_disc) {
+  SUAVE_REQUIRE(p && params, "decode_sample: null plan/params");
+  const suave_model_t& m = p->model;
+  SUAVE_REQUIRE(n >= 0 && n < (int64_t(1) << 31), "decode_sample: row count out of range");
+  if (n == 0) return 0;  // empty request: nothing to read or write, buffers may be null
+  SUAVE_REQUIRE(z != nullptr, "decode_sample: z is null");
+  SUAVE_REQUIRE(s_dense != nullptr || component != nullptr, "decode_sample: need dense assignments or component indices");
+  SUAVE_REQUIRE((m.n_num == 0 || (out_num && ld_num >= m.n_num)) && (m.n_disc == 0 || (out_codes && ld_disc >= m.n_disc)),
+                "decode_sample: output buffers missing or too narrow");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int suave_decode_sample(const suave_plan* p, const float* params, const float* z, const float* s_dense,
+                                   const int32_t* component, int64_t n, const float* noise_normal,
+                                   const float* noise_uniform, const float* noise_exp, uint64_t seed,
+                                   int64_t row_offset, void* workspace, size_t workspace_bytes, void* stream,
+                                   float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc,
+                                   float* y_full_out) {
+  suave::drop_stale_hip_error();
+  if (int rc = check_decode_args(p, params, z, s_dense, component, n, out_num, ld_num, out_codes, ld_disc)) return rc;
+  if (n == 0) return 0;
+  // the workspace is sized by suave_workspace_bytes (the training step's carving); the decode uses its first part
+  Workspace w;
+  carve(p, n, nullptr, &w);
+  SUAVE_REQUIRE(workspace_bytes >= w.total_bytes, "workspace too small (see suave_workspace_bytes)");
+  SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
+  DecodeScratch d;
+  SUAVE_REQUIRE(carve_decode(p, n, workspace, &d) <= workspace_bytes, "workspace too small (see suave_workspace_bytes)");
+  return decode_sample_impl(p, params, z, s_dense, component, (int)n, noise_normal, noise_uniform, noise_exp, seed,
+                            row_offset, d, static_cast<hipStream_t>(stream), out_num, ld_num, out_codes, ld_disc, y_full_out);
+}
+
+// ---- the entry point that allocates nothing (include/suave_hip.h) -------------------------------------------
+// The decode's scratch lives in this file-scope device array: one copy per GPU the library runs on, held until
+// the process ends.  Host code never uses the array's name as an address: suave_plan_create resolves the
+// device's copy with hipGetSymbolAddress (plan->static_scratch) and every launch takes that pointer.
+static __device__ __align__(256) unsigned char scratch[SUAVE_STATIC_SCRATCH_BYTES];
+
+namespace suave {
+int resolve_static_scratch(suave_plan* p) {
+  void* ptr = nullptr;
+  SUAVE_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+  SUAVE_REQUIRE(ptr != nullptr && (reinterpret_cast<uintptr_t>(ptr) & 255) == 0, "static scratch: bad device address");
+  p->static_scratch = ptr;
+  return 0;
+}
+}  // namespace suave
+
+extern "C" int suave_decode_sample_static(const suave_plan* p, const float* params, const float* z, const float* s_dense,
+                                          const int32_t* component, int64_t n, const float* noise_normal,
+                                          const float* noise_uniform, const float* noise_exp, uint64_t seed,
+                                          int64_t row_offset, void* stream, float* out_num, int32_t ld_num,
+                                          int16_t* out_codes, int32_t ld_disc, float* y_full_out) {
+  suave::drop_stale_hip_error();
+  if (int rc = check_decode_args(p, params, z, s_dense, component, n, out_num, ld_num, out_codes, ld_disc)) return rc;
+  if (n == 0) return 0;
+  SUAVE_REQUIRE(p->static_scratch != nullptr, "decode_sample_static: the plan holds no static scratch address");
+  int dev = -1;
+  SUAVE_CHECK_HIP(hipGetDevice(&dev));
+  SUAVE_REQUIRE(dev == p->device, "decode_sample_static: the plan belongs to another device (each GPU has its own scratch)");
+  DecodeScratch d;
+  const size_t need = carve_decode(p, n, p->static_scratch, &d);
+  if (need > (size_t)SUAVE_STATIC_SCRATCH_BYTES) {
+    const size_t per_row = carve_decode(p, 4096, nullptr, &d) / 4096 + 1;
+    set_error("decode_sample_static: " + std::to_string((long long)n) + " rows need " + std::to_string(need) +
+              " bytes of scratch, the static buffer holds " + std::to_string((size_t)SUAVE_STATIC_SCRATCH_BYTES) +
+              " (about " + std::to_string((size_t)SUAVE_STATIC_SCRATCH_BYTES / per_row) + " rows of this model); split the request");
+    return 1;
+  }
+  return decode_sample_impl(p, params, z, s_dense, component, (int)n, noise_normal, noise_uniform, noise_exp, seed,
+                            row_offset, d, static_cast<hipStream_t>(stream), out_num, ld_num, out_codes, ld_disc, y_full_out);
 }
 
 extern "C" int suave_gemm_arithmetic_set(int mode) { return gemm_split_mode_set(mode); }

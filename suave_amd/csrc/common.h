@@ -119,6 +119,7 @@ struct suave_plan {
   std::vector<suave::EmbedCol> embed_host;
   suave::EmbedCol* embed_dev = nullptr;
   int embed_classes_total = 0;
+  void* static_scratch = nullptr;  // this device's copy of api.hip's static scratch array (suave_decode_sample_static)
 };
 
 namespace suave {

@@ -250,6 +250,21 @@ class Engine:
             return out_num[:, : L.n_num], out_codes[:, : L.n_disc], y_out
         return out_num[:, : L.n_num], out_codes[:, : L.n_disc]
 
+    def decode_sample_static(self, z: torch.Tensor, out_num: torch.Tensor, out_codes: torch.Tensor, *,
+                             component: Optional[torch.Tensor] = None, assignments: Optional[torch.Tensor] = None,
+                             noise_normal=None, noise_uniform=None, noise_exp=None, seed: int = 0, row_offset: int = 0,
+                             y_out: Optional[torch.Tensor] = None) -> None:
+        """suave_decode_sample_static: the decode for callers that cannot allocate.  Every buffer, outputs
+        included, comes from the caller; the library's scratch is its own static device array, so this method
+        itself creates no tensor (rows are limited by SUAVE_STATIC_SCRATCH_BYTES, include/suave_hip.h)."""
+
+        rc = self.lib.suave_decode_sample_static(self._plan, self.params.data_ptr(), z.data_ptr(), _ptr(assignments),
+                                                 _ptr(component), int(z.shape[0]), _ptr(noise_normal),
+                                                 _ptr(noise_uniform), _ptr(noise_exp), int(seed), int(row_offset),
+                                                 self._stream(), out_num.data_ptr(), int(out_num.shape[1]),
+                                                 out_codes.data_ptr(), int(out_codes.shape[1]), _ptr(y_out))
+        _lib.check(rc, "suave_decode_sample_static")
+
     # -- Monte-Carlo posterior predictive ------------------------------------------
     def posterior_draws(self, enc_out: torch.Tensor, L: int, *, e=None, eps=None, seed: int = 0, row_offset: int = 0):
         """SUAVE._posterior_draws: returns z [L*B, D] and component [L*B] (draw-major)."""

@@ -27,6 +27,7 @@ EXPORTS = (
     "suave_prior_latents",
     "suave_conditional_latents",
     "suave_decode_sample",
+    "suave_decode_sample_static",
     "suave_posterior_draws",
     "suave_head_params_width",
     "suave_decode_params",
@@ -81,6 +82,7 @@ def load():
     lib.suave_prior_latents.argtypes = [vp, vp, vp, vp, vp, u64, i64, i64, vp, vp, vp]
     lib.suave_conditional_latents.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, i64, i64, vp, vp, vp]
     lib.suave_decode_sample.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, u64, i64, vp, sz, vp, vp, i32, vp, i32, vp]
+    lib.suave_decode_sample_static.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, u64, i64, vp, vp, i32, vp, i32, vp]
     lib.suave_posterior_draws.argtypes = [vp, vp, i64, i32, vp, vp, u64, i64, vp, vp, vp]
     lib.suave_head_params_width.argtypes = [vp, i32, C.POINTER(i32)]
     lib.suave_decode_params.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, sz, vp, vp]
