@@ -555,10 +555,12 @@ def gumbel_softmax(logits, exp_noise, tau):
 # supervised ELBO step  (model.py:1562-1618, 1656-1667)
 # ---------------------------------------------------------------------------
 def elbo_supervised(model, P, x_enc, data, masks, noise, *, beta_scale, tau=1.0,
-                    training=True, want_grad=True):
+                    training=True, want_grad=True, dlatent=None):
     """``SUAVE._forward_elbo_batch`` (behaviour="supervised") and, when
     ``want_grad``, the gradient of ``loss`` w.r.t. every parameter (what
-    ``loss.backward()`` at model.py:1505 leaves in ``.grad``)."""
+    ``loss.backward()`` at model.py:1505 leaves in ``.grad``).  ``dlatent`` [B, D] is the gradient an extra
+    loss term sends into ``outputs["latent"]`` -- the classifier's cross-entropy of joint fine-tuning
+    (model.py:1987-1991)."""
 
     dt = x_enc.dtype
     B = x_enc.shape[0]
@@ -604,6 +606,8 @@ def elbo_supervised(model, P, x_enc, data, masks, noise, *, beta_scale, tau=1.0,
     grads["decoder.y_projection.bias"] = dY.sum(axis=0)
     dh = dY @ P["decoder.y_projection.weight"]
     dz = _backbone_backward("decoder", model, P, dcache["acts"], dcache["pre"], dh, grads, True)
+    if dlatent is not None:
+        dz = dz + np.asarray(dlatent, dt)
     # Gaussian KL (selected component only) + reparameterisation
     vp_raw = np.exp(plv[k])
     vp = np.maximum(vp_raw, dt.type(1e-6))
@@ -798,3 +802,45 @@ def mixture_posterior_statistics(logits, mu, logvar, temperature=None):
     second = (p[:, :, None] * (np.exp(logvar) + mu * mu)).sum(axis=1)
     var = np.maximum(second - wmu * wmu, mu.dtype.type(1e-6))
     return wmu, np.log(var), p
+
+
+# ---------------------------------------------------------------------------
+# rest of the supervised schedule (model.py:1866-2495)
+# ---------------------------------------------------------------------------
+def classifier_loss(latent, W, b, class_weight, targets):
+    """``ClassificationHead`` without hidden layers (heads.py:78-91): logits = latent W^T + b and the weighted
+    cross-entropy ``F.cross_entropy(logits, targets, weight)`` = sum_i w[t_i] * (-log p_i[t_i]) / sum_i w[t_i].
+    Returns loss, logits and the gradients w.r.t. latent, W and b."""
+
+    dt = latent.dtype
+    logits = latent @ W.T + b
+    lp = log_softmax(logits)
+    n = latent.shape[0]
+    rows = np.arange(n)
+    w = np.asarray(class_weight, dt)[targets]
+    loss = -(w * lp[rows, targets]).sum() / w.sum()
+    g = np.exp(lp)
+    g[rows, targets] -= 1.0
+    g = g * (w / w.sum())[:, None]
+    return loss, logits, g @ W, g.T @ latent, g.sum(axis=0)
+
+
+def prior_anchor_gradient(P, anchors, lam):
+    """Gradient of ``lam * sum_t mse(prior_t, anchor_t)`` (model.py:2338-2346, reduction="mean")."""
+
+    return {k: (2.0 * lam / P[k].size) * (P[k] - anchors[k]) for k in anchors}
+
+
+def closed_form_prior_update(probs, mu, logvar):
+    """``_closed_form_prior_update_from_stats`` (model.py:2447-2495): prior logits, means and log-variances
+    from posterior responsibilities."""
+
+    dt = probs.dtype
+    w = probs.sum(axis=0)
+    total = float(w.sum())
+    mixture = np.maximum(w / dt.type(total), dt.type(1e-6))
+    cw = np.maximum(w[:, None], dt.type(1e-6))
+    means = (probs[:, :, None] * mu).sum(axis=0) / cw
+    second = (probs[:, :, None] * (np.exp(logvar) + mu * mu)).sum(axis=0) / cw
+    var = np.maximum(second - means * means, dt.type(1e-6))
+    return np.log(mixture), means, np.log(var)

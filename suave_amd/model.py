@@ -41,6 +41,31 @@ _DEFAULTS = dict(latent_dim=32, n_components=1, beta=1.5, hidden_dims=(256, 128)
 _REFINE_MODES = ("decoder_only", "decoder_prior", "prior_em_only", "prior_em_decoder")
 
 
+class DrawReplay:
+    """Recorded draws of a reference run, consumed in call order by the training phases (parity tests): the
+    per-epoch permutations and, per ELBO call (training batches and validation batches alike), the Exp(1) draws
+    behind the Gumbel noise and the reparameterisation eps.  ``SUAVE._replay`` is None in production: the phases
+    then draw ``torch.randperm`` on the device and the kernels draw their noise from the counter-based generators."""
+
+    def __init__(self, perms, steps) -> None:
+        self.perms = [np.asarray(p, np.int64) for p in perms]
+        self.steps = list(steps)
+        self.grads = []  # filled by the phases: the flat gradient of every optimisation step, before Adam
+
+    def next_perm(self, n: int, device) -> torch.Tensor:
+        p = self.perms.pop(0)
+        if len(p) != n:
+            raise ValueError(f"replayed permutation has {len(p)} rows, the epoch has {n}")
+        return torch.from_numpy(p).to(device)
+
+    def next_noise(self, n_rows: int, device) -> Dict[str, torch.Tensor]:
+        st = self.steps.pop(0)
+        if st["exp"].shape[0] != n_rows:
+            raise ValueError(f"replayed noise has {st['exp'].shape[0]} rows, the batch has {n_rows}")
+        return {"exp_noise": torch.from_numpy(np.ascontiguousarray(st["exp"], np.float32)).to(device),
+                "eps": torch.from_numpy(np.ascontiguousarray(st["eps"], np.float32)).to(device)}
+
+
 class SUAVE:
     def __init__(self, schema: Optional[Schema] = None, *, behaviour: Literal["supervised", "unsupervised"] = "supervised",
                  latent_dim: Optional[int] = None, n_components: int = 1, beta: float = 1.5,
@@ -119,8 +144,24 @@ class SUAVE:
         self._joint_history: list = []
         self._refine_history: list = []
         self._step = 0
+        self._replay: Optional[DrawReplay] = None
+        # which constructor arguments were left to the defaults (model.py:460-473; persisted by save)
+        self._auto_configured: Dict[str, bool] = {
+            "latent_dim": latent_dim is None, "hidden_dims": hidden_dims is None, "head_hidden_dims": False,
+            "classification_loss_weight": classification_loss_weight is None, "dropout": dropout is None,
+            "learning_rate": learning_rate is None, "batch_size": batch_size is None,
+            "kl_warmup_epochs": kl_warmup_epochs is None, "warmup_epochs": warmup_epochs is None,
+            "head_epochs": head_epochs is None, "finetune_epochs": finetune_epochs is None,
+            "early_stop_patience": early_stop_patience is None}
 
     # ------------------------------------------------------------------
+    def _noise_for(self, n_rows: int):
+        return None if self._replay is None else self._replay.next_noise(n_rows, self._engine.device)
+
+    def _record_step_gradient(self) -> None:
+        if self._replay is not None:
+            self._replay.grads.append(self._engine.grads.clone())
+
     def _select_device(self) -> torch.device:
         if self._device is not None:
             return torch.device(self._device)
@@ -258,7 +299,10 @@ class SUAVE:
 
     # ------------------------------------------------------------------
     def _epoch_batches(self, n_rows: int, eff: int):
-        perm = torch.randperm(n_rows, device=self._engine.device, generator=self._gen, dtype=torch.int64)
+        if self._replay is not None:
+            perm = self._replay.next_perm(n_rows, self._engine.device)
+        else:
+            perm = torch.randperm(n_rows, device=self._engine.device, generator=self._gen, dtype=torch.int64)
         perm32 = perm.to(torch.int32)
         for start in range(0, n_rows, max(eff, 1)):  # last batch ragged, no drop-last (model.py:1475-1476)
             yield perm[start:start + eff], perm32[start:start + eff]
@@ -284,7 +328,9 @@ class SUAVE:
                 self._step += 1
                 beta = self.beta * min(warm_step, kl_steps) / kl_steps  # losses.kl_warmup
                 eng.elbo(train, 0, int(idx.numel()), row_index=idx, beta_scale=beta, tau=tau, grad=True,
-                         seed=self.random_state, step=self._step, accumulate_sums=True)
+                         seed=self.random_state, step=self._step, accumulate_sums=True,
+                         noise=self._noise_for(int(idx.numel())))
+                self._record_step_gradient()
                 eng.adam_step(self.learning_rate)
             s = eng.sums.cpu().numpy()  # ONE host sync per epoch (the reference syncs 4-5x per batch)
             cnt = max(s[3], 1.0)
@@ -398,14 +444,16 @@ class SUAVE:
             for idx64, idx in self._epoch_batches(n, eff):
                 nb = int(idx.numel())
                 self._step += 1
+                nz = self._noise_for(nb)
                 fwd = eng.elbo(train, 0, nb, row_index=idx, beta_scale=self.beta, tau=tau, grad=False, training=True,
-                               seed=self.random_state, step=self._step, want=("latent",))
+                               seed=self.random_state, step=self._step, want=("latent",), noise=nz)
                 latent = fwd["latent"].requires_grad_(True)
                 class_loss = clf.loss(clf(latent), y_t[idx64])
                 clf_opt.zero_grad()
                 (class_loss * weight).backward()
                 eng.elbo(train, 0, nb, row_index=idx, beta_scale=self.beta, tau=tau, grad=True, seed=self.random_state,
-                         step=self._step, accumulate_sums=True, dlatent=latent.grad.contiguous())
+                         step=self._step, accumulate_sums=True, dlatent=latent.grad.contiguous(), noise=nz)
+                self._record_step_gradient()
                 eng.adam_step(lrs)
                 clf_opt.step()
                 ce_tot += class_loss.detach().double() * nb
@@ -516,12 +564,14 @@ class SUAVE:
             for _, idx in self._epoch_batches(n, eff):
                 self._step += 1
                 eng.elbo(train, 0, int(idx.numel()), row_index=idx, beta_scale=self.beta, tau=tau, grad=True,
-                         seed=self.random_state, step=self._step, accumulate_sums=True)
+                         seed=self.random_state, step=self._step, accumulate_sums=True,
+                         noise=self._noise_for(int(idx.numel())))
                 if anchors and lam != 0.0:  # + lambda * sum_t mse(prior_t, anchor_t)  (model.py:2338-2346)
                     for slot, snap in anchors:
                         nel = int(np.prod(slot.shape))
                         g = eng.grads[slot.offset: slot.offset + nel].view(*slot.shape)
                         g.add_((self._prior_view(slot.name) - snap) * (2.0 * lam / nel))
+                self._record_step_gradient()
                 eng.adam_step(lrs)
             done += 1
             s = eng.sums.cpu().numpy()
@@ -546,7 +596,7 @@ class SUAVE:
         for i, start in enumerate(range(0, table.n_rows, eff)):
             nb = min(eff, table.n_rows - start)
             eng.elbo(table, start, nb, beta_scale=self.beta, tau=tau, grad=False, training=False, seed=seed, step=i,
-                     accumulate_sums=True)
+                     accumulate_sums=True, noise=self._noise_for(nb))
         s = eng.sums.cpu().numpy()
         n = max(s[3], 1.0)
         return {"nll": float(((s[1] + s[2]) * self.beta - s[0]) / n), "reconstruction": float(s[0] / n),
@@ -572,6 +622,8 @@ class SUAVE:
             "mu": enc[:, K:K + K * D].reshape(-1, K, D).contiguous(),
             "logvar": enc[:, K + K * D:].reshape(-1, K, D).contiguous(),
             "mean": torch.cat([o["mean"] for o in outs]),
+            "post_logvar": torch.cat([o["logvar"] for o in outs]),       # _train_latent_logvar (model.py:2735-2737)
+            "logits": enc[:, :K].contiguous(),                           # _train_component_logits
         }
 
     # ------------------------------------------------------------------
@@ -610,9 +662,13 @@ class SUAVE:
         return torch.from_numpy(np.cumsum(p).astype(np.float32)).to(self._engine.device)
 
     def sample(self, n_samples: int, conditional: bool = False, y=None, batch_size: Optional[int] = None,
-               seed: Optional[int] = None) -> pd.DataFrame:
+               seed: Optional[int] = None, _noise: Optional[Dict[str, torch.Tensor]] = None) -> pd.DataFrame:
         """Generate rows (model.py:4284-4431).  Row ``i`` depends only on ``(seed, i)``: the output is independent
-        of ``batch_size`` and of how rows are sharded over GPUs."""
+        of ``batch_size`` and of how rows are sharded over GPUs.
+
+        ``_noise`` injects the draws instead of generating them from ``seed`` (parity tests): ``u`` [n] and ``eps``
+        [n,D] of the prior draw, or ``u_row`` [n], ``e_comp`` [n,K] and ``eps`` of the conditional draw, and
+        ``normal`` / ``uniform`` [n,n_cols], ``exp`` [n,total classes] of the head samplers."""
 
         self._require_fitted("sample")
         if n_samples <= 0:
@@ -647,15 +703,27 @@ class SUAVE:
         else:
             cdf = self._prior_cdf()
         frames = []
+        nz = _noise or {}
+
+        def rows_of(key, start, nb):  # the chunk's rows of an injected draw tensor
+            t = nz.get(key)
+            return None if t is None else t[start:start + nb].contiguous()
+
         for start in range(0, n_samples, chunk):
             nb = min(chunk, n_samples - start)
             if conditional:
                 z, comp = eng.conditional_latents(labels_t[start:start + nb].contiguous(), class_off_t, class_rows_t,
                                                   self._train_cache["probs"], self._train_cache["mu"],
-                                                  self._train_cache["logvar"], seed=seed, row_offset=start)
+                                                  self._train_cache["logvar"], u_row=rows_of("u_row", start, nb),
+                                                  e_comp=rows_of("e_comp", start, nb), eps=rows_of("eps", start, nb),
+                                                  seed=seed, row_offset=start)
             else:
-                z, comp = eng.prior_latents(nb, cdf, seed=seed, row_offset=start)
-            onum, ocodes = eng.decode_sample(z, component=comp, seed=seed + 1, row_offset=start)
+                z, comp = eng.prior_latents(nb, cdf, u=rows_of("u", start, nb), eps=rows_of("eps", start, nb),
+                                            seed=seed, row_offset=start)
+            onum, ocodes = eng.decode_sample(z, component=comp, seed=seed + 1, row_offset=start,
+                                             noise_normal=rows_of("normal", start, nb),
+                                             noise_uniform=rows_of("uniform", start, nb),
+                                             noise_exp=rows_of("exp", start, nb))
             frames.append(data_utils.frame_from_packed(onum.cpu().numpy(), ocodes.cpu().numpy(), self.schema,
                                                        self._norm_stats_per_col))
         return pd.concat(frames, ignore_index=True) if len(frames) > 1 else frames[0]
@@ -952,76 +1020,124 @@ class SUAVE:
         return imputed.loc[:, X.columns]
 
     # ------------------------------------------------------------------
-    def save(self, path) -> None:
-        """Persist the model in the reference's payload layout (model.py:4456-4579): ``metadata``, ``modules``
-        (``encoder`` / ``decoder`` / ``prior`` / ``classifier`` state dicts under the reference's key names, so an
-        archive written here loads into the reference's modules and vice versa), ``artefacts``."""
+    def _payload(self) -> Dict[str, object]:
+        """The reference's archive payload (model.py:4484-4578) for this model: same key tree, same state_dict key
+        names, so `suave.SUAVE.load` reads an archive written here and `SUAVE.load` here reads the reference's."""
 
-        self._require_fitted("save")
-        st = self._engine.state()
-        enc = {k[len("encoder."):]: torch.from_numpy(v.copy()) for k, v in st.items() if k.startswith("encoder.")}
-        dec = {k[len("decoder."):]: torch.from_numpy(v.copy()) for k, v in st.items() if k.startswith("decoder.")}
-        prior = {k: torch.from_numpy(v.copy()) for k, v in st.items() if k.startswith("prior")}
+        from . import persist
+
+        unsup = self.behaviour == "unsupervised"
         meta = dict(behaviour=self.behaviour, latent_dim=self.latent_dim, n_components=self.n_components, beta=self.beta,
                     hidden_dims=list(self.hidden_dims), head_hidden_dims=list(self.head_hidden_dims), dropout=self.dropout,
-                    learning_rate=self.learning_rate, batch_size=self.batch_size, random_state=self.random_state,
-                    gumbel_temperature=self.gumbel_temperature, inference_tau=self._inference_tau,
+                    learning_rate=self.learning_rate, batch_size=self.batch_size, kl_warmup_epochs=self.kl_warmup_epochs,
+                    val_split=self.val_split, stratify=self.stratify, random_state=self.random_state,
+                    gumbel_temperature=self.gumbel_temperature, tau_start=self._tau_start if unsup else None,
+                    tau_min=self._tau_min if unsup else None, tau_decay=self._tau_decay if unsup else None,  # model.py:476-492
+                    inference_tau=self._inference_tau, warmup_epochs=self.warmup_epochs,
+                    head_epochs=self.head_epochs, finetune_epochs=self.finetune_epochs,
+                    decoder_refine_epochs=self.decoder_refine_epochs, decoder_refine_mode=self.decoder_refine_mode,
+                    decoder_refine_prior_lambda=self.decoder_refine_prior_lambda,
+                    joint_decoder_lr_scale=self.joint_decoder_lr_scale, early_stop_patience=self.early_stop_patience,
                     classification_loss_weight=self.classification_loss_weight,
-                    schema=self.schema.to_dict(), format="suave_amd/1")
-        payload = {
-            "metadata": meta,
-            "modules": {"encoder": enc, "decoder": dec, "prior": prior,
-                        "classifier": ({k: v.detach().cpu() for k, v in self._classifier.state_dict().items()}
-                                       if self._classifier is not None else None),
-                        "temperature_scaler": self._temperature_scaler.state_dict()},
-            "artefacts": {
-                "norm_stats_per_col": self._norm_stats_per_col,
-                "classes": None if self._classes is None else self._classes.tolist(),
-                "is_calibrated": self._is_calibrated,
-                "train_target_indices": (None if getattr(self, "_train_target_indices", None) is None
-                                         else torch.from_numpy(np.asarray(self._train_target_indices))),
-                "train_cache": {k: v.detach().cpu() for k, v in self._train_cache.items()},
-            },
-        }
-        torch.save(payload, path)
+                    auto_configured={**self._auto_configured,
+                                     "classification_loss_weight": not self._classification_loss_weight_user},
+                    auto_hyperparameters=None)
+        clf_state = class_weight = None
+        use_weight = False
+        if self._classifier is not None:
+            clf_state = {k: v.detach().cpu() for k, v in self._classifier.state_dict().items()}
+            use_weight = bool(self._classifier._use_weight)
+            class_weight = self._classifier.class_weight.detach().cpu()
+        return persist.build_payload(
+            metadata=meta, state=self._engine.state(), schema=self.schema, classifier_state=clf_state,
+            class_weight=class_weight, use_weight=use_weight, temperature_scaler=self._temperature_scaler.state_dict(),
+            norm_stats=self._norm_stats_per_col, classes=self._classes, class_to_index=self._class_to_index,
+            is_calibrated=self._is_calibrated, train_cache=self._train_cache,
+            train_target_indices=getattr(self, "_train_target_indices", None),
+            warmup_val_history=self._warmup_val_history, joint_val_metrics=self._joint_val_metrics)
+
+    def save(self, path):
+        """Serialise the model in the reference's archive layout (model.py:4456-4579)."""
+
+        from pathlib import Path
+
+        self._require_fitted("saving")
+        path = Path(path)
+        torch.save(self._payload(), path)
+        return path
 
     @classmethod
     def load(cls, path, *, device: Optional[str] = None) -> "SUAVE":
-        """Restore a model written by :meth:`save` (model.py:4581-4681).  Only plain containers and tensors are
-        stored, so the archive is read with ``weights_only=True``."""
+        """Restore a model from an archive in the reference's layout (model.py:4581-4950), written by either
+        implementation.  The file is read with ``weights_only=True`` (persist.load_archive)."""
 
-        payload = torch.load(path, map_location="cpu", weights_only=True)
-        meta, mods, art = payload["metadata"], payload["modules"], payload["artefacts"]
-        model = cls(Schema(meta["schema"]), behaviour=meta["behaviour"], latent_dim=meta["latent_dim"],
-                    n_components=meta["n_components"], beta=meta["beta"], hidden_dims=meta["hidden_dims"],
-                    head_hidden_dims=meta.get("head_hidden_dims", ()), dropout=meta["dropout"],
-                    learning_rate=meta["learning_rate"], batch_size=meta["batch_size"], random_state=meta["random_state"],
-                    gumbel_temperature=meta["gumbel_temperature"],
-                    classification_loss_weight=meta.get("classification_loss_weight"), device=device)
-        model._inference_tau = float(meta.get("inference_tau", 1.0))
-        model._norm_stats_per_col = art["norm_stats_per_col"]
+        from . import persist
+
+        payload = persist.load_archive(path)
+        if not isinstance(payload, dict) or "metadata" not in payload:
+            raise ValueError("Unexpected model archive format")
+        return cls._load_from_payload(payload, device=device)
+
+    @classmethod
+    def _load_from_payload(cls, payload, *, device: Optional[str] = None) -> "SUAVE":
+        from . import persist
+
+        meta, mods, art = payload.get("metadata", {}), payload.get("modules", {}), payload.get("artefacts", {})
+        if not meta.get("schema"):
+            raise ValueError("Schema is required to restore decoder state")
+        kwargs = {}
+        for key in ("latent_dim", "n_components", "beta", "hidden_dims", "head_hidden_dims", "classification_loss_weight",
+                    "dropout", "learning_rate", "batch_size", "kl_warmup_epochs", "val_split", "stratify", "random_state",
+                    "gumbel_temperature", "tau_start", "tau_min", "tau_decay", "warmup_epochs", "head_epochs",
+                    "finetune_epochs", "decoder_refine_epochs", "decoder_refine_mode", "decoder_refine_prior_lambda",
+                    "joint_decoder_lr_scale", "early_stop_patience"):  # model.py:4695-4751
+            if meta.get(key) is not None:
+                kwargs[key] = meta[key]
+        model = cls(Schema(meta["schema"]), behaviour=str(meta.get("behaviour", "supervised")).lower(), device=device,
+                    **kwargs)
+        auto = meta.get("heuristic_overrides")
+        if not isinstance(auto, dict):
+            auto = meta.get("auto_configured")
+        if isinstance(auto, dict):
+            model._auto_configured = {k: bool(v) for k, v in auto.items()}
+            model._classification_loss_weight_user = not bool(auto.get("classification_loss_weight", False))
+        if meta.get("inference_tau") is not None:
+            model._inference_tau = float(meta["inference_tau"])
+        model._norm_stats_per_col = art.get("normalization", {})
         model._layout = ModelLayout(model.schema, model.n_components, model.latent_dim, model.hidden_dims, model.dropout,
                                     model.behaviour, model._norm_stats_per_col)
         model._engine = eng = Engine(model._layout, model._select_device())
-        tensors = {"encoder." + k: v.numpy() for k, v in mods["encoder"].items()}
-        tensors.update({"decoder." + k: v.numpy() for k, v in mods["decoder"].items()})
-        tensors.update({k: v.numpy() for k, v in mods["prior"].items()})
-        eng.load_state(tensors)
+        eng.load_state(persist.state_from_payload(payload))
+        model._class_to_index = art.get("class_to_index")
         if art.get("classes") is not None:
             model._classes = np.asarray(art["classes"])
             model.classes_ = model._classes
-            model._class_to_index = {c.item() if isinstance(c, np.generic) else c: i for i, c in enumerate(model._classes)}
+            if model._class_to_index is None:
+                model._class_to_index = {c.item() if isinstance(c, np.generic) else c: i
+                                         for i, c in enumerate(model._classes)}
         if art.get("train_target_indices") is not None:
-            model._train_target_indices = art["train_target_indices"].numpy()
-        if mods.get("classifier") is not None:
-            cstate = mods["classifier"]
-            model._classifier = sup.ClassificationHead(model.latent_dim, int(cstate["linear.weight"].shape[0]),
-                                                       class_weight=cstate["class_weight"].numpy(), dropout=model.dropout,
-                                                       hidden_dims=model.head_hidden_dims).to(eng.device)
-            model._classifier.load_state_dict(cstate)
+            tt = art["train_target_indices"]
+            model._train_target_indices = np.asarray(tt.numpy() if isinstance(tt, torch.Tensor) else tt)
+        clf = mods.get("classifier")
+        if model.behaviour == "supervised" and clf:
+            if model._classes is None:
+                raise ValueError("Saved model is missing class labels")
+            cw = clf.get("class_weight") if clf.get("use_weight") else None
+            model._classifier = sup.ClassificationHead(model.latent_dim, int(model._classes.size),
+                                                       class_weight=None if cw is None else np.asarray(cw, np.float32),
+                                                       dropout=model.dropout, hidden_dims=model.head_hidden_dims).to(eng.device)
+            if clf.get("state_dict") is not None:
+                model._classifier.load_state_dict(dict(clf["state_dict"]))
             model._classifier.eval()
-        model._temperature_scaler.load_state_dict(mods.get("temperature_scaler", {}))
-        model._is_calibrated = bool(art.get("is_calibrated", False))
-        model._train_cache = {k: v.to(eng.device) for k, v in art.get("train_cache", {}).items()}
+        tstate = mods.get("temperature_scaler") or {}
+        model._temperature_scaler.load_state_dict(tstate)
+        model._is_calibrated = bool(tstate.get("fitted", False))  # model.py:4889-4891
+        cache = {"probs": art.get("train_component_probs"), "mu": art.get("train_component_mu"),
+                 "logvar": art.get("train_component_logvar"), "mean": art.get("train_latent_mu"),
+                 "post_logvar": art.get("train_latent_logvar"), "logits": art.get("train_component_logits")}
+        model._train_cache = {k: torch.as_tensor(v).float().contiguous().to(eng.device) for k, v in cache.items()
+                              if v is not None}
+        model._warmup_val_history = list(art.get("warmup_val_history") or [])
+        model._joint_val_metrics = art.get("joint_val_metrics")
         model._is_fitted = True
         return model

@@ -63,6 +63,14 @@ class NoiseTape:
         self.multinomial_exp = []
         self.poisson_u = []
         self.poisson_n = []
+        self.randint_u = []
+        self.prior_u = []
+        self.perms = []
+        # Categorical.sample((n,)) from ONE distribution (sampling.py:49-50): "race" = n exponential races
+        # (posterior draws), "cdf" = inversion of the prior's cumulative distribution on binary32 uniforms
+        # (the build's suave_prior_latents map); `prior_logits` must then hold the distribution's logits
+        self.multi_mode = "race"
+        self.prior_logits = None
         self._orig = {}
 
     def __enter__(self):
@@ -72,6 +80,23 @@ class NoiseTape:
         self._orig["dropout"] = F.dropout
         self._orig["multinomial"] = torch.multinomial
         self._orig["poisson"] = torch.poisson
+        self._orig["randint"] = torch.randint
+        self._orig["randperm"] = torch.randperm
+
+        def randint(low, high, size, *a, **k):
+            # torch.randint(0, n, (1,)) of _draw_conditional_latents (model.py:3088): integer draws cannot be replayed
+            # from a binary32 uniform, so the build defines pick = min(int(u * n), n - 1) and the same map replaces
+            # the primitive here (like torch.poisson below)
+            assert low == 0 and tuple(size) == (1,)
+            u = torch.rand(1)
+            tape.randint_u.append(u.clone())
+            pick = min(int(np.float32(u.numpy()[0]) * np.float32(high)), int(high) - 1)
+            return torch.tensor([pick], dtype=torch.long)
+
+        def randperm(n, *a, **k):
+            out = tape._orig["randperm"](n, *a, **k)
+            tape.perms.append(out.detach().clone())
+            return out
 
         def randn_like(t, *a, **k):
             out = tape._orig["randn_like"](t, *a, **k)
@@ -101,6 +126,12 @@ class NoiseTape:
             # which cannot be injected in binary32; the build defines the draw as L independent
             # exponential races and the same map replaces the primitive here (like torch.poisson below)
             assert replacement
+            if tape.multi_mode == "cdf":
+                assert probs.shape[0] == 1 and tape.prior_logits is not None
+                u = torch.rand(num_samples)
+                tape.prior_u.append(u.clone())
+                k = sorc.component_from_uniform(sorc.prior_cdf(tape.prior_logits), u.numpy().astype(np.float32))
+                return torch.from_numpy(k).view(1, -1)
             q = torch.empty((num_samples,) + tuple(probs.shape), dtype=probs.dtype)
             tape._orig["exponential_"](q)
             tape.multinomial_exp.append(q.detach().clone())
@@ -124,6 +155,8 @@ class NoiseTape:
         torch.nn.functional.dropout = dropout
         torch.multinomial = multinomial
         torch.poisson = poisson
+        torch.randint = randint
+        torch.randperm = randperm
         return self
 
     def __exit__(self, *exc):
@@ -133,6 +166,8 @@ class NoiseTape:
         torch.nn.functional.dropout = self._orig["dropout"]
         torch.multinomial = self._orig["multinomial"]
         torch.poisson = self._orig["poisson"]
+        torch.randint = self._orig["randint"]
+        torch.randperm = self._orig["randperm"]
         return False
 
 
@@ -641,6 +676,377 @@ def gen_tensorise(name, seed, n=40):
     print("wrote", name)
 
 
+def _head_noise(rec, pre, cols, tape, i_rn, i_mn, i_ps):
+    """Per-column head-sampler draws of ONE decoder forward, in schema order, starting at the given tape positions."""
+
+    for c in cols:
+        if c.type in ("real", "pos"):
+            rec[pre + f"noise/{c.name}/normal"] = tape.randn[i_rn].numpy()
+            i_rn += 1
+        elif c.type in ("cat", "ordinal"):
+            rec[pre + f"noise/{c.name}/exp"] = tape.multinomial_exp[i_mn].numpy()
+            i_mn += 1
+        else:
+            rec[pre + f"noise/{c.name}/uniform"] = tape.poisson_u[i_ps].numpy()
+            rec[pre + f"noise/{c.name}/normal"] = tape.poisson_n[i_ps].numpy()
+            i_ps += 1
+    return i_rn, i_mn, i_ps
+
+
+def _frame_to_rec(rec, pre, cols, frame):
+    for c in cols:
+        v = frame[c.name]
+        if c.type in ("cat", "ordinal"):
+            rec[pre + f"frame/{c.name}"] = np.asarray(v.cat.codes, np.int64)
+            rec[pre + f"categories/{c.name}"] = np.asarray([str(x) for x in v.cat.categories])
+            rec[pre + f"ordered/{c.name}"] = np.asarray(bool(v.cat.ordered))
+        else:
+            rec[pre + f"frame/{c.name}"] = v.to_numpy()
+        rec[pre + f"dtype/{c.name}"] = np.asarray(str(v.dtype))
+
+
+def gen_generation(name, kind, K, D, hidden, n, seed, n_train=60):
+    """The latent sources of generation and the composed SUAVE.sample (a18 / a19 / a23):
+    sampling.sample_prepared_mixture_latents (sampling.py:38-56) for both behaviours,
+    SUAVE._draw_conditional_latents (model.py:3042-3114) and SUAVE.sample(conditional=False | True)
+    (model.py:4284-4431), each run UNTOUCHED under the noise tape."""
+
+    import warnings
+
+    rng = np.random.default_rng(seed)
+    cols = make_columns(kind)
+    rec = {"columns": cols_json(cols),
+           "meta": json.dumps(dict(kind=kind, K=K, D=D, hidden=list(hidden), n=n, seed=seed, n_train=n_train))}
+    cpu = torch.device("cpu")
+    for behaviour in ("supervised", "unsupervised"):
+        model, om = build_reference(cols, K, D, hidden, 0.0, behaviour, seed)
+        model._is_fitted = True
+        model._decoder.eval()
+        model._select_device = lambda: cpu
+        # category labels of two discrete columns (norm stats drive decoder_outputs_to_frame, sampling.py:156-176)
+        stats = {c.name: dict(c.stats) for c in cols}
+        first_cat = next(c for c in cols if c.type == "cat")
+        stats[first_cat.name]["categories"] = [f"lv{i}" for i in range(first_cat.n_classes)]
+        model._norm_stats_per_col = stats
+        model._feature_layout = {t: {} for t in orc.TYPE_ORDER}
+        for c in cols:
+            model._feature_layout[c.type][c.name] = 1 if c.type in ("real", "pos", "count") else int(c.n_classes)
+        pre = behaviour + "/"
+        for k_, v in ref_params(model, behaviour).items():
+            rec[pre + "param/" + k_] = v
+        rec[pre + "stats"] = json.dumps(stats)
+        logits = model._prior_component_logits_tensor().detach().numpy()
+        # ---- a18: prior latents
+        with NoiseTape() as tape, torch.no_grad():
+            tape.multi_mode, tape.prior_logits = "cdf", logits
+            z, assign = model._draw_latent_samples(n, conditional=False, targets=None, device=cpu)
+        rec[pre + "prior/u"] = tape.prior_u[0].numpy()
+        rec[pre + "prior/eps"] = tape.randn[0].numpy()
+        rec[pre + "prior/z"] = z.numpy()
+        rec[pre + "prior/component"] = assign.argmax(dim=1).numpy().astype(np.int64)
+        rec[pre + "prior/assignments"] = assign.numpy()
+        # ---- a23: SUAVE.sample(conditional=False), one chunk
+        with NoiseTape() as tape, torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tape.multi_mode, tape.prior_logits = "cdf", logits
+            frame = model.sample(n, conditional=False, batch_size=n)
+        rec[pre + "sample/u"] = tape.prior_u[0].numpy()
+        rec[pre + "sample/eps"] = tape.randn[0].numpy()
+        _head_noise(rec, pre + "sample/", cols, tape, 1, 0, 0)
+        _frame_to_rec(rec, pre + "sample/", cols, frame)
+        if behaviour != "supervised":
+            continue
+        # ---- a19: conditional latents from cached training posteriors
+        classes = np.asarray([10, 20, 30])
+        train_targets = rng.integers(0, 3, n_train)
+        model._classes = classes
+        model._class_to_index = {int(c): i for i, c in enumerate(classes)}
+        model._train_target_indices = train_targets.astype(np.int64)
+        model._train_component_probs = torch.from_numpy(rng.dirichlet(np.ones(K), n_train).astype(np.float32))
+        model._train_component_mu = torch.from_numpy(rng.standard_normal((n_train, K, D)).astype(np.float32))
+        model._train_component_logvar = torch.from_numpy((0.3 * rng.standard_normal((n_train, K, D))).astype(np.float32))
+        y = classes[rng.integers(0, 3, n)]
+        rec["cond/classes"] = classes
+        rec["cond/train_targets"] = train_targets.astype(np.int64)
+        rec["cond/train_probs"] = model._train_component_probs.numpy()
+        rec["cond/train_mu"] = model._train_component_mu.numpy()
+        rec["cond/train_logvar"] = model._train_component_logvar.numpy()
+        rec["cond/y"] = y
+        with NoiseTape() as tape, torch.no_grad():
+            z, assign = model._draw_conditional_latents(y, cpu)
+        rec["cond/u_row"] = torch.cat(tape.randint_u).numpy()
+        rec["cond/e_comp"] = torch.cat(tape.multinomial_exp).numpy()          # [n,K]
+        rec["cond/eps"] = torch.cat(tape.randn).numpy()                       # [n,D]
+        rec["cond/z"] = z.numpy()
+        rec["cond/component"] = assign.argmax(dim=1).numpy().astype(np.int64)
+        # the training row each draw used (candidate list of the label's class, model.py:3080-3091)
+        rows = []
+        for lab, u in zip(y, rec["cond/u_row"]):
+            cand = np.flatnonzero(train_targets == model._class_to_index[int(lab)])
+            rows.append(cand[min(int(np.float32(u) * np.float32(cand.size)), cand.size - 1)])
+        rec["cond/rows"] = np.asarray(rows, np.int64)
+        # ---- a23: SUAVE.sample(conditional=True, y), one chunk
+        with NoiseTape() as tape, torch.no_grad():
+            frame = model.sample(n, conditional=True, y=y, batch_size=n)
+        rec["cond_sample/u_row"] = torch.cat(tape.randint_u).numpy()
+        rec["cond_sample/e_comp"] = torch.cat(tape.multinomial_exp[:n]).numpy()
+        rec["cond_sample/eps"] = torch.cat(tape.randn[:n]).numpy()
+        _head_noise(rec, "cond_sample/", cols, tape, n, n, 0)
+        _frame_to_rec(rec, "cond_sample/", cols, frame)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print("wrote", name)
+
+
+
+def _tape_steps(tape, D):
+    """(exp, eps) of every _forward_elbo_batch call on the tape, in call order: the Gumbel Exp(1) draws and the
+    [B, D] reparameterisation draw (the heads' own discarded sample draws are [B, 1] and are skipped: quirk Q2)."""
+
+    eps = [t for t in tape.randn if t.dim() == 2 and t.shape[1] == D]
+    assert len(eps) == len(tape.exp)
+    return [(e.numpy(), z.numpy()) for e, z in zip(tape.exp, eps)]
+
+
+def gen_phases(name, kind, K, D, hidden, n_train, n_val, batch, seed, lr=1e-2, cls_weight=0.7, lam=0.5):
+    """The rest of the supervised schedule, each phase run UNTOUCHED under the noise tape (dropout 0):
+      * `_run_joint_finetune` (model.py:1866-2086): four learning-rate groups (:1894-1909), validation metrics,
+        best-state restore;
+      * `_refine_decoder_after_joint` (:2088-2445) in mode decoder_prior -- the L2 prior anchor (:2338-2346) --
+        and in mode decoder_only (prior frozen), encoder and classifier frozen (:2251-2281);
+      * `_collect_posterior_statistics` + `_closed_form_prior_update_from_stats` (:1669-1741, :2447-2495).
+    Recorded: permutations, the draws of every ELBO call (training and validation), every parameter before and
+    after each phase, the gradients of every optimisation step, the validation metrics."""
+
+    from suave.modules.heads import ClassificationHead
+    import torch.optim
+
+    assert D > 1
+    rng = np.random.default_rng(seed)
+    cols = make_columns(kind)
+    model, om = build_reference(cols, K, D, hidden, 0.0, "supervised", seed)
+    model.learning_rate = lr
+    model.decoder_refine_prior_lambda = lam
+    torch.manual_seed(seed + 3)
+    n_classes = 3
+    model._classes = np.arange(n_classes)
+    model._classifier = ClassificationHead(D, n_classes, class_weight=[1.0, 2.0, 0.5])
+    xnum, codes, mask = make_batch(cols, n_train, 0.3, rng)
+    vxnum, vcodes, vmask = make_batch(cols, n_val, 0.3, rng)
+    x, data_t, mask_t = to_torch_batches(om, xnum, codes, mask)
+    vx, vdata_t, vmask_t = to_torch_batches(om, vxnum, vcodes, vmask)
+    y = torch.from_numpy(rng.integers(0, n_classes, n_train).astype(np.int64))
+    vy = torch.from_numpy(rng.integers(0, n_classes, n_val).astype(np.int64))
+    rec = {"columns": cols_json(cols),
+           "meta": json.dumps(dict(kind=kind, K=K, D=D, hidden=list(hidden), n_train=n_train, n_val=n_val, batch=batch,
+                                   seed=seed, lr=lr, cls_weight=cls_weight, lam=lam, beta=float(model.beta),
+                                   n_classes=n_classes, behaviour="supervised", dropout=0.0)),
+           "xnum": xnum, "codes": codes, "mask": mask, "val/xnum": vxnum, "val/codes": vcodes, "val/mask": vmask,
+           "y": y.numpy(), "val/y": vy.numpy(), "clf/class_weight": model._classifier.class_weight.numpy()}
+
+    def snapshot(pre):
+        for k_, v in ref_params(model, "supervised").items():
+            rec[pre + "param/" + k_] = v
+        for k_, v in model._classifier.state_dict().items():
+            if k_ != "class_weight":
+                rec[pre + "clf/" + k_] = v.detach().numpy().copy()
+
+    named = ref_named_parameters(model, "supervised") + [("clf." + k_, p_) for k_, p_ in model._classifier.named_parameters()]
+    name_of = {id(p_): k_ for k_, p_ in named}
+    step_grads = []
+    orig_step = torch.optim.Adam.step
+
+    def recording_step(self, *a, **k):
+        g = {}
+        for group in self.param_groups:
+            for p_ in group["params"]:
+                if p_.grad is not None:
+                    g[name_of[id(p_)]] = p_.grad.detach().numpy().copy()
+        step_grads.append(g)
+        return orig_step(self, *a, **k)
+
+    # Quirk Q10: `_capture_model_state` snapshots through `tensor.detach().cpu()` (model.py:2680-2694, 4437-4454).  On a
+    # CUDA device that copies; on the CPU it returns the live tensor, so in a CPU run the "best state" aliases the
+    # parameters and `_restore_model_state` restores nothing.  The fixture records the behaviour of the device the
+    # reference is written for (and the build runs on): the snapshot is a copy.
+    from collections import OrderedDict
+
+    def state_dict_copy(module):
+        if module is None:
+            return None
+        return OrderedDict((k_, v.detach().clone()) for k_, v in module.state_dict().items())
+
+    SUAVE._state_dict_to_cpu = staticmethod(state_dict_copy)
+    SUAVE._tensor_to_cpu = staticmethod(lambda t: None if t is None else t.detach().clone())
+
+    def run_phase(pre, fn):
+        snapshot(pre + "before/")
+        step_grads.clear()
+        torch.optim.Adam.step = recording_step
+        try:
+            with NoiseTape() as tape:
+                out = fn()
+        finally:
+            torch.optim.Adam.step = orig_step
+        snapshot(pre + "after/")
+        rec[pre + "n_perms"] = np.asarray(len(tape.perms))
+        for i, p_ in enumerate(tape.perms):
+            rec[pre + f"perm/{i}"] = p_.numpy()
+        steps = _tape_steps(tape, D)
+        rec[pre + "n_steps"] = np.asarray(len(steps))
+        for i, (e, z) in enumerate(steps):
+            rec[pre + f"exp/{i}"] = e
+            rec[pre + f"eps/{i}"] = z
+        rec[pre + "n_opt_steps"] = np.asarray(len(step_grads))
+        for i, g in enumerate(step_grads):
+            for k_, v in g.items():
+                rec[pre + f"grad/{i}/{k_}"] = v
+        return out
+
+    # ---- joint fine-tuning: 2 epochs
+    done = run_phase("joint/", lambda: model._run_joint_finetune(
+        2, x, data_t, mask_t, vx, vdata_t, vmask_t, batch_size=batch, lr_scale=0.1, early_stop_patience=5,
+        y_train_tensor=y, y_val_tensor=vy, classification_loss_weight=cls_weight))
+    rec["joint/epochs_done"] = np.asarray(done)
+    rec["joint/val_metrics"] = json.dumps({k_: float(v) for k_, v in model._joint_val_metrics.items()})
+    model.classification_loss_weight = cls_weight
+    # ---- decoder refinement with the L2 prior anchor: 2 epochs
+    model.decoder_refine_mode = "decoder_prior"
+    done, _ = run_phase("refine_prior/", lambda: model._refine_decoder_after_joint(
+        2, x, data_t, mask_t, vx, vdata_t, vmask_t, batch_size=batch, patience=5))
+    rec["refine_prior/epochs_done"] = np.asarray(done)
+    # ---- decoder only: 1 epoch (prior tensors frozen)
+    model.decoder_refine_mode = "decoder_only"
+    done, _ = run_phase("refine_decoder/", lambda: model._refine_decoder_after_joint(
+        1, x, data_t, mask_t, vx, vdata_t, vmask_t, batch_size=batch, patience=5))
+    rec["refine_decoder/epochs_done"] = np.asarray(done)
+    # ---- closed-form EM refresh of the prior from posterior responsibilities
+    snapshot("em/before/")
+    stats = model._collect_posterior_statistics(x, batch_size=batch, temperature=None)
+    model._closed_form_prior_update_from_stats(stats, device=torch.device("cpu"))
+    snapshot("em/after/")
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print("wrote", name)
+
+
+
+_JSON_LEAVES = {"schema", "normalization", "feature_layout", "class_to_index", "joint_val_metrics", "auto_configured",
+                "heuristic_overrides", "auto_hyperparameters", "temperature_scaler", "temperature_scaler_state",
+                "warmup_val_history", "classes", "hidden_dims", "head_hidden_dims"}
+
+
+def _flatten_payload(obj, prefix, arrays, leaves):
+    """A torch archive as data: tensors / arrays -> npz entries, everything else -> one JSON map by path."""
+
+    last = prefix.split("/")[-1]
+    if isinstance(obj, dict) and last not in _JSON_LEAVES:
+        if not obj:
+            leaves[prefix] = {"kind": "dict", "value": {}}
+        for k, v in obj.items():
+            _flatten_payload(v, f"{prefix}/{k}", arrays, leaves)
+    elif isinstance(obj, torch.Tensor):
+        arrays[prefix] = obj.detach().numpy()
+        leaves[prefix] = {"kind": "tensor"}
+    elif isinstance(obj, np.ndarray):
+        arrays[prefix] = obj
+        leaves[prefix] = {"kind": "ndarray"}
+    elif last == "class_to_index" and isinstance(obj, dict):
+        leaves[prefix] = {"kind": "pairs", "value": [[k, v] for k, v in obj.items()]}
+    else:
+        leaves[prefix] = {"kind": type(obj).__name__, "value": obj}
+
+
+def gen_persistence(name, kind, K, D, hidden, seed, n_train=20):
+    """The archive `SUAVE.save` writes (model.py:4456-4579) for a supervised model (classifier, calibration state,
+    training posterior caches) and an unsupervised one, stored as data: every tensor + the JSON of every other leaf
+    (no pickle travels).  Also proves the other direction in this container: an archive assembled by the build's
+    `suave_amd.persist.build_payload` from the same tensors is read back by the reference's own `SUAVE.load`
+    (model.py:4581-4950) into identical modules."""
+
+    import tempfile
+    from suave.modules.heads import ClassificationHead
+    from suave_amd import persist
+    from suave_amd.types import Schema as OurSchema
+
+    rng = np.random.default_rng(seed)
+    cols = make_columns(kind)
+    rec = {"columns": cols_json(cols), "meta": json.dumps(dict(kind=kind, K=K, D=D, hidden=list(hidden), seed=seed))}
+    for behaviour in ("supervised", "unsupervised"):
+        model, om = build_reference(cols, K, D, hidden, 0.1, behaviour, seed)
+        stats = {c.name: dict(c.stats) for c in cols}
+        first_cat = next(c for c in cols if c.type == "cat")
+        stats[first_cat.name]["categories"] = [f"lv{i}" for i in range(first_cat.n_classes)]
+        model._norm_stats_per_col = stats
+        model._feature_layout = {t: {} for t in orc.TYPE_ORDER}
+        for c in cols:
+            model._feature_layout[c.type][c.name] = 1 if c.type in ("real", "pos", "count") else int(c.n_classes)
+        model._is_fitted = True
+        model._inference_tau = 0.85
+        model._warmup_val_history = [{"nll": 12.5, "reconstruction": -11.0, "categorical_kl": 0.1, "gaussian_kl": 0.9}]
+        t32 = lambda *shape: torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+        model._train_latent_mu, model._train_latent_logvar = t32(n_train, D), t32(n_train, D)
+        model._train_component_logits = t32(n_train, K)
+        model._train_component_mu, model._train_component_logvar = t32(n_train, K, D), t32(n_train, K, D)
+        model._train_component_probs = torch.softmax(model._train_component_logits, dim=-1)
+        if behaviour == "supervised":
+            classes = np.asarray([10, 20, 30])
+            model._classes = classes
+            model.classes_ = classes
+            model._class_to_index = {int(c): i for i, c in enumerate(classes)}
+            model._train_target_indices = rng.integers(0, 3, n_train).astype(np.int64)
+            torch.manual_seed(seed + 5)
+            model._classifier = ClassificationHead(D, 3, class_weight=[1.0, 2.0, 0.5], dropout=0.1)
+            model._temperature_scaler.temperature, model._temperature_scaler.fitted = 1.7, True
+            model._is_calibrated = True
+            model.classification_loss_weight = 0.6
+            model._joint_val_metrics = {"nll": 12.0, "classification_loss": 0.9, "joint_objective": 12.54}
+        pre = behaviour + "/"
+        P = ref_params(model, behaviour)
+        for k_, v in P.items():
+            rec[pre + "param/" + k_] = v
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "ref.pt")
+            model.save(path)
+            payload = torch.load(path, map_location="cpu", weights_only=False)  # written by this script one line above
+            arrays, leaves = {}, {}
+            _flatten_payload(payload, pre + "payload", arrays, leaves)
+            rec.update(arrays)
+            rec[pre + "leaves"] = json.dumps(leaves)
+            rec[pre + "tree"] = json.dumps(persist.tree(payload))
+            # ---- the other direction: the build's payload through the reference's loader
+            cache = {"mean": model._train_latent_mu, "post_logvar": model._train_latent_logvar,
+                     "logits": model._train_component_logits, "mu": model._train_component_mu,
+                     "logvar": model._train_component_logvar, "probs": model._train_component_probs}
+            clf = model._classifier
+            ours = persist.build_payload(
+                metadata=dict(payload["metadata"]), state=P, schema=OurSchema(payload["metadata"]["schema"]),
+                classifier_state=None if clf is None else {k_: v for k_, v in clf.state_dict().items()},
+                class_weight=None if clf is None else clf.class_weight, use_weight=clf is not None,
+                temperature_scaler=model._temperature_scaler.state_dict(), norm_stats=stats,
+                classes=model._classes, class_to_index=model._class_to_index, is_calibrated=model._is_calibrated,
+                train_cache=cache, train_target_indices=model._train_target_indices,
+                warmup_val_history=model._warmup_val_history, joint_val_metrics=model._joint_val_metrics)
+            path2 = os.path.join(tmp, "ours.pt")
+            torch.save(ours, path2)
+            torch.load(path2, map_location="cpu", weights_only=True)  # nothing but tensors and plain containers
+            back = SUAVE.load(path2)
+        for k_, v in ref_params(back, behaviour).items():
+            assert np.array_equal(v, P[k_]), k_
+        assert back._norm_stats_per_col == stats and back._feature_layout == model._feature_layout
+        assert back._inference_tau == 0.85 and back.hidden_dims == tuple(hidden) and back.behaviour == behaviour
+        assert torch.equal(back._train_component_mu, model._train_component_mu)
+        if behaviour == "supervised":
+            assert list(back._classes) == [10, 20, 30] and back._class_to_index == model._class_to_index
+            assert np.array_equal(back._train_target_indices, model._train_target_indices)
+            for k_, v in model._classifier.state_dict().items():
+                assert torch.equal(back._classifier.state_dict()[k_], v), k_
+            assert back._is_calibrated and abs(back._temperature_scaler.temperature - 1.7) < 1e-12
+        ours_tree, ref_tree = persist.tree(ours), persist.tree(payload)
+        assert set(ours_tree) == set(ref_tree), set(ours_tree) ^ set(ref_tree)
+        rec[pre + "ours_loaded_by_reference"] = np.asarray(True)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print("wrote", name)
+
+
 def main():
     only = set(sys.argv[1:])  # optional fixture names: regenerate just those
 
@@ -668,6 +1074,9 @@ def main():
         (gen_joint, ("joint_sup_mixed7", "mixed7", 3, 6, (16, 8), 48, 0.3, 71), {}),
         (gen_predictive, ("predictive_mixed7", "mixed7", 3, 6, (16, 8), 24, 81), {}),
         (gen_impute, ("impute_mixed8", 91), {}),
+        (gen_persistence, ("persistence_mixed7", "mixed7", 3, 6, (16, 8), 121), {}),
+        (gen_phases, ("phases_mixed7", "mixed7", 3, 6, (16, 8), 40, 16, 24, 111), {}),
+        (gen_generation, ("generation_mixed7", "mixed7", 4, 6, (16, 8), 96, 101), {}),
     ]
     for fn, args, kw in jobs:
         if want(args[0]):

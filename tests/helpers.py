@@ -161,3 +161,70 @@ def torch_noise(noise, device):
     if noise.get("dec_drop") is not None:
         out["dec_keep"] = [torch.from_numpy(np.ascontiguousarray(m, np.uint8)).to(device) for m in noise["dec_drop"]]
     return out
+
+
+# ---------------------------------------------------------------------------
+# schedule-phase fixtures (tests/golden/phases_*.npz)
+# ---------------------------------------------------------------------------
+def phase_record(fx, pre):
+    """Draws, snapshots and per-step gradients of one recorded phase ("joint/", "refine_prior/", ...)."""
+
+    out = {"perms": [fx[pre + f"perm/{i}"] for i in range(int(fx[pre + "n_perms"]))],
+           "steps": [{"exp": fx[pre + f"exp/{i}"], "eps": fx[pre + f"eps/{i}"]} for i in range(int(fx[pre + "n_steps"]))],
+           "grads": []}
+    for i in range(int(fx[pre + "n_opt_steps"])):
+        key = pre + f"grad/{i}/"
+        out["grads"].append({k[len(key):]: v for k, v in fx.items() if k.startswith(key)})
+    for when in ("before", "after"):
+        key = pre + when + "/param/"
+        out[when] = {k[len(key):]: v for k, v in fx.items() if k.startswith(key)}
+        key = pre + when + "/clf/"
+        out[when + "_clf"] = {k[len(key):]: v for k, v in fx.items() if k.startswith(key)}
+    return out
+
+
+def update_close(new, old, ref_new, ref_old, lr, n_steps, what=""):
+    """Parameters after a few Adam steps against the reference's.  Adam normalises the gradient, so an entry whose
+    gradient is within the 1e-4 gradient tolerance of zero may move by up to lr per step in either direction; all
+    others must agree closely: at most 2 % of the entries may differ by more than 2 % of the largest update, and
+    none by more than the trust region 2 * lr * n_steps."""
+
+    d = np.asarray(new, np.float64) - np.asarray(old, np.float64)
+    dr = np.asarray(ref_new, np.float64) - np.asarray(ref_old, np.float64)
+    err = np.abs(d - dr)
+    scale = max(float(np.abs(dr).max()), 1e-12)
+    assert float(err.max()) <= 2.0 * lr * n_steps + 1e-7, (what, float(err.max()))
+    assert float((err > 0.02 * scale).mean()) <= 0.02, (what, float((err > 0.02 * scale).mean()))
+
+
+# ---------------------------------------------------------------------------
+# persistence fixture (tests/golden/persistence_*.npz): the reference's archive stored as data
+# ---------------------------------------------------------------------------
+def payload_from_fixture(fx, behaviour):
+    """Rebuild the nested payload `SUAVE.save` of the reference wrote (model.py:4573-4578) from the fixture's
+    arrays and JSON leaves: torch tensors where it held tensors, numpy arrays where it held arrays."""
+
+    import torch
+    from collections import OrderedDict
+
+    root = behaviour + "/payload"
+    leaves = json.loads(str(fx[behaviour + "/leaves"]))
+    payload: dict = {}
+    for path, leaf in leaves.items():
+        keys = path[len(root) + 1:].split("/")
+        node = payload
+        for k in keys[:-1]:
+            node = node.setdefault(k, OrderedDict() if k in ("encoder", "decoder", "state_dict", "mean_state_dict") else {})
+        kind = leaf["kind"]
+        if kind == "tensor":
+            value = torch.from_numpy(np.array(fx[path]))
+        elif kind == "ndarray":
+            value = np.array(fx[path])
+        elif kind == "pairs":
+            value = {k: v for k, v in leaf["value"]}
+        elif kind == "dict" and "value" in leaf and not leaf["value"]:
+            value = {}
+        else:
+            value = leaf.get("value")
+        node[keys[-1]] = value
+    return payload

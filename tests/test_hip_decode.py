@@ -340,3 +340,106 @@ def test_encode_with_embedded_wide_columns_matches_oracle():
     assert rel_err(enc[:, :K], lg) < TOL
     assert rel_err(enc[:, K:K + K * D], mu.reshape(len(idx), -1)) < TOL
     assert rel_err(enc[:, K + K * D:], lv.reshape(len(idx), -1)) < TOL
+
+
+def _generation_model(behaviour):
+    """A fitted-by-hand suave_amd.SUAVE on the generation fixture's parameters."""
+
+    import json
+
+    from suave_amd.engine import Engine
+    from suave_amd.model import SUAVE
+    from suave_amd.plan import ModelLayout
+    from suave_amd.types import Schema
+    from tests.helpers import columns_from_json
+
+    fx = load_golden("generation_mixed7")
+    meta = json.loads(str(fx["meta"]))
+    stats = json.loads(str(fx[behaviour + "/stats"]))
+    cols = columns_from_json(fx["columns"])
+    schema = Schema({c.name: {"type": c.type, **({"n_classes": c.n_classes} if c.n_classes else {})} for c in cols})
+    K, D, hidden = meta["K"], meta["D"], tuple(meta["hidden"])
+    P = {k[len(behaviour) + 7:]: v for k, v in fx.items() if k.startswith(behaviour + "/param/")}
+    m = SUAVE(schema, behaviour=behaviour, latent_dim=D, n_components=K, hidden_dims=hidden, dropout=0.0)
+    m._norm_stats_per_col = stats
+    m._layout = ModelLayout(schema, K, D, hidden, 0.0, behaviour, stats)
+    m._engine = Engine(m._layout, "cuda:0")
+    m._engine.load_state(P)
+    m._is_fitted = True
+    om = orc.OracleModel(cols, n_components=K, latent_dim=D, hidden=hidden, behaviour=behaviour)
+    return fx, meta, cols, om, m
+
+
+def _check_sample_frame(frame, cols, fx, pre):
+    for c in cols:
+        ref = fx[pre + f"frame/{c.name}"]
+        v = frame[c.name]
+        assert str(v.dtype) == str(fx[pre + f"dtype/{c.name}"]), c.name  # float32 / int64 / category
+        if c.type in ("real", "pos"):
+            assert rel_err(v.to_numpy(), ref) < TOL, c.name
+        elif c.type == "count":
+            assert np.array_equal(v.to_numpy(), ref), c.name
+        else:
+            assert np.array_equal(np.asarray(v.cat.codes, np.int64), ref), c.name
+            assert [str(x) for x in v.cat.categories] == list(fx[pre + f"categories/{c.name}"]), c.name
+            assert bool(v.cat.ordered) == bool(fx[pre + f"ordered/{c.name}"]), c.name
+
+
+@pytest.mark.parametrize("behaviour", ["supervised", "unsupervised"])
+def test_golden_prior_latents_and_sample(behaviour):
+    """suave_prior_latents and SUAVE.sample(conditional=False) against the reference's
+    sampling.sample_prepared_mixture_latents (sampling.py:38-56) and SUAVE.sample (model.py:4284-4431) on the
+    recorded draws: components bit-exact, z to 1e-4, the frame's discrete values / dtypes / categories identical."""
+
+    import torch
+
+    fx, meta, cols, om, m = _generation_model(behaviour)
+    eng, n = m._engine, meta["n"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    pre = behaviour + "/prior/"
+    z, comp = eng.prior_latents(n, m._prior_cdf(), u=t(fx[pre + "u"]), eps=t(fx[pre + "eps"]))
+    assert np.array_equal(comp.cpu().numpy().astype(np.int64), fx[pre + "component"])
+    assert rel_err(z.cpu().numpy(), fx[pre + "z"]) < TOL
+    pre = behaviour + "/sample/"
+    per_col = {c.name: {k.split("/")[-1]: v for k, v in fx.items() if k.startswith(pre + f"noise/{c.name}/")} for c in cols}
+    nn, nu, ne = _pack_noise(om, m._layout, per_col, n)
+    noise = {"u": t(fx[pre + "u"]), "eps": t(fx[pre + "eps"]), "normal": t(nn), "uniform": t(nu), "exp": t(ne)}
+    _check_sample_frame(m.sample(n, _noise=noise), cols, fx, pre)
+    _check_sample_frame(m.sample(n, batch_size=17, _noise=noise), cols, fx, pre)  # chunking does not change rows
+
+
+def test_golden_conditional_latents_and_sample():
+    """suave_conditional_latents and SUAVE.sample(conditional=True, y) against SUAVE._draw_conditional_latents
+    (model.py:3042-3114): chosen component bit-exact (it is drawn from the chosen training row's cached
+    probabilities, so a wrong row shows), z to 1e-4, frame identical for discrete columns."""
+
+    import torch
+
+    fx, meta, cols, om, m = _generation_model("supervised")
+    eng, n = m._engine, meta["n"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    classes = fx["cond/classes"]
+    m._classes = classes
+    m._class_to_index = {int(c): i for i, c in enumerate(classes)}
+    m._train_target_indices = fx["cond/train_targets"]
+    m._train_cache = {"probs": t(fx["cond/train_probs"]), "mu": t(fx["cond/train_mu"]), "logvar": t(fx["cond/train_logvar"])}
+    tt = fx["cond/train_targets"]
+    class_rows = np.concatenate([np.flatnonzero(tt == c) for c in range(len(classes))]).astype(np.int64)
+    class_off = np.concatenate([[0], np.cumsum([(tt == c).sum() for c in range(len(classes))])]).astype(np.int64)
+    labels = np.searchsorted(classes, fx["cond/y"]).astype(np.int32)
+    z, comp = eng.conditional_latents(t(labels), t(class_off), t(class_rows), m._train_cache["probs"], m._train_cache["mu"],
+                                      m._train_cache["logvar"], u_row=t(fx["cond/u_row"]), e_comp=t(fx["cond/e_comp"]),
+                                      eps=t(fx["cond/eps"]))
+    assert np.array_equal(comp.cpu().numpy().astype(np.int64), fx["cond/component"])
+    assert rel_err(z.cpu().numpy(), fx["cond/z"]) < TOL
+    # z = mu[row, k] + eps * exp(0.5 logvar[row, k]) with the reference's rows: pins the chosen training rows too
+    rows, k = fx["cond/rows"], fx["cond/component"]
+    z_rows = fx["cond/train_mu"][rows, k] + fx["cond/eps"] * np.exp(0.5 * fx["cond/train_logvar"][rows, k])
+    assert rel_err(z.cpu().numpy(), z_rows) < 1e-5
+    pre = "cond_sample/"
+    per_col = {c.name: {kk.split("/")[-1]: v for kk, v in fx.items() if kk.startswith(pre + f"noise/{c.name}/")} for c in cols}
+    nn, nu, ne = _pack_noise(om, m._layout, per_col, n)
+    noise = {"u_row": t(fx[pre + "u_row"]), "e_comp": t(fx[pre + "e_comp"]), "eps": t(fx[pre + "eps"]),
+             "normal": t(nn), "uniform": t(nu), "exp": t(ne)}
+    _check_sample_frame(m.sample(n, conditional=True, y=fx["cond/y"], _noise=noise), cols, fx, pre)
+    _check_sample_frame(m.sample(n, conditional=True, y=fx["cond/y"], batch_size=40, _noise=noise), cols, fx, pre)

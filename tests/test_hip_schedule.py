@@ -1,0 +1,128 @@
+"""GPU parity of the rest of the supervised schedule against phases the
+reference ran itself (tests/golden/phases_mixed7.npz, written by tests/golden/make_golden.py::gen_phases):
+
+* `_run_joint_finetune` (model.py:1866-2086): four learning-rate groups, classifier CE through `latent`;
+* `_refine_decoder_after_joint` (:2088-2445): mode decoder_prior with the L2 prior anchor (:2338-2346) and mode
+  decoder_only; encoder and classifier frozen; best-state restore on the validation ELBO;
+* `_closed_form_prior_update_from_stats` (:2447-2495).
+
+`suave_amd.SUAVE`'s own phase methods run on the HIP step with the recorded permutations and draws
+(`DrawReplay`); the gradient of EVERY optimisation step is compared with the reference's (1e-4 at the first step,
+1e-3 once the parameters have drifted by rounding), then the parameters after the phase.
+"""
+
+import json
+
+import numpy as np
+import pytest
+
+from tests.helpers import columns_from_json, load_golden, phase_record, rel_err, update_close
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _model(fx, meta, rec):
+    import torch
+    from suave_amd import supervised as sup
+    from suave_amd.engine import Engine, PackedTable
+    from suave_amd.model import SUAVE, DrawReplay
+    from suave_amd.plan import ModelLayout
+    from suave_amd.types import Schema
+
+    cols = columns_from_json(fx["columns"])
+    schema = Schema({c.name: {"type": c.type, **({"n_classes": c.n_classes} if c.n_classes else {})} for c in cols})
+    stats = {c.name: dict(c.stats or {}) for c in cols}
+    K, D, hidden = meta["K"], meta["D"], tuple(meta["hidden"])
+    m = SUAVE(schema, behaviour="supervised", latent_dim=D, n_components=K, hidden_dims=hidden, dropout=0.0,
+              learning_rate=meta["lr"], beta=meta["beta"], decoder_refine_prior_lambda=meta["lam"])
+    m._norm_stats_per_col = stats
+    m._layout = ModelLayout(schema, K, D, hidden, 0.0, "supervised", stats)
+    m._engine = eng = Engine(m._layout, "cuda:0")
+    eng.load_state(rec["before"])
+    m._classifier = sup.ClassificationHead(D, meta["n_classes"], class_weight=fx["clf/class_weight"]).to(eng.device)
+    m._classifier.load_state_dict({**{k: torch.from_numpy(v) for k, v in rec["before_clf"].items()},
+                                   "class_weight": torch.from_numpy(fx["clf/class_weight"])})
+    m._classes = np.arange(meta["n_classes"])
+    m._replay = DrawReplay(rec["perms"], rec["steps"])
+    train = PackedTable(fx["xnum"], fx["codes"], fx["mask"], eng.device)
+    val = PackedTable(fx["val/xnum"], fx["val/codes"], fx["val/mask"], eng.device)
+    y = torch.from_numpy(fx["y"]).to(eng.device)
+    vy = torch.from_numpy(fx["val/y"]).to(eng.device)
+    return m, train, val, y, vy
+
+
+def _check_phase(m, rec, lr_of, n_opt, frozen):
+    lay = m._layout
+    assert len(m._replay.grads) == n_opt == len(rec["grads"])
+    assert not m._replay.steps and not m._replay.perms  # every recorded draw was consumed, in order
+    for t, (flat, ref_g) in enumerate(zip(m._replay.grads, rec["grads"])):
+        got = lay.unpack(flat.cpu().numpy())
+        ref_g = {k: v for k, v in ref_g.items() if not k.startswith("clf.")}
+        gmax = max(float(np.abs(v).max()) for v in ref_g.values())
+        tol = TOL if t == 0 else 10 * TOL
+        for k, v in ref_g.items():
+            err = float(np.abs(got[k].reshape(v.shape) - v).max())
+            assert err <= tol * max(float(np.abs(v).max()), 1e-3 * gmax) + 1e-7, (t, k, err)
+    new = m._engine.state()
+    for k, before in rec["before"].items():
+        if frozen(k):
+            assert np.array_equal(rec["after"][k], before), k           # the reference left it untouched
+            assert np.array_equal(new[k].reshape(before.shape), before), k  # and so did the HIP phase, bit for bit
+        else:
+            update_close(new[k].reshape(before.shape), before, rec["after"][k], before, lr_of(k), n_opt, k)
+
+
+def test_joint_finetune_phase_matches_reference():
+    fx = load_golden("phases_mixed7")
+    meta = json.loads(str(fx["meta"]))
+    rec = phase_record(fx, "joint/")
+    m, train, val, y, vy = _model(fx, meta, rec)
+    done = m._joint_finetune(train, val, y, vy, 2, meta["batch"], 0.1, 5, meta["cls_weight"])
+    assert done == int(fx["joint/epochs_done"])
+    lr = meta["lr"]
+    _check_phase(m, rec, lambda k: lr * (0.1 if k.startswith(("decoder.", "prior.")) else 1.0), len(rec["grads"]),
+                 lambda k: False)
+    clf = {k: v.detach().cpu().numpy() for k, v in m._classifier.state_dict().items()}
+    for k, before in rec["before_clf"].items():
+        update_close(clf[k], before, rec["after_clf"][k], before, lr, len(rec["grads"]), "clf." + k)
+    ref_m = json.loads(str(fx["joint/val_metrics"]))
+    for key in ("nll", "reconstruction", "categorical_kl", "gaussian_kl", "classification_loss", "joint_objective"):
+        assert abs(m._joint_val_metrics[key] - ref_m[key]) <= 2e-3 * abs(ref_m[key]) + 1e-5, key
+
+
+@pytest.mark.parametrize("phase,mode,epochs", [("refine_prior", "decoder_prior", 2), ("refine_decoder", "decoder_only", 1)])
+def test_decoder_refine_phase_matches_reference(phase, mode, epochs):
+    fx = load_golden("phases_mixed7")
+    meta = json.loads(str(fx["meta"]))
+    rec = phase_record(fx, phase + "/")
+    m, train, val, y, vy = _model(fx, meta, rec)
+    m.decoder_refine_mode = mode
+    m.classification_loss_weight = meta["cls_weight"]
+    m._joint_val_metrics = json.loads(str(fx["joint/val_metrics"]))
+    clf_before = {k: v.detach().clone() for k, v in m._classifier.state_dict().items()}
+    done = m._refine_decoder(train, val, epochs, meta["batch"], 5)
+    assert done == int(fx[phase + "/epochs_done"])
+    train_prior = mode == "decoder_prior"
+    _check_phase(m, rec, lambda k: meta["lr"], len(rec["grads"]),
+                 lambda k: k.startswith("encoder.") or (k.startswith("prior.") and not train_prior))
+    import torch
+
+    for k, v in m._classifier.state_dict().items():
+        assert torch.equal(v, clf_before[k]), k
+
+
+def test_closed_form_prior_update_matches_reference():
+    fx = load_golden("phases_mixed7")
+    meta = json.loads(str(fx["meta"]))
+    before = {k[len("em/before/param/"):]: v for k, v in fx.items() if k.startswith("em/before/param/")}
+    rec = {"before": before, "before_clf": {k[len("joint/before/clf/"):]: v for k, v in fx.items()
+                                            if k.startswith("joint/before/clf/")}, "perms": [], "steps": []}
+    m, train, val, y, vy = _model(fx, meta, rec)
+    m._closed_form_prior_update(train)
+    new = m._engine.state()
+    for k in ("prior.logits", "prior.mu", "prior.logvar"):
+        assert rel_err(new[k], fx["em/after/param/" + k]) < TOL, k
+    for k, v in before.items():
+        if not k.startswith("prior."):
+            assert np.array_equal(new[k].reshape(v.shape), v), k

@@ -209,3 +209,195 @@ def test_impute_routing_matches_reference(behaviour):
     w = orc.softmax((lg - np.log(e)) / np.float32(tau))
     assert rel_err(w, fx[f"{behaviour}/sample/assignments"]) < TOL
     assert rel_err((w[:, :, None] * mu).sum(1), fx[f"{behaviour}/sample/latent"]) < TOL
+
+
+def _generation_fixture(behaviour):
+    import json
+
+    from tests.helpers import columns_from_json
+
+    fx = load_golden("generation_mixed7")
+    meta = json.loads(str(fx["meta"]))
+    stats = json.loads(str(fx[behaviour + "/stats"]))
+    cols = columns_from_json(fx["columns"])
+    om = orc.OracleModel(cols, n_components=meta["K"], latent_dim=meta["D"], hidden=tuple(meta["hidden"]), behaviour=behaviour)
+    P = {k[len(behaviour) + 7:]: v for k, v in fx.items() if k.startswith(behaviour + "/param/")}
+    return fx, meta, stats, cols, om, P
+
+
+def _prior_tensors(om, P):
+    """model.py:595-618: supervised prior tensors; unsupervised logits / logvar are zeros and the means are
+    PriorMean.component_means() = W^T + b (prior.py:31-39)."""
+
+    if om.behaviour == "supervised":
+        return P["prior.logits"], P["prior.mu"], P["prior.logvar"]
+    mu = P["prior_mean.linear.weight"].T + P["prior_mean.linear.bias"][None, :]
+    return np.zeros(om.K, np.float32), mu.astype(np.float32), np.zeros((om.K, om.D), np.float32)
+
+
+def _check_frame(om, cols, P, z, k, fx, pre):
+    y, _ = orc.decoder_trunk_forward(om, P, z)
+    s = np.eye(om.K, dtype=np.float32)[k]
+    nz = {c.name: {kk.split("/")[-1]: v for kk, v in fx.items() if kk.startswith(pre + f"noise/{c.name}/")} for c in cols}
+    out = sorc.sample_heads(om, P, y, s, nz)
+    for c in cols:
+        ref = fx[pre + f"frame/{c.name}"]
+        if c.type in ("real", "pos"):
+            assert rel_err(out[c.name], ref) < TOL, c.name
+        else:
+            assert np.array_equal(out[c.name].astype(np.int64), ref.astype(np.int64)), c.name
+
+
+@pytest.mark.parametrize("behaviour", ["supervised", "unsupervised"])
+def test_prior_latents_and_sample_match_reference(behaviour):
+    """sampling.sample_prepared_mixture_latents (sampling.py:38-56) and SUAVE.sample(conditional=False)
+    (model.py:4284-4431) run untouched under the noise tape: components bit-exact, z to 1e-5, frame values
+    bit-exact for discrete columns."""
+
+    fx, meta, stats, cols, om, P = _generation_fixture(behaviour)
+    lg, mu, lv = _prior_tensors(om, P)
+    pre = behaviour + "/prior/"
+    z, k = sorc.prior_latents(lg, mu, lv, fx[pre + "u"], fx[pre + "eps"])
+    assert np.array_equal(k, fx[pre + "component"])
+    assert np.array_equal(np.eye(om.K, dtype=np.float32)[k], fx[pre + "assignments"])
+    assert rel_err(z, fx[pre + "z"]) < 1e-5
+    pre = behaviour + "/sample/"
+    z, k = sorc.prior_latents(lg, mu, lv, fx[pre + "u"], fx[pre + "eps"])
+    _check_frame(om, cols, P, z, k, fx, pre)
+
+
+def test_conditional_latents_and_sample_match_reference():
+    """SUAVE._draw_conditional_latents (model.py:3042-3114) and SUAVE.sample(conditional=True): chosen training
+    rows and components bit-exact, z to 1e-5, frame values bit-exact for discrete columns."""
+
+    fx, meta, stats, cols, om, P = _generation_fixture("supervised")
+    classes, tt = fx["cond/classes"], fx["cond/train_targets"]
+    class_rows = np.concatenate([np.flatnonzero(tt == c) for c in range(len(classes))]).astype(np.int64)
+    class_off = np.concatenate([[0], np.cumsum([(tt == c).sum() for c in range(len(classes))])]).astype(np.int64)
+    labels = np.searchsorted(classes, fx["cond/y"]).astype(np.int32)
+    args = (class_off, class_rows, labels, fx["cond/train_probs"], fx["cond/train_mu"], fx["cond/train_logvar"])
+    z, k, rows = sorc.conditional_latents(*args, fx["cond/u_row"], fx["cond/e_comp"], fx["cond/eps"])
+    assert np.array_equal(rows, fx["cond/rows"])
+    assert np.array_equal(k, fx["cond/component"])
+    assert rel_err(z, fx["cond/z"]) < 1e-5
+    z, k, _ = sorc.conditional_latents(*args, fx["cond_sample/u_row"], fx["cond_sample/e_comp"], fx["cond_sample/eps"])
+    _check_frame(om, cols, P, z, k, fx, "cond_sample/")
+
+
+def _oracle_val_nll(om, P, vx, vdata, vmasks, beta, noise):
+    out = orc.elbo_supervised(om, P, vx, vdata, vmasks, noise, beta_scale=beta, tau=1.0, training=False, want_grad=False)
+    n = vx.shape[0]
+    return float(((out["categorical_kl"].sum() + out["gaussian_kl"].sum()) * beta - out["reconstruction"].sum()) / n)
+
+
+@pytest.mark.parametrize("phase", ["joint", "refine_prior", "refine_decoder"])
+def test_schedule_phase_replay_matches_reference(phase):
+    """_run_joint_finetune (model.py:1866-2086) and _refine_decoder_after_joint (:2088-2445, modes decoder_prior
+    with the L2 anchor :2338-2346 and decoder_only) replayed with the oracle on the recorded permutations and draws:
+    the gradient of every optimisation step, which tensors each phase updates (:1894-1909, :2251-2281), the
+    learning-rate groups and the parameters after the best-state restore."""
+
+    from tests.helpers import phase_record, update_close
+
+    fx = load_golden("phases_mixed7")
+    om, _, meta = fixture_model(fx)
+    rec = phase_record(fx, phase + "/")
+    lr, beta, w_cls, lam, bs = meta["lr"], meta["beta"], meta["cls_weight"], meta["lam"], meta["batch"]
+    x, data, masks = orc.dense_from_packed(om, fx["xnum"], fx["codes"], fx["mask"])
+    vx, vdata, vmasks = orc.dense_from_packed(om, fx["val/xnum"], fx["val/codes"], fx["val/mask"])
+    y, vy = fx["y"], fx["val/y"]
+    cw = fx["clf/class_weight"]
+    P = {k: v.copy() for k, v in rec["before"].items()}
+    clf = {k: v.copy() for k, v in rec["before_clf"].items()}
+    steps = list(rec["steps"])
+    perms = list(rec["perms"])
+    joint = phase == "joint"
+    train_prior = phase == "refine_prior"
+    dec_keys = [k for k in P if k.startswith("decoder.")]
+    enc_keys = [k for k in P if k.startswith("encoder.")]
+    prior_keys = [k for k in P if k.startswith("prior.")]
+    anchors = {k: P[k].copy() for k in prior_keys}
+    state, clf_state = {}, {}
+
+    def val_metrics():
+        nll = _oracle_val_nll(om, P, vx, vdata, vmasks, beta, steps.pop(0))
+        if not joint:
+            return (nll,)
+        lg, mu, lv, _ = orc.encoder_forward(om, P, vx)
+        pm, _, _ = orc.mixture_posterior_statistics(lg, mu, lv)
+        ce = float(orc.classifier_loss(pm, clf["linear.weight"], clf["linear.bias"], cw, vy)[0])
+        return (nll + w_cls * ce, nll)
+
+    best = val_metrics()
+    best_state = ({k: v.copy() for k, v in P.items()}, {k: v.copy() for k, v in clf.items()})
+    n = x.shape[0]
+    t = 0
+    for epoch in range(len(perms)):
+        perm = perms[epoch]
+        for s0 in range(0, n, bs):
+            idx = perm[s0:s0 + bs]
+            nz = steps.pop(0)
+            bd = {k: v[idx] for k, v in data.items()}
+            bm = {k: v[idx] for k, v in masks.items()}
+            dlat = None
+            if joint:
+                fwd = orc.elbo_supervised(om, P, x[idx], bd, bm, nz, beta_scale=beta, tau=1.0, want_grad=False)
+                _, _, dlat, gW, gb = orc.classifier_loss(fwd["latent"], clf["linear.weight"], clf["linear.bias"], cw, y[idx])
+                dlat, gW, gb = w_cls * dlat, w_cls * gW, w_cls * gb
+            out = orc.elbo_supervised(om, P, x[idx], bd, bm, nz, beta_scale=beta, tau=1.0, dlatent=dlat)
+            g = out["grads"]
+            if train_prior:
+                for k, v in orc.prior_anchor_gradient(P, anchors, lam).items():
+                    g[k] = g[k] + v
+            ref_g = rec["grads"][t]
+            t += 1
+            # which tensors the phase hands to Adam (model.py:1894-1909, 2262-2266)
+            want = set(dec_keys) | (set(enc_keys) | set(prior_keys) | {"clf.linear.weight", "clf.linear.bias"} if joint
+                                    else (set(prior_keys) if train_prior else set()))
+            assert set(ref_g) == want
+            gmax = max(float(np.abs(v).max()) for k, v in ref_g.items() if not k.startswith("clf."))
+            tol = TOL if t == 1 else 10 * TOL  # later steps: the parameters have already drifted by ~1e-6
+            for k, v in ref_g.items():
+                mine = {"clf.linear.weight": gW, "clf.linear.bias": gb}[k] if k.startswith("clf.") else g[k]
+                assert np.abs(mine.reshape(v.shape) - v).max() <= tol * max(float(np.abs(v).max()), 1e-3 * gmax) + 1e-7, (t, k)
+            upd = {k: g[k] for k in want if not k.startswith("clf.")}
+            scale = {k: (0.1 if joint and (k.startswith("decoder.") or k.startswith("prior.")) else 1.0) for k in upd}
+            orc.adam_step(P, upd, state, lr=lr, step=t, lr_scale=scale)
+            if joint:
+                orc.adam_step(clf, {"linear.weight": gW, "linear.bias": gb}, clf_state, lr=lr, step=t)
+        m = val_metrics()
+        if m < best and any(a < b - 1e-8 for a, b in zip(m, best)):
+            best, best_state = m, ({k: v.copy() for k, v in P.items()}, {k: v.copy() for k, v in clf.items()})
+    assert not steps and t == len(rec["grads"])
+    P, clf = best_state
+    for k in P:
+        frozen = (not joint) and (k in enc_keys or (k in prior_keys and not train_prior))
+        if frozen:
+            assert np.array_equal(rec["after"][k], rec["before"][k]), k  # the reference left it untouched
+            assert np.array_equal(P[k], rec["before"][k]), k
+        else:  # (an unchanged tensor here means the phase restored its starting state: validation never improved)
+            group_lr = lr * (0.1 if joint and (k.startswith("decoder.") or k.startswith("prior.")) else 1.0)
+            update_close(P[k], rec["before"][k], rec["after"][k], rec["before"][k], group_lr, t, k)
+    for k in clf:
+        if joint:
+            update_close(clf[k], rec["before_clf"][k], rec["after_clf"][k], rec["before_clf"][k], lr, t, k)
+        else:
+            assert np.array_equal(rec["after_clf"][k], rec["before_clf"][k]), k
+
+
+def test_closed_form_prior_update_matches_reference():
+    """_collect_posterior_statistics + _closed_form_prior_update_from_stats (model.py:1669-1741, 2447-2495)."""
+
+    fx = load_golden("phases_mixed7")
+    om, _, meta = fixture_model(fx)
+    P = {k[len("em/before/param/"):]: v for k, v in fx.items() if k.startswith("em/before/param/")}
+    x, _, _ = orc.dense_from_packed(om, fx["xnum"], fx["codes"], fx["mask"])
+    lg, mu, lv, _ = orc.encoder_forward(om, P, x)
+    _, _, probs = orc.mixture_posterior_statistics(lg, mu, lv)
+    logits, means, logvar = orc.closed_form_prior_update(probs, mu, lv)
+    assert rel_err(logits, fx["em/after/param/prior.logits"]) < TOL
+    assert rel_err(means, fx["em/after/param/prior.mu"]) < TOL
+    assert rel_err(logvar, fx["em/after/param/prior.logvar"]) < TOL
+    for k, v in P.items():  # the EM refresh touches the prior only
+        if not k.startswith("prior."):
+            assert np.array_equal(fx["em/after/param/" + k], v), k
