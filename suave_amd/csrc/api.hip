@@ -114,6 +114,7 @@ struct Workspace {
   float* wideT;  // row-major transposed copies of the wide heads' weights (WideCol::t_off), rewritten every backward
   int16_t* ecodes;  // [n_embed, rows] codes of the embedded columns (first encoder layer)
   float* wT[2 * SUAVE_MAX_HIDDEN + 2];  // row-major transposes of the layer weights, in all_layers() order
+  unsigned char* chain_img;             // bf16 plane images of the fused chains' weights (chain.hip), rewritten every call
   float* slab;
   double* sums_slab;
   size_t slab_floats;
@@ -174,6 +175,47 @@ std::vector<const suave_layer_t*> all_layers(const suave_plan* p) {
   return v;
 }
 
+// ---- fused chains (chain.hip): which parts of this model they take -----------------------------------------
+// decoder: z -> hidden layers -> y_projection in one launch (all widths <= kChainMaxWidth)
+bool decoder_chain_ok(const suave_plan* p) {
+  const suave_model_t& m = p->model;
+  if (!chain_enabled()) return false;
+  int k = m.latent_dim;
+  for (int i = 0; i < m.n_hidden; ++i) {
+    if (!chain_layer_ok(m.dec[i].n_out, k)) return false;
+    k = m.dec[i].n_out;
+  }
+  return chain_layer_ok(m.y_proj.n_out, k);
+}
+// encoder: x -> hidden layers (-> the component_logits rows of the head) in one launch; embedded first layers
+// (wide categorical columns, embed.hip) keep the per-layer path
+bool encoder_chain_ok(const suave_plan* p) {
+  const suave_model_t& m = p->model;
+  if (!chain_enabled() || !p->embed_host.empty() || m.n_hidden == 0) return false;
+  int k = m.enc_in;
+  for (int i = 0; i < m.n_hidden; ++i) {
+    if (!chain_layer_ok(m.enc[i].n_out, k)) return false;
+    k = m.enc[i].n_out;
+  }
+  return true;
+}
+size_t chain_images_bytes(const suave_plan* p) {  // the larger of the two chains' images (they run one after the other)...
+  const suave_model_t& m = p->model;
+  size_t enc = 0, dec = 0;
+  int k = m.enc_in;
+  for (int i = 0; i < m.n_hidden; ++i) { enc += chain_image_bytes(m.enc[i].n_out, k); k = m.enc[i].n_out; }
+  enc += chain_image_bytes(m.n_components, k);
+  k = m.latent_dim;
+  for (int i = 0; i < m.n_hidden; ++i) { dec += chain_image_bytes(m.dec[i].n_out, k); k = m.dec[i].n_out; }
+  dec += chain_image_bytes(m.y_proj.n_out, k);
+  // ... but kept side by side (+ the decoder's data-gradient chain: the same shapes transposed)
+  size_t bwd = 0;
+  k = m.latent_dim;
+  for (int i = 0; i < m.n_hidden; ++i) { bwd += chain_image_bytes(k, m.dec[i].n_out); k = m.dec[i].n_out; }
+  bwd += chain_image_bytes(k, m.y_proj.n_out);
+  return enc + dec + bwd + 64;
+}
+
 void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
   const suave_model_t& m = p->model;
   Carver c{static_cast<char*>(base)};
@@ -204,6 +246,7 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
     int li = 0;
     for (const suave_layer_t* l : all_layers(p)) w->wT[li++] = c.take<float>((size_t)l->n_in * round_up(l->n_out, 4) + 4);
   }
+  w->chain_img = c.take<unsigned char>(chain_images_bytes(p) + 16);
   w->catkl = c.take<float>(R);
   w->gausskl = c.take<float>(R);
   w->recon = c.take<float>(R);
@@ -287,6 +330,61 @@ int fwd_layer(const suave_plan* p, const float* params, const suave_layer_t& l, 
   g.step = nz ? nz->step : 0;
   g.stream_id = stream_id;
   return launch_gemm(g, p->n_cu, s);
+}
+
+// Decoder trunk + y_projection as one fused chain (decoder.py:286-300, :343-344).  hd == nullptr: the hidden
+// activations never leave the registers (validation, generation).
+int decoder_chain_forward(const suave_plan* p, const float* params, const float* z, int rows, float* const* hd, float* y,
+                          float drop_p, const suave_noise_t* nz, const suave_batch_t* b, int vdiv, unsigned char* images,
+                          hipStream_t s) {
+  const suave_model_t& m = p->model;
+  ChainArgs a;
+  std::memset(&a, 0, sizeof(a));
+  ChainWeights w[kChainMaxLayers];
+  int k = m.latent_dim, n = 0;
+  for (int i = 0; i < m.n_hidden; ++i, ++n) {
+    const suave_layer_t& l = m.dec[i];
+    w[n] = ChainWeights{params + l.w_off, l.n_out, k, l.ld, 0};
+    a.L[n].bias = params + l.b_off; a.L[n].out = hd ? hd[i] : nullptr; a.L[n].ldo = p->ldH[i];
+    a.L[n].epi = kChainReluDrop; a.L[n].keep = nz ? nz->dec_keep[i] : nullptr; a.L[n].stream_id = kStreamDecDrop + i;
+    k = l.n_out;
+  }
+  w[n] = ChainWeights{params + m.y_proj.w_off, m.y_proj.n_out, k, m.y_proj.ld, 0};
+  a.L[n].bias = params + m.y_proj.b_off; a.L[n].out = y; a.L[n].ldo = p->ldY; a.L[n].epi = kChainBias;
+  ++n;
+  a.n_layers = n; a.in = z; a.ld_in = p->ldD; a.in_width = m.latent_dim; a.rows = rows; a.drop_p = drop_p;
+  a.seed = nz ? nz->seed : 0; a.step = nz ? nz->step : 0;
+  a.row_ids = (b && vdiv == 1) ? b->row_index : nullptr;
+  a.row_begin = b ? b->row_begin * vdiv : 0;
+  return launch_chain(a, w, images, s);
+}
+
+// Encoder trunk (+ component_logits, written to `logits` with row stride ld_logits) as one fused chain
+// (encoder.py:46-58, :63-64).  he_all == false: only the last hidden activation is written.
+int encoder_chain_forward(const suave_plan* p, const float* params, const float* x, int rows, float* const* he, bool he_all,
+                          float* logits, int ld_logits, float drop_p, const suave_noise_t* nz, const suave_batch_t* b,
+                          unsigned char* images, hipStream_t s) {
+  const suave_model_t& m = p->model;
+  ChainArgs a;
+  std::memset(&a, 0, sizeof(a));
+  ChainWeights w[kChainMaxLayers];
+  int k = m.enc_in, n = 0;
+  for (int i = 0; i < m.n_hidden; ++i, ++n) {
+    const suave_layer_t& l = m.enc[i];
+    w[n] = ChainWeights{params + l.w_off, l.n_out, k, l.ld, 0};
+    a.L[n].bias = params + l.b_off; a.L[n].out = (he_all || i == m.n_hidden - 1) ? he[i] : nullptr; a.L[n].ldo = p->ldH[i];
+    a.L[n].epi = kChainReluDrop; a.L[n].keep = nz ? nz->enc_keep[i] : nullptr; a.L[n].stream_id = kStreamEncDrop + i;
+    k = l.n_out;
+  }
+  if (logits != nullptr && n < kChainMaxLayers) {
+    w[n] = ChainWeights{params + m.enc_head.w_off, m.n_components, k, m.enc_head.ld, 0};
+    a.L[n].bias = params + m.enc_head.b_off; a.L[n].out = logits; a.L[n].ldo = ld_logits; a.L[n].epi = kChainBias;
+    ++n;
+  }
+  a.n_layers = n; a.in = x; a.ld_in = p->ldI; a.in_width = m.enc_in; a.rows = rows; a.drop_p = drop_p;
+  a.seed = nz ? nz->seed : 0; a.step = nz ? nz->step : 0;
+  a.row_ids = b->row_index; a.row_begin = b->row_begin;
+  return launch_chain(a, w, images, s);
 }
 
 // data gradient: dA = (dC * W) [* relu/dropout mask of H]
@@ -456,6 +554,14 @@ int encoder_trunk_forward(const suave_plan* p, const float* params, const suave_
   const suave_model_t& m = p->model;
   const float* act = w.x;
   int ld_act = p->ldI;
+  if (encoder_chain_ok(p)) {
+    if (int rc = encoder_chain_forward(p, params, w.x, batch->n_rows, w.he, want_ecodes, nullptr, 0, drop_p, nz, batch,
+                                       w.chain_img, s))
+      return rc;
+    *act_out = w.he[m.n_hidden - 1];
+    *ld_out = p->ldH[m.n_hidden - 1];
+    return 0;
+  }
   for (int i = 0; i < m.n_hidden; ++i) {
     const bool embed = i == 0 && !p->embed_host.empty();
     if (embed) {
@@ -544,17 +650,22 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     a.eps_buf = w.eps; a.latent_out = out ? out->latent : nullptr;
     if (int rc = launch_mix_fwd(a, s)) return rc;
   }
-  act = w.z;
-  ld_act = p->ldD;
-  for (int i = 0; i < nh; ++i) {
-    if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], V, true, drop_p, nz->dec_keep[i], batch,
-                           nz, kStreamDecDrop + i, K, s))
+  if (decoder_chain_ok(p)) {
+    if (int rc = decoder_chain_forward(p, params, w.z, V, grad ? w.hd : nullptr, w.y, drop_p, nz, batch, K, w.chain_img, s))
       return rc;
-    act = w.hd[i];
-    ld_act = p->ldH[i];
+  } else {
+    act = w.z;
+    ld_act = p->ldD;
+    for (int i = 0; i < nh; ++i) {
+      if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], V, true, drop_p, nz->dec_keep[i], batch,
+                             nz, kStreamDecDrop + i, K, s))
+        return rc;
+      act = w.hd[i];
+      ld_act = p->ldH[i];
+    }
+    if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, V, false, 0.f, nullptr, batch, nz, 0, K, s))
+      return rc;
   }
-  if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, V, false, 0.f, nullptr, batch, nz, 0, K, s))
-    return rc;
   const int n_chunks = (int)p->chunks_host.size();
   const int lgrid = loss_grid(p, V);
   const int lworkers = loss_workers(p, V);
@@ -710,7 +821,14 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   if (int rc = launch_expand(p, *batch, w.x, w.cells, s)) return rc;
   const float* act = w.x;
   int ld_act = p->ldI;
-  if (int rc = encoder_trunk_forward(p, params, batch, nz, drop_p, w, grad, &act, &ld_act, s)) return rc;
+  const bool enc_chain = encoder_chain_ok(p) && nh + 1 <= kChainMaxLayers;
+  if (enc_chain) {  // trunk + component_logits in one launch; logits land in sel[:, 0:K]
+    if (int rc = encoder_chain_forward(p, params, w.x, B, w.he, grad, w.sel, p->ldK + 2 * p->ldD, drop_p, nz, batch,
+                                       w.chain_img, s))
+      return rc;
+    act = w.he[nh - 1];
+    ld_act = p->ldH[nh - 1];
+  } else if (int rc = encoder_trunk_forward(p, params, batch, nz, drop_p, w, grad, &act, &ld_act, s)) return rc;
   // ---- encoder head, selected component only ----
   // Only the logits and the selected component's mu / logvar enter the supervised loss (model.py:1587-1598,
   // losses.py:60-84), so the head is: logits GEMM -> assignment -> stable sort of the rows by component ->
@@ -735,7 +853,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   auto head_geometry = [&](GemmArgs& g) {
     g.perm = w.perm; g.chunk_comp = w.chunk_comp; g.hK = K; g.hD = D; g.hldK = p->ldK; g.hldD = p->ldD;
   };
-  {
+  if (!enc_chain) {
     GemmArgs g = gemm_base();  // logits = h * W[0:K]^T + b[0:K]  -> sel[:, 0:K]
     g.A = hlast_e; g.B = params + m.enc_head.w_off; g.C = w.sel; g.bias = params + m.enc_head.b_off;
     g.M = B; g.N = K; g.K = m.enc_head.n_in; g.lda = ldhe_last; g.ldb = m.enc_head.ld; g.ldc = ldS;
@@ -762,17 +880,22 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   la.prior_terms = w.prior_terms; la.sums_slab = w.sums_slab + (size_t)lworkers * n_chunks * 4;
   if (int rc = launch_reparam(la, s)) return rc;
   // ---- decoder trunk ----
-  act = w.z;
-  ld_act = p->ldD;
-  for (int i = 0; i < nh; ++i) {
-    if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], B, true, drop_p, nz->dec_keep[i], batch,
-                           nz, kStreamDecDrop + i, 1, s))
+  if (decoder_chain_ok(p)) {
+    if (int rc = decoder_chain_forward(p, params, w.z, B, grad ? w.hd : nullptr, w.y, drop_p, nz, batch, 1, w.chain_img, s))
       return rc;
-    act = w.hd[i];
-    ld_act = p->ldH[i];
+  } else {
+    act = w.z;
+    ld_act = p->ldD;
+    for (int i = 0; i < nh; ++i) {
+      if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], B, true, drop_p, nz->dec_keep[i], batch,
+                             nz, kStreamDecDrop + i, 1, s))
+        return rc;
+      act = w.hd[i];
+      ld_act = p->ldH[i];
+    }
+    if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, batch, nz, 0, 1, s))
+      return rc;
   }
-  if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, batch, nz, 0, 1, s))
-    return rc;
   // ---- fused likelihood (+ gradients) ----
   size_t slab_off = 0;
   float* head_slab = w.slab;
@@ -1274,19 +1397,43 @@ struct DecodeScratch {
   float* z;
   float* hd[SUAVE_MAX_HIDDEN];
   float* y;
+  unsigned char* chain_img;  // weight images of the fused decoder chain (null: per-layer path)
 };
 
 size_t carve_decode(const suave_plan* p, int64_t rows, void* base, DecodeScratch* d) {
   Carver c{static_cast<char*>(base)};
   const size_t R = (size_t)std::max<int64_t>(rows, 1);
   d->z = c.take<float>(R * p->ldD);
-  for (int i = 0; i < p->model.n_hidden; ++i) d->hd[i] = c.take<float>(R * p->ldH[i]);
+  d->chain_img = nullptr;
+  if (decoder_chain_ok(p)) {  // the hidden activations stay in registers: only the weight images need room
+    for (int i = 0; i < p->model.n_hidden; ++i) d->hd[i] = nullptr;
+    d->chain_img = c.take<unsigned char>(chain_images_bytes(p));
+  } else {
+    for (int i = 0; i < p->model.n_hidden; ++i) d->hd[i] = c.take<float>(R * p->ldH[i]);
+  }
   d->y = c.take<float>(R * p->ldY);
   return (c.off + 255) & ~size_t(255);
 }
 
 // Decoder trunk + y_projection + per-column sample draw on caller-validated arguments.  None of the kernels
 // below needs its scratch to start at any value: pad columns are masked when the tiles are staged.
+// eval-mode decoder trunk + y_projection on w.z -> w.y: no dropout (model.py:3613-3617, 4397-4419)
+int decoder_trunk_eval(const suave_plan* p, const float* params, const DecodeScratch& w, int B, hipStream_t st) {
+  const suave_model_t& m = p->model;
+  if (w.chain_img != nullptr) return decoder_chain_forward(p, params, w.z, B, nullptr, w.y, 0.f, nullptr, nullptr, 1, w.chain_img, st);
+  suave_batch_t dummy;
+  std::memset(&dummy, 0, sizeof(dummy));
+  const float* act = w.z;
+  int ld_act = p->ldD;
+  for (int i = 0; i < m.n_hidden; ++i) {
+    if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], B, true, 0.f, nullptr, &dummy, nullptr, 0, 1, st))
+      return rc;
+    act = w.hd[i];
+    ld_act = p->ldH[i];
+  }
+  return fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, &dummy, nullptr, 0, 1, st);
+}
+
 int decode_sample_impl(const suave_plan* p, const float* params, const float* z, const float* s_dense,
                        const int32_t* component, int B, const float* noise_normal, const float* noise_uniform,
                        const float* noise_exp, uint64_t seed, int64_t row_offset, const DecodeScratch& w, hipStream_t st,
@@ -1294,18 +1441,7 @@ int decode_sample_impl(const suave_plan* p, const float* params, const float* z,
   const suave_model_t& m = p->model;
   SUAVE_CHECK_HIP(hipMemcpy2DAsync(w.z, sizeof(float) * p->ldD, z, sizeof(float) * m.latent_dim,
                                    sizeof(float) * m.latent_dim, B, hipMemcpyDeviceToDevice, st));
-  suave_batch_t dummy;
-  std::memset(&dummy, 0, sizeof(dummy));
-  const float* act = w.z;
-  int ld_act = p->ldD;
-  for (int i = 0; i < m.n_hidden; ++i) {  // eval mode: no dropout (model.py:3613-3617, 4397-4419)
-    if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], B, true, 0.f, nullptr, &dummy, nullptr, 0, 1, st))
-      return rc;
-    act = w.hd[i];
-    ld_act = p->ldH[i];
-  }
-  if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, &dummy, nullptr, 0, 1, st))
-    return rc;
+  if (int rc = decoder_trunk_eval(p, params, w, B, st)) return rc;
   if (y_full_out)
     SUAVE_CHECK_HIP(hipMemcpy2DAsync(y_full_out, sizeof(float) * m.y_rows, w.y, sizeof(float) * p->ldY,
                                      sizeof(float) * m.y_rows, B, hipMemcpyDeviceToDevice, st));
@@ -1444,24 +1580,16 @@ extern "C" int suave_decode_params(const suave_plan* p, const float* params, con
   SUAVE_REQUIRE(s_dense != nullptr || component != nullptr, "decode_params: need dense assignments or component indices");
   const suave_model_t& m = p->model;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  Workspace w;
-  carve(p, n, workspace, &w);
-  SUAVE_REQUIRE(workspace_bytes >= w.total_bytes, "workspace too small (see suave_workspace_bytes)");
+  Workspace wfull;
+  carve(p, n, nullptr, &wfull);
+  SUAVE_REQUIRE(workspace_bytes >= wfull.total_bytes, "workspace too small (see suave_workspace_bytes)");
+  SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
+  DecodeScratch w;
+  SUAVE_REQUIRE(carve_decode(p, n, workspace, &w) <= workspace_bytes, "workspace too small (see suave_workspace_bytes)");
   const int B = (int)n;
   SUAVE_CHECK_HIP(hipMemcpy2DAsync(w.z, sizeof(float) * p->ldD, z, sizeof(float) * m.latent_dim,
                                    sizeof(float) * m.latent_dim, B, hipMemcpyDeviceToDevice, st));
-  suave_batch_t dummy;
-  std::memset(&dummy, 0, sizeof(dummy));
-  const float* act = w.z;
-  int ld_act = p->ldD;
-  for (int i = 0; i < m.n_hidden; ++i) {
-    if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], B, true, 0.f, nullptr, &dummy, nullptr, 0, 1, st))
-      return rc;
-    act = w.hd[i];
-    ld_act = p->ldH[i];
-  }
-  if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, &dummy, nullptr, 0, 1, st))
-    return rc;
+  if (int rc = decoder_trunk_eval(p, params, w, B, st)) return rc;
   int32_t width = 0;
   if (int rc = suave_head_params_width(p, col_index, &width)) return rc;
   return launch_head_params(p, col_index, params, w.y, s_dense, component, n, out_params, width, st);

@@ -79,7 +79,7 @@ def test_static_decode_rejects_oversized_requests_and_accepts_empty():
     eng = Engine(layout_from_columns(cols, K=10, D=32, hidden=(256, 128)), "cuda:0")
     eng.load_state(om.init_params(seed=1))
     L = eng.layout
-    n = 14979 + 64  # one tile beyond the documented limit of this model
+    n = 1 << 18  # far beyond what the 32 MiB buffer holds for this model
     z = torch.zeros((n, 32), device=eng.device)
     comp = torch.zeros((n,), dtype=torch.int32, device=eng.device)
     out_num = torch.empty((n, L.n_num), device=eng.device)
