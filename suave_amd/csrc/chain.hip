@@ -148,7 +148,11 @@ __device__ __forceinline__ void chain_layer(const ChainArgs& a, const int l, Cha
                                             const int rowc, const bool row_ok, const uint32_t rid) {
   const ChainLayer& L = a.L[l];
   const int lane = tid & 63;
-  const int l31 = lane & 31, kh = lane >> 5;
+  // The lane coordinates are laundered per layer: everything derived from them (input addresses of every k pair,
+  // the per-feature-group dropout constants, ...) is loop-invariant across the layer loop, and hoisted out of it
+  // by the compiler those few hundred values no longer fit the register file (they were spilled to scratch).
+  int l31 = lane & 31, kh = lane >> 5, rowv = rowc;
+  asm volatile("" : "+v"(l31), "+v"(kh), "+v"(rowv));
   const bool first = l == 0;
   f32x16 cur[NF];
 #pragma unroll
@@ -156,7 +160,7 @@ __device__ __forceinline__ void chain_layer(const ChainArgs& a, const int l, Cha
 #pragma unroll
     for (int r = 0; r < 16; ++r) cur[F][r] = 0.f;
 
-  const float* xrow = a.in + (size_t)rowc * a.ld_in;
+  const float* xrow = a.in + (size_t)rowv * a.ld_in;
   float4 xin[4];
   auto load_input = [&](int kp) {  // the lane's 16 inputs of k pair kp, in fragment order
 #pragma unroll
@@ -248,12 +252,24 @@ __device__ __forceinline__ void chain_layer(const ChainArgs& a, const int l, Cha
   const bool hashed = relu && a.drop_p > 0.f && L.keep == nullptr;
   const bool injected = relu && a.drop_p > 0.f && L.keep != nullptr;
   const bool masked = L.epi == kChainMask;
+  // (the schedule is pinned per feature tile, with the next tile's bias in flight: left alone the compiler hoists
+  // every load of the unrolled epilogue to its top -- 128+ VGPRs -- and spills, which a lone wave per SIMD cannot hide)
+  float4 bnext[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bnext[g] = *reinterpret_cast<const float4*>(L.biasp + 8 * g + 4 * kh);
 #pragma unroll
   for (int F = 0; F < NF; ++F) {
+    float4 bcur[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bcur[g] = bnext[g];
+    if (F + 1 < NF) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bnext[g] = *reinterpret_cast<const float4*>(L.biasp + 32 * (F + 1) + 8 * g + 4 * kh);
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int f0 = 32 * F + 8 * g + 4 * kh;
-      const float4 b4 = *reinterpret_cast<const float4*>(L.biasp + f0);
+      const float4 b4 = bcur[g];
       float v[4] = {cur[F][4 * g + 0] + b4.x, cur[F][4 * g + 1] + b4.y, cur[F][4 * g + 2] + b4.z, cur[F][4 * g + 3] + b4.w};
       if (relu) {
 #pragma unroll
@@ -268,25 +284,25 @@ __device__ __forceinline__ void chain_layer(const ChainArgs& a, const int l, Cha
         v[3] = (h1 >> 16) >= thr16 ? v[3] * inv_keep : 0.f;
       }
       if (injected) {  // parity runs: keep mask [rows, N] bytes
-        const uint8_t* kr = L.keep + (size_t)rowc * L.N;
+        const uint8_t* kr = L.keep + (size_t)rowv * L.N;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = kr[min(f0 + j, L.N - 1)] != 0 ? v[j] * inv_keep : 0.f;
       }
       if (masked) {  // backward through ReLU + dropout: the forward activation tells both
-        const float4 hv = *reinterpret_cast<const float4*>(L.mask_src + (size_t)rowc * L.ld_mask + (f0 < n_store ? f0 : 0));
+        const float4 hv = *reinterpret_cast<const float4*>(L.mask_src + (size_t)rowv * L.ld_mask + (f0 < n_store ? f0 : 0));
         v[0] = hv.x > 0.f ? v[0] * inv_keep : 0.f;
         v[1] = hv.y > 0.f ? v[1] * inv_keep : 0.f;
         v[2] = hv.z > 0.f ? v[2] * inv_keep : 0.f;
         v[3] = hv.w > 0.f ? v[3] * inv_keep : 0.f;
       }
+      // (features past N are exactly 0 here without a guard: zero weight rows, zero padded bias, relu / dropout /
+      // mask of 0 is 0 -- so the next layer's pad columns are finite)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = f0 + j < L.N ? v[j] : 0.f;  // features past N meet zero weights in the next layer: keep them finite
-        prev[F][4 * g + j] = v[j];
-      }
+      for (int j = 0; j < 4; ++j) prev[F][4 * g + j] = v[j];
       if (L.out != nullptr && row_ok && f0 < n_store)
         *reinterpret_cast<float4*>(L.out + (size_t)row * L.ldo + f0) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
