@@ -352,7 +352,9 @@ def main():
     table.xnum, table.codes, table.mask = xnum, codes, mask
     table.n_rows, table.ld_num, table.ld_disc, table.ld_mask = rows, xnum.shape[1], codes.shape[1], mask.shape[1]
 
-    buckets = parallel.gradient_buckets(layout)
+    # N > 1: the decoder-side gradient bucket is all-reduced behind the library's event while the encoder backward
+    # still runs, the encoder bucket after it (suave_amd/parallel.py DataParallel, suave_elbo_backward_overlap)
+    dp = parallel.DataParallel(layout, device) if dist is not None else None
     n_batches = max(1, rows // B)
     warmup_steps = max(1, 10 * n_batches)  # kl_warmup_epochs = 10 (model.py:59, :1448)
     state = {"perm": None, "step": 0}
@@ -366,9 +368,9 @@ def main():
         idx = state["perm"][i * B:(i + 1) * B]
         beta = 1.5 * min(state["step"], warmup_steps) / warmup_steps  # losses.kl_warmup
         eng.elbo(table, 0, B, row_index=idx, beta_scale=beta, tau=1.0, grad=True, global_rows=B * world,
-                 seed=1234, step=state["step"], accumulate_sums=True)
-        if dist is not None:  # RCCL sum of the flat gradient (each rank already scaled by 1/global_rows)
-            parallel.allreduce_gradients(eng.grads, buckets)
+                 seed=1234, step=state["step"], accumulate_sums=True, ready_event=dp.ready if dp else None)
+        if dp is not None:  # RCCL sum of the flat gradient (each rank already scaled by 1/global_rows)
+            dp.reduce_gradients(eng.grads)
         eng.adam_step(lr)
 
     def fence():

@@ -178,7 +178,8 @@ int suave_elbo_forward(const suave_plan* plan, const float* params, const suave_
  * loss.backward() (model.py:1496-1505).  loss = -mean_b(recon - beta*(KLs)) over
  * global_rows rows (== batch rows on one GPU; the global batch under data
  * parallelism, so that summing rank gradients gives the single-batch gradient).
- * grads [n_params] is overwritten with d loss / d params.
+ * grads [n_params] is overwritten with d loss / d params (all zeros for a batch of zero rows: the share of a
+ * rank whose shard of a small ragged batch is empty).
  * dlatent (may be NULL; supervised branch only) is [B,D] = d(extra loss)/d latent, added to the
  * gradient that reaches outputs["latent"]: the classification loss of joint fine-tuning
  * (`logits = classifier(outputs["latent"])`, model.py:1987-1991), whose head lives outside this library. */
@@ -186,6 +187,21 @@ int suave_elbo_backward(const suave_plan* plan, const float* params, const suave
                         const suave_noise_t* noise, float beta_scale, float tau,
                         int64_t global_rows, void* workspace, size_t workspace_bytes, void* stream,
                         const suave_elbo_out_t* out, float* grads, const float* dlatent);
+
+/* suave_elbo_backward for data-parallel callers -- no counterpart in the reference (it has no distributed code;
+ * the insertion point is between loss.backward() and optimizer.step(), model.py:1504-1506).  Same arguments and
+ * results.  In addition the library reduces the decoder-side bucket of the flat gradient (decoder trunk,
+ * y_projection, likelihood heads, prior: one contiguous range) as soon as the decoder backward has produced it
+ * and records `decoder_ready_event` (a hipEvent_t) on the stream at that point; the encoder backward and its
+ * reduction follow.  A caller makes its communication stream wait for the event and all-reduces that bucket while
+ * the encoder backward runs, then all-reduces the encoder bucket once the call's stream work is done.  (The
+ * unsupervised branch records the event at the end: its prior gradient is produced last.)  An empty batch writes
+ * a zero gradient and records the event. */
+int suave_elbo_backward_overlap(const suave_plan* plan, const float* params, const suave_batch_t* batch,
+                                const suave_noise_t* noise, float beta_scale, float tau,
+                                int64_t global_rows, void* workspace, size_t workspace_bytes, void* stream,
+                                const suave_elbo_out_t* out, float* grads, const float* dlatent,
+                                void* decoder_ready_event);
 
 /* torch.optim.Adam step (defaults betas=(0.9,0.999), eps=1e-8, no weight decay;
  * model.py:1443) on the flat buffers.  group_begin[g]..group_begin[g+1] is the

@@ -324,8 +324,7 @@ int fwd_layer(const suave_plan* p, const float* params, const suave_layer_t& l, 
   g.epi = relu_drop ? kEpiReluDrop : kEpiBias;
   g.drop_p = relu_drop ? drop_p : 0.f;
   g.keep = keep;
-  g.row_ids = (vdiv == 1) ? b->row_index : nullptr;
-  g.row_begin = b->row_begin * vdiv;
+  g.row_ids = b->row_index; g.row_begin = b->row_begin; g.row_vdiv = vdiv;
   g.seed = nz ? nz->seed : 0;
   g.step = nz ? nz->step : 0;
   g.stream_id = stream_id;
@@ -354,8 +353,7 @@ int decoder_chain_forward(const suave_plan* p, const float* params, const float*
   ++n;
   a.n_layers = n; a.in = z; a.ld_in = p->ldD; a.in_width = m.latent_dim; a.rows = rows; a.drop_p = drop_p;
   a.seed = nz ? nz->seed : 0; a.step = nz ? nz->step : 0;
-  a.row_ids = (b && vdiv == 1) ? b->row_index : nullptr;
-  a.row_begin = b ? b->row_begin * vdiv : 0;
+  a.row_ids = b ? b->row_index : nullptr; a.row_begin = b ? b->row_begin : 0; a.row_vdiv = vdiv;
   return launch_chain(a, w, images, s);
 }
 
@@ -793,18 +791,29 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
 
 int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* batch, const suave_noise_t* noise,
               float beta_scale, float tau, int training, int64_t global_rows, void* workspace,
-              size_t workspace_bytes, hipStream_t s, const suave_elbo_out_t* out, float* grads, const float* dlatent) {
+              size_t workspace_bytes, hipStream_t s, const suave_elbo_out_t* out, float* grads, const float* dlatent,
+              hipEvent_t ready_event = nullptr) {
   SUAVE_REQUIRE(p != nullptr && params != nullptr, "plan/params is null");
   if (int rc = check_batch(p, batch)) return rc;
   const suave_model_t& m = p->model;
   SUAVE_REQUIRE(dlatent == nullptr || m.behaviour == 0, "dlatent is only defined for the supervised branch (model.py:1987-1991)");
   SUAVE_REQUIRE(global_rows >= 1, "global_rows must be positive");
-  if (m.behaviour == 1)
-    return elbo_unsup_impl(p, params, batch, noise, beta_scale, tau, training, global_rows, workspace, workspace_bytes, s,
-                           out, grads);
+  if (batch->n_rows == 0) {  // an empty shard still owes its gradient (zero) and its event to the all-reduce
+    if (grads) SUAVE_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * m.n_params, s));
+    if (ready_event) SUAVE_CHECK_HIP(hipEventRecord(ready_event, s));
+    return 0;
+  }
+  if (m.behaviour == 1) {
+    if (int rc = elbo_unsup_impl(p, params, batch, noise, beta_scale, tau, training, global_rows, workspace, workspace_bytes,
+                                 s, out, grads))
+      return rc;
+    // (the PriorMean gradient comes out of the mixture finalisation, after the decoder backward: the unsupervised
+    // branch has one bucket, ready when everything is)
+    if (ready_event) SUAVE_CHECK_HIP(hipEventRecord(ready_event, s));
+    return 0;
+  }
   const bool grad = grads != nullptr;
   const int B = batch->n_rows;
-  if (B == 0) return 0;
   SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(params) & 15) == 0, "params must be 16-byte aligned");
   SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
   Workspace w;
@@ -964,6 +973,44 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
         if (i >= 0) lcur = &m.dec[i];
       }
     }
+    // ---- prior gradients: per-component column sums of prior_terms, out[c][k] (k_prior_colsum) ----
+    {
+      const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components;
+      const int ldc = round_up(Nt + 1, 4);
+      const int splits = prior_colsum_blocks(B);
+      if (int rc = launch_prior_colsum(w.prior_terms, ldT, w.kidx, B, Mt, Nt, ldc, w.slab + slab_off, s)) return rc;
+      SUAVE_REQUIRE(red.n_segs + 4 <= kMaxReduceSegs, "too many reduction segments");
+      ReduceSeg sm{};  // prior.mu[k][d] = out[d][k]
+      sm.src_off = (int64_t)slab_off; sm.slab_stride = (int64_t)Mt * ldc; sm.n_slabs = splits;
+      sm.rows = D; sm.cols = K; sm.src_ld = ldc; sm.dst_off = m.prior_mu_off; sm.dst_si = 1; sm.dst_sj = D;
+      red.segs[red.n_segs++] = sm;
+      ReduceSeg sv = sm;  // prior.logvar[k][d] = out[D + d][k]
+      sv.src_off += (int64_t)D * ldc; sv.dst_off = m.prior_logvar_off;
+      red.segs[red.n_segs++] = sv;
+      ReduceSeg sl = sm;  // prior.logits[j] = out[2D + j][K]  (ones column)
+      sl.src_off += (int64_t)2 * D * ldc + K; sl.rows = K; sl.cols = 1; sl.dst_off = m.prior_logits_off;
+      sl.dst_si = 1; sl.dst_sj = 1;
+      red.segs[red.n_segs++] = sl;
+      slab_off += (size_t)splits * Mt * ldc;
+    }
+    // ---- likelihood-head weights ----
+    {
+      ReduceSeg sh{};
+      sh.src_off = 0; sh.slab_stride = m.head_len; sh.n_slabs = lworkers / loss_workers_per_block(); sh.rows = 1; sh.cols = m.head_len;  // one row per block
+      sh.src_ld = m.head_len; sh.dst_off = m.head_off; sh.dst_si = 0; sh.dst_sj = 1;
+      red.segs[red.n_segs++] = sh;
+      max_elems = std::max(max_elems, m.head_len);
+    }
+    // ---- the decoder-side bucket (decoder, likelihood heads, prior: one contiguous range of the flat gradient) is
+    // complete here.  With an event to signal, reduce it now and record the event, so that a data-parallel caller
+    // can all-reduce this bucket while the encoder backward below is still running (suave_elbo_backward_overlap).
+    if (ready_event) {
+      if (int rc = launch_reduce(red, max_elems, s)) return rc;
+      SUAVE_CHECK_HIP(hipEventRecord(ready_event, s));
+      red.n_segs = 0;
+      red.sums_slab = nullptr; red.n_sum_slabs = 0; red.sums_out = nullptr;  // the epoch sums went with the first launch
+      max_elems = 256;
+    }
     // ---- latent backward ----
     if (dlatent) {  // classification loss of joint fine-tuning reaches the encoder through outputs["latent"]
       hipLaunchKernelGGL(k_add_rows, dim3(std::min((B * D + 255) / 256, 2048)), dim3(256), 0, s, w.dz, p->ldD, dlatent, D, B, D);
@@ -1016,39 +1063,12 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
         if (int rc = encoder_embed_backward(p, w, B, grads, s)) return rc;
       }
     }
-    // ---- prior gradients: per-component column sums of prior_terms, out[c][k] (k_prior_colsum) ----
-    {
-      const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components;
-      const int ldc = round_up(Nt + 1, 4);
-      const int splits = prior_colsum_blocks(B);
-      if (int rc = launch_prior_colsum(w.prior_terms, ldT, w.kidx, B, Mt, Nt, ldc, w.slab + slab_off, s)) return rc;
-      SUAVE_REQUIRE(red.n_segs + 4 <= kMaxReduceSegs, "too many reduction segments");
-      ReduceSeg sm{};  // prior.mu[k][d] = out[d][k]
-      sm.src_off = (int64_t)slab_off; sm.slab_stride = (int64_t)Mt * ldc; sm.n_slabs = splits;
-      sm.rows = D; sm.cols = K; sm.src_ld = ldc; sm.dst_off = m.prior_mu_off; sm.dst_si = 1; sm.dst_sj = D;
-      red.segs[red.n_segs++] = sm;
-      ReduceSeg sv = sm;  // prior.logvar[k][d] = out[D + d][k]
-      sv.src_off += (int64_t)D * ldc; sv.dst_off = m.prior_logvar_off;
-      red.segs[red.n_segs++] = sv;
-      ReduceSeg sl = sm;  // prior.logits[j] = out[2D + j][K]  (ones column)
-      sl.src_off += (int64_t)2 * D * ldc + K; sl.rows = K; sl.cols = 1; sl.dst_off = m.prior_logits_off;
-      sl.dst_si = 1; sl.dst_sj = 1;
-      red.segs[red.n_segs++] = sl;
-      slab_off += (size_t)splits * Mt * ldc;
-    }
-    // ---- likelihood-head weights ----
-    {
-      ReduceSeg sh{};
-      sh.src_off = 0; sh.slab_stride = m.head_len; sh.n_slabs = lworkers / loss_workers_per_block(); sh.rows = 1; sh.cols = m.head_len;  // one row per block
-      sh.src_ld = m.head_len; sh.dst_off = m.head_off; sh.dst_si = 0; sh.dst_sj = 1;
-      red.segs[red.n_segs++] = sh;
-      max_elems = std::max(max_elems, m.head_len);
-    }
     SUAVE_REQUIRE(slab_off <= w.slab_floats, "internal: slab overflow");
   }
-  if (grad || red.sums_out) {
+  if ((grad && red.n_segs > 0) || red.sums_out) {
     if (int rc = launch_reduce(red, max_elems, s)) return rc;
   }
+  if (!grad && ready_event) SUAVE_CHECK_HIP(hipEventRecord(ready_event, s));
   // ---- per-row outputs ----
   if (out) {
     if (out->reconstruction)
@@ -1365,6 +1385,18 @@ extern "C" int suave_elbo_backward(const suave_plan* plan, const float* params, 
   SUAVE_REQUIRE(grads != nullptr, "elbo_backward: grads is null");
   return elbo_impl(plan, params, batch, noise, beta_scale, tau, 1, global_rows, workspace, workspace_bytes,
                    static_cast<hipStream_t>(stream), out, grads, dlatent);
+}
+
+extern "C" int suave_elbo_backward_overlap(const suave_plan* plan, const float* params, const suave_batch_t* batch,
+                                           const suave_noise_t* noise, float beta_scale, float tau, int64_t global_rows,
+                                           void* workspace, size_t workspace_bytes, void* stream,
+                                           const suave_elbo_out_t* out, float* grads, const float* dlatent,
+                                           void* decoder_ready_event) {
+  suave::drop_stale_hip_error();
+  SUAVE_REQUIRE(grads != nullptr, "elbo_backward_overlap: grads is null");
+  SUAVE_REQUIRE(decoder_ready_event != nullptr, "elbo_backward_overlap: the event is null (use suave_elbo_backward)");
+  return elbo_impl(plan, params, batch, noise, beta_scale, tau, 1, global_rows, workspace, workspace_bytes,
+                   static_cast<hipStream_t>(stream), out, grads, dlatent, static_cast<hipEvent_t>(decoder_ready_event));
 }
 
 extern "C" int suave_encode(const suave_plan* p, const float* params, const suave_batch_t* batch,

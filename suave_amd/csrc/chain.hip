@@ -314,7 +314,14 @@ __global__ __launch_bounds__(256, 1) void k_chain(ChainArgs a) {
   const int row = blockIdx.x * kChainRows + wave * 32 + (lane & 31);
   const bool row_ok = row < a.rows;
   const int rowc = row_ok ? row : a.rows - 1;  // loads of rows past the end read the last row; nothing is stored
-  const uint32_t rid = a.row_ids ? static_cast<uint32_t>(a.row_ids[rowc]) : static_cast<uint32_t>(a.row_begin + rowc);
+  uint32_t rid;  // dropout key of the row: its table row (x components + component for virtual rows), see GemmArgs
+  if (a.row_vdiv > 1) {
+    const int drow = rowc / a.row_vdiv;
+    const uint32_t trow = a.row_ids ? static_cast<uint32_t>(a.row_ids[drow]) : static_cast<uint32_t>(a.row_begin + drow);
+    rid = trow * static_cast<uint32_t>(a.row_vdiv) + static_cast<uint32_t>(rowc - drow * a.row_vdiv);
+  } else {
+    rid = a.row_ids ? static_cast<uint32_t>(a.row_ids[rowc]) : static_cast<uint32_t>(a.row_begin + rowc);
+  }
 
   ChainState st;
   f32x16 prev[kMaxF];  // activated outputs of the previous layer (fp32), this lane's row

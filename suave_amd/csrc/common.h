@@ -202,8 +202,10 @@ struct GemmArgs {
   const float* H;         // kEpiMaskBwd: forward activation, same shape/ld as C;
                           // kEpiReluDrop: optional addend of the pre-activation (same shape/ld as C, may be C itself)
   const uint8_t* keep;    // kEpiReluDrop: injected keep mask [M, N] (ld = N) or null
-  const int32_t* row_ids; // table row id per output row (RNG key) or null -> row_begin + i
+  const int32_t* row_ids; // table row id per data row (RNG key) or null -> row_begin + data row
   int64_t row_begin;
+  int row_vdiv;           // > 1: output row i is virtual row (data row i / row_vdiv, component i % row_vdiv) and its
+                          // RNG key is table row * row_vdiv + component, so the draw follows the table row
   int M, N, K;
   int lda, ldb, ldc;
   int a_kmajor, b_kmajor; // element (i,k) at A[k*lda+i] if a_kmajor else A[i*lda+k]; same for B(k,j)

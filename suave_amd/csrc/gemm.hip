@@ -604,7 +604,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
             if (a.drop_p > 0.f) {
               if (hashed_drop) {
-                const uint32_t rid = a.row_ids ? static_cast<uint32_t>(a.row_ids[row]) : static_cast<uint32_t>(a.row_begin + row);
+                uint32_t rid;
+                if (a.row_vdiv > 1) {
+                  const int drow = row / a.row_vdiv;
+                  const uint32_t trow = a.row_ids ? static_cast<uint32_t>(a.row_ids[drow]) : static_cast<uint32_t>(a.row_begin + drow);
+                  rid = trow * static_cast<uint32_t>(a.row_vdiv) + static_cast<uint32_t>(row - drow * a.row_vdiv);
+                } else {
+                  rid = a.row_ids ? static_cast<uint32_t>(a.row_ids[row]) : static_cast<uint32_t>(a.row_begin + row);
+                }
                 const uint32_t hrow = drop_row_hash(key, rid);
                 const uint32_t h0 = hash32(hrow ^ (static_cast<uint32_t>(col >> 1) * 0x85EBCA77u));
                 const uint32_t h1 = hash32(hrow ^ (static_cast<uint32_t>((col >> 1) + 1) * 0x85EBCA77u));

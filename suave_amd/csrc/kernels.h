@@ -250,8 +250,9 @@ struct ChainArgs {
   int rows;
   float drop_p;
   uint64_t seed, step;
-  const int32_t* row_ids;     // table row of each batch row (dropout key) or null -> row_begin + i
+  const int32_t* row_ids;     // table row of each data row (dropout key) or null -> row_begin + data row
   int64_t row_begin;
+  int row_vdiv;               // > 1: virtual rows (data row, component), keyed as in GemmArgs
 };
 // weight of chain layer l: W [n_out, ld] row-major, or (transposed) the layer is x -> x * W with W [n_in, ld]
 struct ChainWeights {

@@ -129,10 +129,12 @@ class Engine:
              beta_scale: float, tau: Optional[float] = 1.0, grad: bool = True, training: bool = True,
              global_rows: Optional[int] = None, noise: Optional[Mapping[str, object]] = None, seed: int = 0,
              step: int = 0, want: Sequence[str] = (), accumulate_sums: bool = False,
-             dlatent: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+             dlatent: Optional[torch.Tensor] = None, ready_event: Optional[torch.cuda.Event] = None
+             ) -> Dict[str, torch.Tensor]:
         """One ELBO forward (+ backward into ``self.grads``).  ``want`` selects
         per-row outputs among reconstruction, categorical_kl, gaussian_kl,
-        latent, component, enc_out."""
+        latent, component, enc_out.  ``ready_event`` (grad only): recorded by the library once the
+        decoder-side gradient bucket is final, before the encoder backward (suave_elbo_backward_overlap)."""
 
         B = int(n_rows)
         unsup = self.layout.behaviour != "supervised"
@@ -156,7 +158,13 @@ class Engine:
             out.sums = self.sums.data_ptr()
         base = (ws.data_ptr() + 255) // 256 * 256
         nbytes = ws.numel() - (base - ws.data_ptr())
-        if grad:
+        if grad and ready_event is not None:
+            rc = self.lib.suave_elbo_backward_overlap(self._plan, self.params.data_ptr(), C.byref(batch), C.byref(nz),
+                                                      float(beta_scale), float(tau), int(global_rows or B), base, nbytes,
+                                                      self._stream(), C.byref(out), self.grads.data_ptr(), _ptr(dlatent),
+                                                      int(ready_event.cuda_event))
+            _lib.check(rc, "suave_elbo_backward_overlap")
+        elif grad:
             rc = self.lib.suave_elbo_backward(self._plan, self.params.data_ptr(), C.byref(batch), C.byref(nz),
                                               float(beta_scale), float(tau), int(global_rows or B), base, nbytes,
                                               self._stream(), C.byref(out), self.grads.data_ptr(), _ptr(dlatent))

@@ -22,6 +22,7 @@ EXPORTS = (
     "suave_workspace_bytes",
     "suave_elbo_forward",
     "suave_elbo_backward",
+    "suave_elbo_backward_overlap",
     "suave_adam_step",
     "suave_encode",
     "suave_prior_latents",
@@ -77,6 +78,8 @@ def load():
                                        C.POINTER(ElboOutT)]
     lib.suave_elbo_backward.argtypes = [vp, vp, C.POINTER(BatchT), C.POINTER(NoiseT), f32, f32, i64, vp, sz, vp,
                                         C.POINTER(ElboOutT), vp, vp]
+    lib.suave_elbo_backward_overlap.argtypes = [vp, vp, C.POINTER(BatchT), C.POINTER(NoiseT), f32, f32, i64, vp, sz, vp,
+                                                C.POINTER(ElboOutT), vp, vp, vp]
     lib.suave_adam_step.argtypes = [vp, vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, i64, f32, f32, f32, vp]
     lib.suave_encode.argtypes = [vp, vp, C.POINTER(BatchT), f32, vp, sz, vp, vp, vp, vp, vp]
     lib.suave_prior_latents.argtypes = [vp, vp, vp, vp, vp, u64, i64, i64, vp, vp, vp]

@@ -29,6 +29,7 @@ import pandas as pd
 import torch
 
 from . import data as data_utils
+from . import parallel
 from . import supervised as sup
 from .engine import Engine, PackedTable
 from .plan import ModelLayout
@@ -145,6 +146,7 @@ class SUAVE:
         self._refine_history: list = []
         self._step = 0
         self._replay: Optional[DrawReplay] = None
+        self._dp: Optional[parallel.DataParallel] = None  # set by fit when torch.distributed has > 1 rank
         # which constructor arguments were left to the defaults (model.py:460-473; persisted by save)
         self._auto_configured: Dict[str, bool] = {
             "latent_dim": latent_dim is None, "hidden_dims": hidden_dims is None, "head_hidden_dims": False,
@@ -161,6 +163,26 @@ class SUAVE:
     def _record_step_gradient(self) -> None:
         if self._replay is not None:
             self._replay.grads.append(self._engine.grads.clone())
+
+    def _shard(self, rows: torch.Tensor) -> torch.Tensor:
+        """This rank's rows of a global batch (all of them on one GPU)."""
+
+        return rows if self._dp is None else self._dp.shard(rows)
+
+    def _span(self, n_rows: int):
+        return (0, n_rows) if self._dp is None else self._dp.span(n_rows)
+
+    def _all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        return t if self._dp is None else self._dp.all_reduce(t)
+
+    def _backward(self, table: PackedTable, idx: torch.Tensor, **kw) -> None:
+        """One ELBO forward + backward on this rank's rows ``idx`` of a global batch, gradients reduced over ranks."""
+
+        dp = self._dp
+        self._engine.elbo(table, 0, int(idx.numel()), row_index=idx, grad=True, seed=self.random_state, step=self._step,
+                          accumulate_sums=True, ready_event=None if dp is None else dp.ready, **kw)
+        if dp is not None:
+            dp.reduce_gradients(self._engine.grads)
 
     def _select_device(self) -> torch.device:
         if self._device is not None:
@@ -191,7 +213,15 @@ class SUAVE:
             finetune_epochs: Optional[int] = None, decoder_refine_epochs: Optional[int] = None,
             joint_decoder_lr_scale: Optional[float] = None, early_stop_patience: Optional[int] = None) -> "SUAVE":
         """The reference's staged schedule (model.py:883-1380): ELBO warm-up, then for behaviour="supervised" the
-        classifier-head phase, joint fine-tuning and decoder refinement.  ``epochs`` overrides the warm-up length."""
+        classifier-head phase, joint fine-tuning and decoder refinement.  ``epochs`` overrides the warm-up length.
+
+        Data parallelism (no counterpart in the reference, which is single-device): when ``torch.distributed`` is
+        initialised with more than one rank, every rank calls ``fit`` with the SAME ``X`` / ``y``; each global batch
+        is sharded by rows over the ranks (``parallel.DataParallel``), gradients are summed over RCCL with the
+        decoder-side bucket overlapped with the encoder backward, epoch / validation sums and the EM statistics are
+        all-reduced, and every rank ends with bit-identical parameters equal (to fp32 summation order) to those of
+        a one-GPU fit on the whole batches.  The classifier head's own dropout masks (torch's generator) are
+        per-rank and are the one thing that does not reproduce the one-GPU draw."""
 
         if schema is not None:
             self.schema = schema
@@ -257,6 +287,11 @@ class SUAVE:
                 y_val_t = torch.from_numpy(self._map_targets(y_arr[val_idx])).to(eng.device)
         train = self._table(X_train)
         val = self._table(X_val) if n_val else None
+        self._dp = parallel.DataParallel.from_environment(self._layout, eng.device)
+        if self._dp is not None:
+            if self._replay is not None:
+                raise RuntimeError("recorded draws (parity tests) are per batch row and cannot be replayed on sharded batches")
+            self._dp.check_replicated(train.mask, train.xnum, train.codes)
         self._gen = torch.Generator(device=eng.device)
         self._gen.manual_seed(self.random_state)
         self._step = 0
@@ -327,12 +362,12 @@ class SUAVE:
                 warm_step += 1
                 self._step += 1
                 beta = self.beta * min(warm_step, kl_steps) / kl_steps  # losses.kl_warmup
-                eng.elbo(train, 0, int(idx.numel()), row_index=idx, beta_scale=beta, tau=tau, grad=True,
-                         seed=self.random_state, step=self._step, accumulate_sums=True,
-                         noise=self._noise_for(int(idx.numel())))
+                nb = int(idx.numel())
+                self._backward(train, self._shard(idx), beta_scale=beta, tau=tau, global_rows=nb,
+                               noise=self._noise_for(nb))
                 self._record_step_gradient()
                 eng.adam_step(self.learning_rate)
-            s = eng.sums.cpu().numpy()  # ONE host sync per epoch (the reference syncs 4-5x per batch)
+            s = self._all_reduce(eng.sums).cpu().numpy()  # ONE host sync per epoch (the reference syncs 4-5x per batch)
             cnt = max(s[3], 1.0)
             self._train_history.append({"reconstruction": s[0] / cnt, "categorical_kl": s[1] / cnt,
                                         "gaussian_kl": s[2] / cnt})
@@ -366,6 +401,8 @@ class SUAVE:
                 opt.step()
                 tot += loss.detach().double() * idx.numel()
             self._head_history.append(float(tot.item()) / n)
+        if self._dp is not None:  # the phase is replicated (cached latents, same seed); rank 0's bits win
+            self._dp.broadcast_module(self._classifier)
         self._classifier.eval()
 
     def _validation_scores(self, val: Optional[PackedTable], bs: int, y_val_t: Optional[torch.Tensor],
@@ -442,25 +479,31 @@ class SUAVE:
             eng.sums.zero_()
             ce_tot = torch.zeros((), device=eng.device, dtype=torch.float64)
             for idx64, idx in self._epoch_batches(n, eff):
-                nb = int(idx.numel())
+                nb = int(idx.numel())  # the global batch; `loc` are this rank's rows of it
                 self._step += 1
                 nz = self._noise_for(nb)
-                fwd = eng.elbo(train, 0, nb, row_index=idx, beta_scale=self.beta, tau=tau, grad=False, training=True,
-                               seed=self.random_state, step=self._step, want=("latent",), noise=nz)
+                loc, loc64 = self._shard(idx), self._shard(idx64)
+                fwd = eng.elbo(train, 0, int(loc.numel()), row_index=loc, beta_scale=self.beta, tau=tau, grad=False,
+                               training=True, seed=self.random_state, step=self._step, want=("latent",), noise=nz)
                 latent = fwd["latent"].requires_grad_(True)
-                class_loss = clf.loss(clf(latent), y_t[idx64])
+                if self._dp is None:
+                    class_loss = clf.loss(clf(latent), y_t[loc64])
+                else:  # the weighted mean over the GLOBAL batch: this rank's terms over the global weight sum
+                    class_loss = clf.loss_terms(clf(latent), y_t[loc64]) / clf.loss_weight(y_t[idx64])
                 clf_opt.zero_grad()
                 (class_loss * weight).backward()
-                eng.elbo(train, 0, nb, row_index=idx, beta_scale=self.beta, tau=tau, grad=True, seed=self.random_state,
-                         step=self._step, accumulate_sums=True, dlatent=latent.grad.contiguous(), noise=nz)
+                self._backward(train, loc, beta_scale=self.beta, tau=tau, global_rows=nb,
+                               dlatent=latent.grad.contiguous(), noise=nz)
+                if self._dp is not None:
+                    self._dp.reduce_module_gradients(clf)
                 self._record_step_gradient()
                 eng.adam_step(lrs)
                 clf_opt.step()
                 ce_tot += class_loss.detach().double() * nb
-            s = eng.sums.cpu().numpy()
+            s = self._all_reduce(eng.sums).cpu().numpy()
             cnt = max(s[3], 1.0)
             elbo_loss = -(s[0] - self.beta * (s[1] + s[2])) / cnt
-            ce = float(ce_tot.item()) / cnt
+            ce = float(self._all_reduce(ce_tot).item()) / cnt
             metrics = self._validation_scores(val, bs, y_val_t, weight)
             self._joint_history.append({"train_elbo_loss": elbo_loss, "train_classification_loss": ce,
                                         "train_joint": elbo_loss + weight * ce, "val": metrics})
@@ -487,14 +530,17 @@ class SUAVE:
         w = torch.zeros(K, device=eng.device, dtype=torch.float64)
         m1 = torch.zeros((K, D), device=eng.device, dtype=torch.float64)
         m2 = torch.zeros((K, D), device=eng.device, dtype=torch.float64)
-        for s0 in range(0, train.n_rows, 65536):
-            o = eng.encode(train, s0, min(65536, train.n_rows - s0))
+        r0, r1 = self._span(train.n_rows)  # sufficient statistics are sums over rows: shard, then all-reduce
+        for s0 in range(r0, r1, 65536):
+            o = eng.encode(train, s0, min(65536, r1 - s0))
             p = o["probs"].double()
             mu = o["enc_out"][:, K:K + K * D].reshape(-1, K, D).double()
             lv = o["enc_out"][:, K + K * D:].reshape(-1, K, D).double()
             w += p.sum(dim=0)
             m1 += (p.unsqueeze(-1) * mu).sum(dim=0)
             m2 += (p.unsqueeze(-1) * (torch.exp(lv) + mu * mu)).sum(dim=0)
+        for t in (w, m1, m2):
+            self._all_reduce(t)
         total = float(w.sum().item())
         if total <= 0.0:
             return
@@ -563,9 +609,9 @@ class SUAVE:
             eng.sums.zero_()
             for _, idx in self._epoch_batches(n, eff):
                 self._step += 1
-                eng.elbo(train, 0, int(idx.numel()), row_index=idx, beta_scale=self.beta, tau=tau, grad=True,
-                         seed=self.random_state, step=self._step, accumulate_sums=True,
-                         noise=self._noise_for(int(idx.numel())))
+                nb = int(idx.numel())
+                self._backward(train, self._shard(idx), beta_scale=self.beta, tau=tau, global_rows=nb,
+                               noise=self._noise_for(nb))
                 if anchors and lam != 0.0:  # + lambda * sum_t mse(prior_t, anchor_t)  (model.py:2338-2346)
                     for slot, snap in anchors:
                         nel = int(np.prod(slot.shape))
@@ -574,7 +620,7 @@ class SUAVE:
                 self._record_step_gradient()
                 eng.adam_step(lrs)
             done += 1
-            s = eng.sums.cpu().numpy()
+            s = self._all_reduce(eng.sums).cpu().numpy()
             cnt = max(s[3], 1.0)
             m = decorate(val_elbo())
             self._refine_history.append({"train_elbo_loss": -(s[0] - self.beta * (s[1] + s[2])) / cnt, "val": m})
@@ -595,9 +641,10 @@ class SUAVE:
         eff = min(batch_size, table.n_rows)
         for i, start in enumerate(range(0, table.n_rows, eff)):
             nb = min(eff, table.n_rows - start)
-            eng.elbo(table, start, nb, beta_scale=self.beta, tau=tau, grad=False, training=False, seed=seed, step=i,
-                     accumulate_sums=True, noise=self._noise_for(nb))
-        s = eng.sums.cpu().numpy()
+            b, e = self._span(nb)  # noise is keyed by (seed, step, table row): the sums do not depend on the sharding
+            eng.elbo(table, start + b, e - b, beta_scale=self.beta, tau=tau, grad=False, training=False, seed=seed,
+                     step=i, accumulate_sums=True, noise=self._noise_for(nb))
+        s = self._all_reduce(eng.sums).cpu().numpy()
         n = max(s[3], 1.0)
         return {"nll": float(((s[1] + s[2]) * self.beta - s[0]) / n), "reconstruction": float(s[0] / n),
                 "categorical_kl": float(s[1] / n), "gaussian_kl": float(s[2] / n)}

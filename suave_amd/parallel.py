@@ -9,10 +9,17 @@ bit-identical because every rank applies the same reduced gradient.
 
 Generation / encode / impute shard by rows with no collective: the counter-based generators are keyed
 by the global row index (``row_offset``), so outputs do not depend on the number of GPUs.
+
+``DataParallel`` is what ``SUAVE.fit`` and ``bench.py`` drive: the gradient all-reduce is cut in two buckets
+in the order the backward finishes them.  ``suave_elbo_backward_overlap`` records an event as soon as the
+decoder + likelihood heads + prior bucket is final -- before the latent / encoder backward is launched -- and
+the first collective starts behind that event on RCCL's stream while the encoder backward still runs on the
+compute stream; the encoder bucket follows on the compute stream's tail.
 """
 
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -87,3 +94,120 @@ def allreduce_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     return sums
+
+
+class DataParallel:
+    """Row-sharded data parallelism of one fit: rank / world, the two gradient buckets and the overlap plumbing.
+
+    Every rank holds the same packed table and the same parameters and walks the same global batches (same
+    permutation: same seed, same generator); of each global batch it computes the rows ``shard_rows`` gives it,
+    with ``global_rows`` = the global batch size.  The kernels key their noise by (seed, step, table row), so the
+    reduced gradient equals the one-GPU gradient of the whole batch up to fp32 summation order.
+    """
+
+    def __init__(self, layout, device, group=None) -> None:
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = torch.device(device)
+        self.host_staged = dist.get_backend(group) != "nccl"  # gloo rehearsal: reduce through host memory
+        self.early = (layout.group_ranges["decoder"][0], layout.group_ranges["prior"][1])  # final before the encoder backward
+        self.late = tuple(layout.group_ranges["encoder"])
+        if not (self.late[1] == self.early[0] or self.early[1] == self.late[0]):
+            raise ValueError("gradient groups are expected to be two adjacent ranges")
+        self.ready: Optional[torch.cuda.Event] = None
+        self.side: Optional[torch.cuda.Stream] = None
+        if not self.host_staged:
+            self.side = torch.cuda.Stream(self.device)
+            self.ready = torch.cuda.Event()
+            self.ready.record(torch.cuda.current_stream(self.device))  # materialise the hipEvent_t the library records
+
+    @classmethod
+    def from_environment(cls, layout, device, group=None) -> Optional["DataParallel"]:
+        """None unless torch.distributed is initialised with more than one rank (SUAVE_DP_SINGLE_RANK=1 keeps the
+        plumbing on for a one-rank group: the rehearsal of the RCCL stream / event path on a one-GPU box)."""
+
+        if not dist.is_available() or not dist.is_initialized():
+            return None
+        if dist.get_world_size(group) == 1 and os.environ.get("SUAVE_DP_SINGLE_RANK", "0") != "1":
+            return None
+        return cls(layout, device, group)
+
+    # -- sharding ---------------------------------------------------------------
+    def span(self, n_rows: int) -> Tuple[int, int]:
+        return shard_rows(n_rows, self.rank, self.world)
+
+    def shard(self, rows: torch.Tensor) -> torch.Tensor:
+        """This rank's rows of a global batch (a tensor of table row ids)."""
+
+        b, e = self.span(int(rows.shape[0]))
+        return rows[b:e]
+
+    # -- collectives ------------------------------------------------------------
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place SUM over ranks; every rank ends with the same bits."""
+
+        if self.host_staged and t.is_cuda:
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def reduce_gradients(self, flat_grads: torch.Tensor) -> None:
+        """SUM the flat gradient over ranks.  With RCCL, and ``self.ready`` handed to ``Engine.elbo`` for this
+        step, the decoder-side bucket is reduced while the encoder backward is still running; the compute stream
+        is made to wait for both collectives before it returns to the caller (who launches Adam next)."""
+
+        if self.host_staged:
+            for b, e in (self.early, self.late):
+                self.all_reduce(flat_grads[b:e])
+            return
+        self.side.wait_event(self.ready)
+        with torch.cuda.stream(self.side):
+            first = dist.all_reduce(flat_grads[self.early[0]:self.early[1]], op=dist.ReduceOp.SUM, group=self.group,
+                                    async_op=True)
+        second = dist.all_reduce(flat_grads[self.late[0]:self.late[1]], op=dist.ReduceOp.SUM, group=self.group,
+                                 async_op=True)
+        first.wait()   # both: the current (compute) stream waits, the host does not
+        second.wait()
+
+    def reduce_module_gradients(self, module: torch.nn.Module) -> None:
+        """SUM the gradients of a small torch module (the classifier head) as one flat buffer."""
+
+        ps = [p for p in module.parameters() if p.requires_grad]
+        if not ps:
+            return
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])
+        self.all_reduce(flat)
+        off = 0
+        for p in ps:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(flat[off:off + n].view_as(p))
+            off += n
+
+    def broadcast_module(self, module: torch.nn.Module, src: int = 0) -> None:
+        for t in list(module.parameters()) + list(module.buffers()):
+            if self.host_staged and t.is_cuda:
+                host = t.detach().cpu()
+                dist.broadcast(host, src=src, group=self.group)
+                t.data.copy_(host)
+            else:
+                dist.broadcast(t.data, src=src, group=self.group)
+
+    def check_replicated(self, *tensors: torch.Tensor) -> None:
+        """Every rank must have been given the same table: compare a (rows, checksum) pair over ranks."""
+
+        sig = torch.tensor([float(sum(int(t.shape[0]) for t in tensors))] +
+                           [float(t.double().sum().item()) if t.numel() else 0.0 for t in tensors], dtype=torch.float64)
+        lo, hi = sig.clone(), sig.clone()
+        if not self.host_staged:
+            lo, hi = lo.to(self.device), hi.to(self.device)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not torch.equal(lo.cpu(), hi.cpu()):
+            raise ValueError("data-parallel fit needs the SAME X / y on every rank (rows are sharded inside fit); "
+                             "the ranks' tables differ")

@@ -67,6 +67,15 @@ class ClassificationHead(nn.Module):
     def loss(self, logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
         return F.cross_entropy(logits, targets, weight=self.class_weight if self._use_weight else None)
 
+    # the same loss cut for row-sharded batches: loss == loss_terms(all rows) / loss_weight(all targets)
+    def loss_terms(self, logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        return F.cross_entropy(logits, targets, weight=self.class_weight if self._use_weight else None, reduction="sum")
+
+    def loss_weight(self, targets: torch.Tensor) -> torch.Tensor:
+        if self._use_weight:
+            return self.class_weight[targets].sum()
+        return torch.tensor(float(targets.numel()), device=targets.device)
+
 
 class TemperatureScaler:
     """calibrate.py:16-112: one log-temperature fitted by Adam on the cross-entropy of ``logits / T``."""

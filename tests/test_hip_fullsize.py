@@ -142,15 +142,22 @@ def test_generation_is_invariant_to_row_sharding_and_in_range(s64):
 
 
 def test_empty_inputs_are_accepted(s64):
-    """Zero-row batches: every entry point returns success and touches nothing (reference: batch == 0 guards,
-    model.py:3361-3362, 3398-3399, 4238)."""
+    """Zero-row batches: every entry point returns success and launches no model kernel (reference: batch == 0
+    guards, model.py:3361-3362, 3398-3399, 4238); the backward's gradient of nothing is zero."""
 
     import torch
 
     eng, table, layout = s64
-    g0 = eng.grads.clone()
-    eng.elbo(table, 0, 0, beta_scale=1.0, grad=True, global_rows=1)
-    assert torch.equal(g0, eng.grads)
+    eng.grads.fill_(1.0)
+    s0 = eng.sums.clone()
+    eng.elbo(table, 0, 0, beta_scale=1.0, grad=True, global_rows=1, accumulate_sums=True)
+    assert not eng.grads.any() and torch.equal(s0, eng.sums)
+    ev = torch.cuda.Event()
+    ev.record()
+    eng.grads.fill_(1.0)
+    eng.elbo(table, 0, 0, beta_scale=1.0, grad=True, global_rows=1, ready_event=ev)  # an empty shard still records
+    ev.synchronize()
+    assert not eng.grads.any()
     assert eng.encode(table, 0, 0)["enc_out"].shape[0] == 0
     z = torch.empty((0, layout.latent_dim), device=eng.device)
     onum, ocodes = eng.decode_sample(z, component=torch.empty((0,), dtype=torch.int32, device=eng.device))
@@ -162,3 +169,33 @@ def test_empty_inputs_are_accepted(s64):
     with pytest.raises(SuaveHipError, match="positive integer"):  # model.py:3313-3314
         eng.posterior_draws(torch.empty((0, K + 2 * K * D), device=eng.device), 0)
     assert eng.decode_params(z, 0, component=torch.empty((0,), dtype=torch.int32, device=eng.device)).shape[0] == 0
+
+
+def test_overlap_entry_point_matches_and_its_event_marks_a_final_decoder_bucket(s64):
+    """suave_elbo_backward_overlap (include/suave_hip.h): same gradient bits as suave_elbo_backward, and what a
+    communication stream reads from the decoder + heads + prior range once the event has fired -- while the
+    encoder backward is still running on the compute stream -- is already that range's final value."""
+
+    import torch
+
+    eng, table, layout = s64
+    B = 65536
+    idx = torch.randperm(ROWS, device=eng.device, generator=torch.Generator(eng.device).manual_seed(3))[:B].to(torch.int32)
+    dl = (0.01 * torch.randn((B, layout.latent_dim), device=eng.device, generator=torch.Generator(eng.device).manual_seed(4)))
+    eng.elbo(table, 0, B, row_index=idx, beta_scale=0.7, grad=True, seed=5, step=9, dlatent=dl, global_rows=2 * B)
+    ref = eng.grads.clone()
+    lo, hi = layout.group_ranges["decoder"][0], layout.group_ranges["prior"][1]
+    side = torch.cuda.Stream(eng.device)
+    ev = torch.cuda.Event()
+    ev.record()
+    early = torch.empty(hi - lo, device=eng.device)
+    for _ in range(3):
+        eng.grads.zero_()  # (alignment padding between tensors is never written: keep it equal to ref's)
+        eng.elbo(table, 0, B, row_index=idx, beta_scale=0.7, grad=True, seed=5, step=9, dlatent=dl, global_rows=2 * B,
+                 ready_event=ev)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            early.copy_(eng.grads[lo:hi])
+        torch.cuda.synchronize()
+        assert torch.equal(eng.grads, ref)
+        assert torch.equal(early, ref[lo:hi])

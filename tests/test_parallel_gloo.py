@@ -105,3 +105,72 @@ def test_two_rank_gradient_equals_single_batch(B):
         assert np.allclose(flat, ref, rtol=1e-4, atol=1e-6)
         assert abs(sums[0] - float(full["reconstruction"].sum())) < 1e-3 and sums[3] == B
     assert np.array_equal(results[0][2], results[1][2])  # replicas stay bit-identical
+
+
+def _dp_worker(rank, world, port, out_q):
+    """DataParallel's host logic (what SUAVE.fit drives) on CPU tensors: sharding, the two-bucket reduction, the
+    classifier-head gradient of a row-sharded weighted cross-entropy, broadcast, and the replicated-table check."""
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from suave_amd import supervised as sup
+
+    layout = layout_from_columns(s64_columns(12), K=3, D=4, hidden=(16, 8))
+    dp = parallel.DataParallel.from_environment(layout, "cpu")
+    assert dp is not None and dp.host_staged and dp.ready is None
+    rows = torch.arange(51)
+    mine = dp.shard(rows)
+    flat = torch.full((layout.n_params,), float(rank + 1))
+    dp.reduce_gradients(flat)
+    # classifier head: sharded loss_terms / global loss_weight == the whole batch's weighted mean
+    torch.manual_seed(0)
+    clf = sup.ClassificationHead(4, 3, class_weight=np.array([0.5, 1.0, 2.5], np.float32))
+    g = torch.Generator().manual_seed(1)
+    lat = torch.randn(51, 4, generator=g)
+    y = torch.randint(0, 3, (51,), generator=g)
+    loss = clf.loss_terms(clf(lat[mine]), y[mine]) / clf.loss_weight(y)
+    loss.backward()
+    dp.reduce_module_gradients(clf)
+    grad = torch.cat([p.grad.reshape(-1) for p in clf.parameters()])
+    with torch.no_grad():
+        for p in clf.parameters():
+            p.add_(float(rank))  # make the replicas differ, then rank 0's bits must win
+    dp.broadcast_module(clf)
+    after = torch.cat([p.detach().reshape(-1) for p in clf.parameters()])
+    dp.check_replicated(torch.ones(5, 2), torch.arange(10.0).view(5, 2))
+    mismatch = False
+    try:
+        dp.check_replicated(torch.full((5, 2), float(rank)))
+    except ValueError:
+        mismatch = True
+    out_q.put((rank, mine.numpy(), flat.numpy(), grad.numpy(), after.numpy(), mismatch))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_host_logic():
+    from suave_amd import supervised as sup
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(np.concatenate([res[0][1], res[1][1]]), np.arange(51))  # shards tile the batch
+    assert (res[0][2] == 3.0).all() and np.array_equal(res[0][2], res[1][2])       # both buckets cover every entry once
+    torch.manual_seed(0)
+    clf = sup.ClassificationHead(4, 3, class_weight=np.array([0.5, 1.0, 2.5], np.float32))
+    g = torch.Generator().manual_seed(1)
+    lat = torch.randn(51, 4, generator=g)
+    y = torch.randint(0, 3, (51,), generator=g)
+    clf.loss(clf(lat), y).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in clf.parameters()]).numpy()
+    assert np.array_equal(res[0][3], res[1][3]) and np.allclose(res[0][3], want, rtol=1e-5, atol=1e-7)
+    assert np.array_equal(res[0][4], res[1][4])
+    assert res[0][5] and res[1][5]
