@@ -33,7 +33,7 @@ for path in paths:
                 continue
             acc[disp[did][:2]][pmc.get(d.get("pmc_id"), "?")].append(d.get("value", 0.0))
         for k, dd in acc.items():
-            if "chain" in k[0] or "gemm" in k[0] or "loss" in k[0] or "sample" in k[0]:
+            if any(w in k[0] for w in ("chain", "gemm", "loss", "sample", "k_")):
                 print(f"{k[0][:60]} blocks={k[1]}")
                 for cn, v in sorted(dd.items()):
                     print(f"    {cn:32s} {sum(v)/len(v):18.1f} (n={len(v)})")

@@ -138,7 +138,8 @@ int tn_splits(const suave_plan* p, int n_out, int n_in1, int64_t rows) {
   const bool narrow = n_in1 <= 64;
   const int tiles = narrow ? ((n_out + 255) / 256) * ((n_in1 + 63) / 64) : ((n_out + 127) / 128) * ((n_in1 + 127) / 128);
   static const int factor = [] { const char* e = getenv("SUAVE_TN_FACTOR"); return e ? std::max(1, atoi(e)) : 1; }();
-  int64_t s = (factor * (int64_t)p->n_cu + tiles - 1) / tiles;
+  static const int divisor = [] { const char* e = getenv("SUAVE_TN_DIV"); return e ? std::max(1, atoi(e)) : 1; }();
+  int64_t s = (factor * (int64_t)p->n_cu / divisor + tiles - 1) / tiles;
   s = std::min<int64_t>(s, std::max<int64_t>(1, rows / 256));
   return (int)std::max<int64_t>(1, std::min<int64_t>(s, 512));
 }
@@ -416,15 +417,13 @@ int bwd_weight_args(const suave_plan* p, const suave_layer_t& l, const float* dC
   g.splits = splits;
   g.slab_stride = (int64_t)l.n_out * ldc;
   g.ones_col = l.n_in;
-  SUAVE_REQUIRE(red->n_segs + 2 <= kMaxReduceSegs, "too many reduction segments");
-  ReduceSeg w{};
+  SUAVE_REQUIRE(red->n_segs + 1 <= kMaxReduceSegs, "too many reduction segments");
+  ReduceSeg w{};  // weight columns + the ones column (bias gradient) of every slab row
   w.src_off = (int64_t)*slab_off; w.slab_stride = g.slab_stride; w.n_slabs = splits;
   w.rows = l.n_out; w.cols = l.n_in; w.src_ld = ldc;
   w.dst_off = l.w_off; w.dst_si = l.ld; w.dst_sj = 1;
+  w.bias_off1 = l.b_off + 1;
   red->segs[red->n_segs++] = w;
-  ReduceSeg bseg = w;
-  bseg.src_off += l.n_in; bseg.cols = 1; bseg.dst_off = l.b_off; bseg.dst_si = 1; bseg.dst_sj = 1;
-  red->segs[red->n_segs++] = bseg;
   *max_elems = std::max(*max_elems, l.n_out * l.n_in);
   *slab_off += (size_t)splits * l.n_out * ldc;
   *out = g;

@@ -117,7 +117,7 @@ struct ReduceSeg {
   int64_t src_off, slab_stride;
   int32_t n_slabs, rows, cols, src_ld;
   int32_t dst_off, dst_si, dst_sj;
-  int32_t pad;
+  int32_t bias_off1;  // != 0: column `cols` of every slab row is summed too, into dst[bias_off1 - 1 + i]
 };
 
 constexpr int kMaxReduceSegs = 48;

@@ -7,6 +7,7 @@
 // (_mixture_posterior_statistics); torch F.gumbel_softmax.
 #include "kernels.h"
 #include <algorithm>
+#include <cstdlib>
 
 #include "detmath.h"
 
@@ -513,34 +514,62 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
 }
 
 // dW_head[row(q, c)][j] = sum over the chunks of component c (all chunks for the logits rows), fixed order.
-__global__ __launch_bounds__(256) void k_head_reduce(HeadReduceArgs a) {
-  const int n_head = a.K + 2 * a.K * a.D;
-  const int64_t total = (int64_t)n_head * (a.n_in + 1);
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int R = (int)(e / (a.n_in + 1)), j = (int)(e % (a.n_in + 1));
-    int q, s0, s1;
-    if (R < a.K) {
-      q = R; s0 = 0; s1 = a.chunk_begin[a.K];
-    } else {
-      const int t = R - a.K;
-      const bool is_lv = t >= a.K * a.D;
-      const int u = is_lv ? t - a.K * a.D : t;
-      const int c = u / a.D, d = u % a.D;
-      q = a.ldK + (is_lv ? a.ldD : 0) + d;
-      s0 = a.chunk_begin[c]; s1 = a.chunk_begin[c + 1];
+// Both shapes are latency chains of strided loads, so they are cut short rather than wide:
+//   * blocks [0, logit_blocks): the K logits rows, whose sums run over EVERY chunk (266 at B = 65 536): 64 elements
+//     per block, the four waves take a quarter of the chunk range each, 16 loads in flight, quarters added in order;
+//   * the rest: the mu / logvar rows of component c sum only c's chunks (~27): one thread per element, 16 loads in
+//     flight, the tail of the range as a guarded batch instead of one load at a time.
+__global__ __launch_bounds__(256) void k_head_reduce(HeadReduceArgs a, int logit_blocks) {
+  const int n1 = a.n_in + 1;
+  const size_t stride = (size_t)a.ldS * a.ldc;
+  if ((int)blockIdx.x < logit_blocks) {
+    __shared__ float part[4][64];
+    const int sub = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 64 + lane;
+    const bool valid = e < a.K * n1;
+    const int R = valid ? e / n1 : 0, j = valid ? e - R * n1 : 0;
+    const int S = a.chunk_begin[a.K];
+    const int per = (S + 3) / 4;
+    const int s0 = min(sub * per, S), s1 = min(S, s0 + per);
+    const float* src = a.slab + (size_t)R * a.ldc + j;
+    float t = 0.f;
+    if (valid) {
+      for (int s = s0; s < s1; s += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = (s + u < s1) ? src[(size_t)(s + u) * stride] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += v[u];
+      }
     }
+    part[sub][lane] = t;
+    __syncthreads();
+    if (sub == 0 && valid) {
+      const float r = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+      if (j < a.n_in) a.grads[a.w_off + (size_t)R * a.ld + j] = r;
+      else a.grads[a.b_off + R] = r;
+    }
+    return;
+  }
+  const int64_t total = (int64_t)2 * a.K * a.D * n1;
+  for (int64_t e = (int64_t)(blockIdx.x - logit_blocks) * 256 + threadIdx.x; e < total;
+       e += (int64_t)(gridDim.x - logit_blocks) * 256) {
+    const int t_row = (int)(e / n1), j = (int)(e % n1);
+    const int R = a.K + t_row;
+    const bool is_lv = t_row >= a.K * a.D;
+    const int u_row = is_lv ? t_row - a.K * a.D : t_row;
+    const int c = u_row / a.D, d = u_row % a.D;
+    const int q = a.ldK + (is_lv ? a.ldD : 0) + d;
+    const int s0 = a.chunk_begin[c], s1 = a.chunk_begin[c + 1];
     const float* src = a.slab + (size_t)q * a.ldc + j;
-    const size_t stride = (size_t)a.ldS * a.ldc;
-    float t = 0.f;  // fixed summation order; 8 independent loads in flight
-    int s = s0;
-    for (; s + 8 <= s1; s += 8) {
-      float v[8];
+    float t = 0.f;
+    for (int s = s0; s < s1; s += 16) {
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + u) * stride];
+      for (int u = 0; u < 16; ++u) v[u] = (s + u < s1) ? src[(size_t)(s + u) * stride] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t += v[u];
+      for (int u = 0; u < 16; ++u) t += v[u];
     }
-    for (; s < s1; ++s) t += src[(size_t)s * stride];
     if (j < a.n_in) a.grads[a.w_off + (size_t)R * a.ld + j] = t;
     else a.grads[a.b_off + R] = t;
   }
@@ -865,7 +894,10 @@ __global__ __launch_bounds__(256) void k_prior_colsum(const float* __restrict__ 
 }
 
 // ---- host launchers -----------------------------------------------------------
-int prior_colsum_blocks(int n_rows) { return std::max(1, std::min((n_rows + 63) / 64, 1024)); }  // ~21 rows per thread: three load rounds (512 blocks: no better)
+int prior_colsum_blocks(int n_rows) {
+  static const int cap = [] { const char* e = getenv("SUAVE_PRIOR_BLOCKS"); return e ? std::max(1, atoi(e)) : 1024; }();  // tuning knob
+  return std::max(1, std::min((n_rows + 63) / 64, cap));
+}  // ~21 rows per thread: three load rounds (512 blocks: no better)
 
 int launch_prior_colsum(const float* terms, int ldT, const int32_t* kidx, int n_rows, int n_cols, int K, int ldc, float* slab,
                         hipStream_t s) {
@@ -948,9 +980,11 @@ int launch_reparam(const LatentFwdArgs& a, hipStream_t s) {
 }
 
 int launch_head_reduce(const HeadReduceArgs& a, hipStream_t s) {
-  const int64_t total = (int64_t)(a.K + 2 * a.K * a.D) * (a.n_in + 1);
+  const int64_t total = (int64_t)2 * a.K * a.D * (a.n_in + 1);
+  const int logit_blocks = (a.K * (a.n_in + 1) + 63) / 64;
   ProfScope prof_scope(kProfReduce, s);
-  hipLaunchKernelGGL(k_head_reduce, dim3((int)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_head_reduce, dim3(logit_blocks + (int)std::min<int64_t>(std::max<int64_t>((total + 255) / 256, 1), 2048)),
+                     dim3(256), 0, s, a, logit_blocks);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -18,6 +18,8 @@
 // reduced across the 64 rows with DPP wavefront reductions, accumulated per
 // block in LDS over the block's tiles, and flushed once to a slab that a
 // fixed-order reduction sums (deterministic, no float atomics).
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace suave {
@@ -30,6 +32,7 @@ constexpr int kMissing = kCellMissing;
 // barrier anywhere in the kernel, so a slow column type in one wave never stalls another.
 constexpr int kLossWaves = 4;
 constexpr int kLossThreads = kLossWaves * 64;
+constexpr int kWeightPad = 32;  // readable floats past a chunk's weight image: the numeric heads read KMAX weights at once
 
 // Sum over the 64 lanes with DPP row operations; result is wave-uniform.
 __device__ __forceinline__ float wave_sum_dpp(float v) {
@@ -67,7 +70,7 @@ __device__ unsigned long long g_loss_dbg[16];
 #endif
 
 template <bool GRAD, int KMAX>
-__global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
+__global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS admits three blocks per CU)
 #ifdef SUAVE_LOSS_TIMING
   unsigned long long dbg_acc[16] = {0};
   LOSS_T(tk0);
@@ -77,11 +80,11 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_floats = 64 * a.ldy + 2 * a.hw_max + a.max_classes * 64;
+  const int wave_floats = 64 * a.ldy + 2 * a.hw_max + kWeightPad + a.max_classes * 64;
   float* ytile = lds + (size_t)wave * wave_floats;  // [64][ldy]  this wave's y slice, overwritten with dY
   float* hw_acc = ytile + 64 * a.ldy;               // [hw_max]   head-weight gradients of this chunk
   float* wsm = hw_acc + a.hw_max;                   // [hw_max]   this chunk's head weights
-  float* gsw = wsm + a.hw_max + lane;               // [max_classes][64] per-class scratch of the categorical head
+  float* gsw = wsm + a.hw_max + kWeightPad + lane;  // [max_classes][64] per-class scratch of the categorical head
   const int chunk_id = blockIdx.y;
   const ColChunk ch = a.chunks[chunk_id];
   const int hw_begin = a.cols[ch.col_begin].w_off;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
   const int hw_next = (chunk_id + 1 < (int)gridDim.y) ? a.cols[a.chunks[chunk_id + 1].col_begin].w_off
                                                       : a.head_off + a.head_len;
   const int hw_len = min(a.hw_max, hw_next - hw_begin);
-  for (int i = lane; i < hw_len; i += 64) wsm[i] = a.params[hw_begin + i];
+  for (int i = lane; i < a.hw_max + kWeightPad; i += 64) wsm[i] = i < hw_len ? a.params[hw_begin + i] : 0.f;
   if (GRAD)
     for (int i = lane; i < a.hw_max; i += 64) hw_acc[i] = 0.f;
 
@@ -151,6 +154,142 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
         if (c0 + e >= 0 && c0 + e < ch.y_len) dst[e] = src[c0 + e];
     }
   };
+  // Register-blocked discrete heads (y_dim = classes <= YB): the column's y slice and, class by class, its weight
+  // row are read from LDS in one batch (clamped, branch-free), and the YB wavefront reductions of a class's weight
+  // gradient are independent DPP chains the scheduler interleaves.  (The operand-at-a-time loops they replace
+  // waited for an LDS round trip per multiply and ran the reductions one after the other.)
+  auto cat_col = [&](auto tag, const suave_col_t& col, int cell, bool obs, float u, float* yb, const float* wl, float* hw,
+                     int k, float& recon, float (&ds)[KMAX]) {
+    constexpr int YB = decltype(tag)::value;
+    const int yd = col.y_dim, C = col.n_classes, ldw = yd + K;
+    const int code = obs ? cell : -1;
+    float yv[YB];
+#pragma unroll
+    for (int i = 0; i < YB; ++i) {
+      const float t = yb[min(i, yd - 1)];
+      yv[i] = i < yd ? t : 0.f;
+    }
+    // sweep 1: logits, online log-sum-exp (logit 0 is pinned to 0)
+    float mx = 0.f, se = 1.f, lcode = 0.f;
+    for (int cl = 1; cl < C; ++cl) {
+      const float* wr = wl + (cl - 1) * ldw;
+      float wv[YB];
+#pragma unroll
+      for (int i = 0; i < YB; ++i) wv[i] = wr[min(i, yd - 1)];
+      float L = wr[yd + k];
+#pragma unroll
+      for (int i = 0; i < YB; ++i) L += wv[i] * yv[i];
+      gsw[cl * 64] = L;
+      if (L > mx) { se = se * __expf(mx - L) + 1.0f; mx = L; }
+      else se += __expf(L - mx);
+      if (cl == code) lcode = L;
+    }
+    const float lse = mx + __logf(se);
+    const bool has = code >= 0 && code < C;
+    recon += (obs && has) ? (lcode - lse) : 0.f;
+    if (GRAD) {
+      const bool live = obs && has;  // all-zero one-hot: sum(x) = 0 -> zero gradient
+      float dy[YB];
+#pragma unroll
+      for (int i = 0; i < YB; ++i) dy[i] = 0.f;
+      // sweep 2: g_c = u * (x_c - softmax_c); weight, assignment and y gradients of the class in one pass
+      for (int cl = 1; cl < C; ++cl) {
+        const float* wr = wl + (cl - 1) * ldw;
+        float* hr = hw + (cl - 1) * ldw;
+        float wv[YB], wk[KMAX];
+#pragma unroll
+        for (int i = 0; i < YB; ++i) wv[i] = wr[min(i, yd - 1)];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) wk[j] = wr[yd + j];  // (reads past K stay inside the padded weight image)
+        const float p = __expf(gsw[cl * 64] - lse);
+        const float g = live ? u * ((cl == code ? 1.0f : 0.f) - p) : 0.f;
+        float t[YB];
+#pragma unroll
+        for (int i = 0; i < YB; ++i) t[i] = wave_sum_dpp(g * yv[i]);
+#pragma unroll
+        for (int i = 0; i < YB; ++i) {
+          if (i < yd) acc_add(hr, i, t[i], lane);
+          dy[i] += g * wv[i];
+        }
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+          if (j < K) ds[j] += g * wk[j];
+        acc_add_lanes(hr + yd + k, g);
+      }
+#pragma unroll
+      for (int i = 0; i < YB; ++i)
+        if (i < yd) yb[i] = dy[i];
+    }
+  };
+  auto ord_col = [&](auto tag, const suave_col_t& col, int cell, bool obs, float u, float* yb, const float* wl, float* hw,
+                     int k, float& recon, float (&ds)[KMAX]) {
+    constexpr int YB = decltype(tag)::value;
+    const int yd = col.y_dim, C = col.n_classes;
+    const float* wml = wsm + (col.w2_off - hw_begin);  // mean_layer [yd + K]
+    float* hwm = hw_acc + (col.w2_off - hw_begin);
+    const int code = obs ? cell : -1;
+    const int t = max(code, 0);  // target = max(round(sum thermo) - 1, 0)
+    float yv[YB], wmv[YB], wmk[KMAX], raw[YB];
+#pragma unroll
+    for (int i = 0; i < YB; ++i) {
+      const float y = yb[min(i, yd - 1)];
+      yv[i] = i < yd ? y : 0.f;
+      wmv[i] = wml[min(i, yd - 1)];
+      raw[i] = wl[min(i, max(C - 2, 0)) * K + k];  // threshold parameters of this row's component
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) wmk[j] = wml[yd + j];
+    float mo = wml[yd + k];
+#pragma unroll
+    for (int i = 0; i < YB; ++i) mo += wmv[i] * yv[i];
+    float thr = 0.f, sg_t = 1.0f, sg_tm1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < YB; ++j) {
+      if (j < C - 1) {
+        thr += softplus_f(raw[j]) + kEps;
+        const float sgj = sigmoid_f(thr - mo);
+        if (j == t) sg_t = sgj;
+        if (j == t - 1) sg_tm1 = sgj;
+      }
+    }
+    const float p_raw = sg_t - sg_tm1;
+    const float p = fminf(fmaxf(p_raw, kEps), 1.0f);
+    recon += obs ? __logf(p) : 0.f;
+    if (GRAD) {
+      const float gp = (obs && p_raw >= kEps && p_raw <= 1.0f) ? u / p : 0.f;
+      const float du_t = (gp != 0.f && t < C - 1) ? gp * sg_t * (1.0f - sg_t) : 0.f;
+      const float du_tm1 = (gp != 0.f && t > 0) ? -gp * sg_tm1 * (1.0f - sg_tm1) : 0.f;
+      const float gmean = -(du_t + du_tm1);
+      float s[YB];
+#pragma unroll
+      for (int i = 0; i < YB; ++i) s[i] = wave_sum_dpp(gmean * yv[i]);
+#pragma unroll
+      for (int i = 0; i < YB; ++i) {
+        if (i < yd) {
+          acc_add(hwm, i, s[i], lane);
+          yb[i] = gmean * wmv[i];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j)
+        if (j < K) ds[j] += gmean * wmk[j];
+      acc_add_lanes(hwm + yd + k, gmean);
+#pragma unroll
+      for (int jj = 0; jj < YB; ++jj) {
+        if (jj < C - 1) {
+          float wk[KMAX];
+#pragma unroll
+          for (int j = 0; j < KMAX; ++j) wk[j] = wl[jj * K + j];
+          const float dsp = (jj <= t - 1 ? du_tm1 : 0.f) + (jj <= t ? du_t : 0.f);
+          const float gpart = dsp * softplus_grad_f(raw[jj]);
+#pragma unroll
+          for (int j = 0; j < KMAX; ++j)
+            if (j < K) ds[j] += gpart * wk[j];
+          acc_add_lanes(hw + jj * K + k, gpart);
+        }
+      }
+    }
+  };
   if (worker < n_tiles) prefetch(worker);
 
   for (int tile = worker; tile < n_tiles; tile += n_workers) {
@@ -190,14 +329,18 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
     }
     float* yrow = ytile + lane * a.ldy;
     int cell_next = valid ? cell_ptr[(size_t)ch.col_begin * 64] : kMissing;
+    suave_col_t col_next = a.cols[ch.col_begin];  // descriptor and cell of the next column are fetched a column ahead
 
     LOSS_T(t1);
     LOSS_ACC(0, t1 - t0);
     for (int c = ch.col_begin; c < ch.col_end; ++c) {
       LOSS_T(tc0);
-      const suave_col_t col = a.cols[c];
+      const suave_col_t col = col_next;
       const int cell = cell_next;
-      if (c + 1 < ch.col_end) cell_next = valid ? cell_ptr[(size_t)(c + 1) * 64] : kMissing;
+      if (c + 1 < ch.col_end) {
+        cell_next = valid ? cell_ptr[(size_t)(c + 1) * 64] : kMissing;
+        col_next = a.cols[c + 1];
+      }
       const bool obs = cell != kMissing;
       const float u = obs ? up : 0.f;
       float* yb = yrow + (col.y_off - ch.y_begin);
@@ -207,7 +350,65 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
       const float* wl = wsm + (col.w_off - hw_begin);
       const float* w = wl;
       float* hw = hw_acc + (col.w_off - hw_begin);
-      if (col.type == SUAVE_TYPE_REAL || col.type == SUAVE_TYPE_POS) {
+      if ((col.type == SUAVE_TYPE_REAL || col.type == SUAVE_TYPE_POS) && yd == 1) {
+        // y_dim == 1 (the default; decoder.py:87-99): every LDS operand of the column is read before the arithmetic starts, the
+        // K assignment weights unconditionally up to KMAX (the weight image is padded), so one wait covers them all
+        const float* wvl = wsm + (col.w2_off - hw_begin);
+        float* hwv = hw_acc + (col.w2_off - hw_begin);
+        const float y0 = yb[0], w0 = wl[0];
+        const float bm = wl[1 + k], bv = wvl[k];
+        float wk[KMAX], wvk[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) { wk[j] = wl[1 + j]; wvk[j] = wvl[j]; }
+        const float am = bm + w0 * y0;
+        const float x = obs ? __int_as_float(cell) : 0.f;
+        const float v = softplus_f(bv) + kEps;
+        const float mean = am * col.scale + col.shift;
+        const float vs = v * (col.scale * col.scale);
+        const float xr = x * col.scale + col.shift;
+        const float cc = fmaxf(vs, kEps);
+        const float rr = xr - mean;
+        float nll = 0.5f * (kLog2Pi + __logf(cc) + rr * rr / cc);
+        if (col.type == SUAVE_TYPE_POS) nll += xr;
+        recon += obs ? -nll : 0.f;
+        if (GRAD) {
+          // masked / out-of-tile lanes get an exact zero (select, not 0 * x: x may be inf or NaN there)
+          const float ga = obs ? u * (rr / cc) * col.scale : 0.f;
+          const float gb = (obs && vs >= kEps) ? u * (-0.5f) * (1.0f / cc - rr * rr / (cc * cc)) *
+                                                      (col.scale * col.scale) * softplus_grad_f(bv)
+                                                : 0.f;
+          const float t = wave_sum_dpp(ga * y0);
+          yb[0] = ga * w0;
+#pragma unroll
+          for (int j = 0; j < KMAX; ++j)
+            if (j < K) ds[j] += ga * wk[j] + gb * wvk[j];
+          acc_add(hw, 0, t, lane);
+          acc_add_lanes(hw + 1 + k, ga);
+          acc_add_lanes(hwv + k, gb);
+        }
+      } else if (col.type == SUAVE_TYPE_COUNT && yd == 1) {
+        const float y0 = yb[0], w0 = wl[0];
+        float wk[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) wk[j] = wl[1 + j];
+        const float rho = wl[1 + k] + w0 * y0;
+        const float x = obs ? __int_as_float(cell) : 0.f;
+        const float rate = softplus_f(rho) + kEps;
+        const float cnt = fmaxf(__expf(x) - col.shift, 0.f);
+        const float rc = fmaxf(rate, kEps);
+        const float lp = (cnt == 0.f ? 0.f : cnt * __logf(rc)) - rc - lgammaf(cnt + 1.0f);
+        recon += obs ? lp : 0.f;
+        if (GRAD) {
+          const float gr = obs ? u * (cnt / rc - 1.0f) * softplus_grad_f(rho) : 0.f;
+          const float t = wave_sum_dpp(gr * y0);
+          yb[0] = gr * w0;
+#pragma unroll
+          for (int j = 0; j < KMAX; ++j)
+            if (j < K) ds[j] += gr * wk[j];
+          acc_add(hw, 0, t, lane);
+          acc_add_lanes(hw + 1 + k, gr);
+        }
+      } else if (col.type == SUAVE_TYPE_REAL || col.type == SUAVE_TYPE_POS) {  // y_dim > 1 (Schema y_dimensions override)
         const float* wvl = wsm + (col.w2_off - hw_begin);
         const float* wv = wvl;
         float* hwv = hw_acc + (col.w2_off - hw_begin);
@@ -269,97 +470,107 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
           acc_add_lanes(hw + yd + k, gr);
         }
       } else if (col.type == SUAVE_TYPE_CAT) {
-        const int C = col.n_classes;
-        const int ldw = yd + K;
-        const int code = obs ? cell : -1;
-        // sweep 1: logits, online log-sum-exp (logit 0 is pinned to 0)
-        float mx = 0.f, se = 1.f, lcode = 0.f;
-        for (int cl = 1; cl < C; ++cl) {
-          const float* wr = w + (cl - 1) * ldw;
-          float L = wl[(cl - 1) * ldw + yd + k];
-          for (int i = 0; i < yd; ++i) L += wr[i] * yb[i];
-          gsw[cl * 64] = L;
-          if (L > mx) { se = se * __expf(mx - L) + 1.0f; mx = L; }
-          else se += __expf(L - mx);
-          if (cl == code) lcode = L;
-        }
-        const float lse = mx + __logf(se);
-        const bool has = code >= 0 && code < C;
-        recon += (obs && has) ? (lcode - lse) : 0.f;
-        if (GRAD) {
-          const bool live = obs && has;     // all-zero one-hot: sum(x) = 0 -> zero gradient
-          // sweep 2: g_c = u * (x_c - softmax_c); weight gradients while y is intact
+        if (yd <= 2) cat_col(std::integral_constant<int, 2>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds);
+        else if (yd <= 4) cat_col(std::integral_constant<int, 4>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds);
+        else if (yd <= 8) cat_col(std::integral_constant<int, 8>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds);
+        else {  // more classes than the register-blocked paths take: one LDS round trip per operand
+  const int C = col.n_classes;
+          const int ldw = yd + K;
+          const int code = obs ? cell : -1;
+          // sweep 1: logits, online log-sum-exp (logit 0 is pinned to 0)
+          float mx = 0.f, se = 1.f, lcode = 0.f;
           for (int cl = 1; cl < C; ++cl) {
-            const float p = __expf(gsw[cl * 64] - lse);
-            const float g = live ? u * ((cl == code ? 1.0f : 0.f) - p) : 0.f;
-            gsw[cl * 64] = g;
-            float* hr = hw + (cl - 1) * ldw;
-            for (int i = 0; i < yd; ++i) {
-              const float t = wave_sum_dpp(g * yb[i]);
-              acc_add(hr, i, t, lane);
-            }
             const float* wr = w + (cl - 1) * ldw;
-#pragma unroll
-            for (int j = 0; j < KMAX; ++j) {
-              if (j < K) {
-                ds[j] += g * wr[yd + j];
-              }
-            }
-            acc_add_lanes(hr + yd + k, g);
+            float L = wl[(cl - 1) * ldw + yd + k];
+            for (int i = 0; i < yd; ++i) L += wr[i] * yb[i];
+            gsw[cl * 64] = L;
+            if (L > mx) { se = se * __expf(mx - L) + 1.0f; mx = L; }
+            else se += __expf(L - mx);
+            if (cl == code) lcode = L;
           }
-          // sweep 3: dY
-          for (int i = 0; i < yd; ++i) {
-            float dy = 0.f;
-            for (int cl = 1; cl < C; ++cl) dy += gsw[cl * 64] * w[(cl - 1) * ldw + i];
-            yb[i] = dy;
+          const float lse = mx + __logf(se);
+          const bool has = code >= 0 && code < C;
+          recon += (obs && has) ? (lcode - lse) : 0.f;
+          if (GRAD) {
+            const bool live = obs && has;     // all-zero one-hot: sum(x) = 0 -> zero gradient
+            // sweep 2: g_c = u * (x_c - softmax_c); weight gradients while y is intact
+            for (int cl = 1; cl < C; ++cl) {
+              const float p = __expf(gsw[cl * 64] - lse);
+              const float g = live ? u * ((cl == code ? 1.0f : 0.f) - p) : 0.f;
+              gsw[cl * 64] = g;
+              float* hr = hw + (cl - 1) * ldw;
+              for (int i = 0; i < yd; ++i) {
+                const float t = wave_sum_dpp(g * yb[i]);
+                acc_add(hr, i, t, lane);
+              }
+              const float* wr = w + (cl - 1) * ldw;
+#pragma unroll
+              for (int j = 0; j < KMAX; ++j) {
+                if (j < K) {
+                  ds[j] += g * wr[yd + j];
+                }
+              }
+              acc_add_lanes(hr + yd + k, g);
+            }
+            // sweep 3: dY
+            for (int i = 0; i < yd; ++i) {
+              float dy = 0.f;
+              for (int cl = 1; cl < C; ++cl) dy += gsw[cl * 64] * w[(cl - 1) * ldw + i];
+              yb[i] = dy;
+            }
           }
         }
       } else {  // ordinal: cumulative link
-        const int C = col.n_classes;
-        const float* wml = wsm + (col.w2_off - hw_begin);  // mean_layer [yd + K]
-        const float* wm = wml;
-        float* hwm = hw_acc + (col.w2_off - hw_begin);
-        const int code = obs ? cell : -1;
-        const int t = max(code, 0);  // target = max(round(sum thermo) - 1, 0)
-        float mo = wml[yd + k];
-        for (int i = 0; i < yd; ++i) mo += wm[i] * yb[i];
-        float thr = 0.f, sg_t = 1.0f, sg_tm1 = 0.f;
-        for (int j = 0; j < C - 1; ++j) {
-          thr += softplus_f(wl[j * K + k]) + kEps;
-          const float sgj = sigmoid_f(thr - mo);
-          if (j == t) sg_t = sgj;
-          if (j == t - 1) sg_tm1 = sgj;
-        }
-        const float p_raw = sg_t - sg_tm1;
-        const float p = fminf(fmaxf(p_raw, kEps), 1.0f);
-        recon += obs ? __logf(p) : 0.f;
-        if (GRAD) {
-          const float gp = (obs && p_raw >= kEps && p_raw <= 1.0f) ? u / p : 0.f;
-          const float du_t = (gp != 0.f && t < C - 1) ? gp * sg_t * (1.0f - sg_t) : 0.f;
-          const float du_tm1 = (gp != 0.f && t > 0) ? -gp * sg_tm1 * (1.0f - sg_tm1) : 0.f;
-          const float gmean = -(du_t + du_tm1);
-          for (int i = 0; i < yd; ++i) {
-            const float s = wave_sum_dpp(gmean * yb[i]);
-            acc_add(hwm, i, s, lane);
-            yb[i] = gmean * wm[i];
+        const int need = max(yd, col.n_classes - 1);  // y features and thresholds both live in YB registers
+        if (need <= 4) ord_col(std::integral_constant<int, 4>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds);
+        else if (need <= 8) ord_col(std::integral_constant<int, 8>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds);
+        else {
+  const int C = col.n_classes;
+          const float* wml = wsm + (col.w2_off - hw_begin);  // mean_layer [yd + K]
+          const float* wm = wml;
+          float* hwm = hw_acc + (col.w2_off - hw_begin);
+          const int code = obs ? cell : -1;
+          const int t = max(code, 0);  // target = max(round(sum thermo) - 1, 0)
+          float mo = wml[yd + k];
+          for (int i = 0; i < yd; ++i) mo += wm[i] * yb[i];
+          float thr = 0.f, sg_t = 1.0f, sg_tm1 = 0.f;
+          for (int j = 0; j < C - 1; ++j) {
+            thr += softplus_f(wl[j * K + k]) + kEps;
+            const float sgj = sigmoid_f(thr - mo);
+            if (j == t) sg_t = sgj;
+            if (j == t - 1) sg_tm1 = sgj;
           }
-#pragma unroll
-          for (int j = 0; j < KMAX; ++j) {
-            if (j < K) {
-              ds[j] += gmean * wm[yd + j];
+          const float p_raw = sg_t - sg_tm1;
+          const float p = fminf(fmaxf(p_raw, kEps), 1.0f);
+          recon += obs ? __logf(p) : 0.f;
+          if (GRAD) {
+            const float gp = (obs && p_raw >= kEps && p_raw <= 1.0f) ? u / p : 0.f;
+            const float du_t = (gp != 0.f && t < C - 1) ? gp * sg_t * (1.0f - sg_t) : 0.f;
+            const float du_tm1 = (gp != 0.f && t > 0) ? -gp * sg_tm1 * (1.0f - sg_tm1) : 0.f;
+            const float gmean = -(du_t + du_tm1);
+            for (int i = 0; i < yd; ++i) {
+              const float s = wave_sum_dpp(gmean * yb[i]);
+              acc_add(hwm, i, s, lane);
+              yb[i] = gmean * wm[i];
             }
-          }
-          acc_add_lanes(hwm + yd + k, gmean);
-          for (int jj = 0; jj < C - 1; ++jj) {
-            const float dsp = (jj <= t - 1 ? du_tm1 : 0.f) + (jj <= t ? du_t : 0.f);
-            const float gpart = dsp * softplus_grad_f(wl[jj * K + k]);
 #pragma unroll
             for (int j = 0; j < KMAX; ++j) {
               if (j < K) {
-                ds[j] += gpart * w[jj * K + j];
+                ds[j] += gmean * wm[yd + j];
               }
             }
-            acc_add_lanes(hw + jj * K + k, gpart);
+            acc_add_lanes(hwm + yd + k, gmean);
+            for (int jj = 0; jj < C - 1; ++jj) {
+              const float dsp = (jj <= t - 1 ? du_tm1 : 0.f) + (jj <= t ? du_t : 0.f);
+              const float gpart = dsp * softplus_grad_f(wl[jj * K + k]);
+#pragma unroll
+              for (int j = 0; j < KMAX; ++j) {
+                if (j < K) {
+                  ds[j] += gpart * w[jj * K + j];
+                }
+              }
+              acc_add_lanes(hw + jj * K + k, gpart);
+            }
           }
         }
       }
@@ -439,7 +650,7 @@ __global__ __launch_bounds__(kLossThreads, 4) void k_loss(LossArgs a) {
 
 size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes, int ldx, int ldm) {
   (void)K; (void)ldx; (void)ldm;
-  return (size_t)kLossWaves * ((size_t)64 * ldy + 2 * (size_t)hw_max + (size_t)max_classes * 64) * sizeof(float);
+  return (size_t)kLossWaves * ((size_t)64 * ldy + 2 * (size_t)hw_max + kWeightPad + (size_t)max_classes * 64) * sizeof(float);
 }
 
 int loss_workers_per_block() { return kLossWaves; }

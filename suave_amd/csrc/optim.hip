@@ -8,108 +8,150 @@
 namespace suave {
 
 
-__global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
-  const int seg_id = blockIdx.y;
-  if (seg_id == a.n_segs) {  // scalar sums (double), one block: strided partials, then a fixed-order tree
-    if (blockIdx.x == 0 && a.sums_slab && a.sums_out) {
-      __shared__ double part[3][256];
-      const int t = threadIdx.x;
+// Work list of one launch: block 0 sums the scalar (double) partials; blocks blk_begin[g] .. blk_begin[g + 1] own
+// reduce_epb(segment g) consecutive (vector) elements each.  A flat list instead of a (max elements, segments) grid:
+// most blocks of that grid had nothing to do, and the few that had ran two to a CU.
+struct ReduceMap {
+  int32_t blk_begin[kMaxReduceSegs + 1];
+};
+constexpr int kReduceWaves = 16;  // waves of a block
+
+// Elements per block.  The slab range of an element is cut over the block's waves, and for segments with many
+// slabs and few elements (per-block column sums: 1024 slabs of 74 x 12 floats) also over lane groups of a wave, so
+// that a lane's whole share (<= 16 loads) is in flight at once: the kernel is a latency chain, not a stream.
+__host__ __device__ inline int reduce_epb(int n_slabs) { return n_slabs > 1024 ? 4 : n_slabs > 256 ? 16 : 64; }
+
+__host__ __device__ inline bool reduce_seg_vec(const ReduceSeg& sg, const float* slab) {
+  // Slabs whose rows are 16-byte aligned (every GEMM slab: ldc and the slab offsets are multiples of 4 floats) are
+  // read as float4: lane = 4 consecutive columns of one row, 1 KB per wave load instead of 256 B.
+  return ((sg.src_off | sg.src_ld | sg.slab_stride) & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0;
+}
+
+__global__ __launch_bounds__(kReduceWaves * 64) void k_reduce(ReduceArgs a, ReduceMap map) {
+  const int t = threadIdx.x;
+  if (blockIdx.x == 0) {  // scalar sums (double), one block -- first in dispatch order: it is a latency chain
+    if (a.sums_slab && a.sums_out) {
+      __shared__ double part[3][kReduceWaves];
       double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-      for (int s = t; s < a.n_sum_slabs; s += 256) {
-        s0 += a.sums_slab[(size_t)s * 4 + 0];
-        s1 += a.sums_slab[(size_t)s * 4 + 1];
-        s2 += a.sums_slab[(size_t)s * 4 + 2];
+      for (int s = t; s < a.n_sum_slabs; s += kReduceWaves * 64 * 4) {  // 12 loads in flight per thread
+        double v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = s + kReduceWaves * 64 * u;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) v[u][c] = e < a.n_sum_slabs ? a.sums_slab[(size_t)e * 4 + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s0 += v[u][0]; s1 += v[u][1]; s2 += v[u][2]; }
       }
-      part[0][t] = s0; part[1][t] = s1; part[2][t] = s2;
+      // lanes of a wave in a fixed butterfly order, then the sixteen wave sums in order: one barrier instead of ten
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_xor(s0, off, 64);
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+      }
+      if ((t & 63) == 0) { part[0][t >> 6] = s0; part[1][t >> 6] = s1; part[2][t >> 6] = s2; }
       __syncthreads();
-      for (int w = 128; w > 0; w >>= 1) {
-        if (t < w) { part[0][t] += part[0][t + w]; part[1][t] += part[1][t + w]; part[2][t] += part[2][t + w]; }
-        __syncthreads();
+      if (t < 3) {
+        double r = 0.0;
+        for (int w = 0; w < kReduceWaves; ++w) r += part[t][w];
+        part[t][0] = r;
       }
       if (t < 3) a.sums_out[t] += part[t][0];
       if (t == 0) a.sums_out[3] += a.n_rows;
     }
     return;
   }
-  // wave = quarter of the slab range, lane = element: 4 x 16 loads in flight per element, the four partial
-  // sums are combined in a fixed order (deterministic).
-  __shared__ float part[4][64];
+  int seg_id = 0;
+  const int blk = blockIdx.x - 1;
+#pragma unroll
+  for (int g = 1; g < kMaxReduceSegs; ++g)  // (uniform; the whole ascending table is fetched at once, entries past
+    seg_id = blk >= map.blk_begin[g] ? g : seg_id;  //  the last segment hold the block count: never selected)
   const ReduceSeg sg = a.segs[seg_id];
-  const int64_t total = (int64_t)sg.rows * sg.cols;
-  const int sub = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int per = (sg.n_slabs + 3) / 4;
-  const int s_begin = min(sub * per, sg.n_slabs), s_end = min(sg.n_slabs, s_begin + per);
-  // Slabs whose rows are 16-byte aligned (every GEMM slab: ldc and the slab offsets are multiples of 4 floats) are
-  // read as float4: lane = 4 consecutive columns of one row, 1 KB per wave load instead of 256 B.
-  const bool vec = ((sg.src_off | sg.src_ld | sg.slab_stride) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.slab) & 15) == 0;
-  if (vec) {
-    __shared__ float4 part4[4][64];
-    const int qpr = (sg.cols + 3) >> 2;  // float4 per row (the padding columns up to src_ld are readable)
-    const int64_t total4 = (int64_t)sg.rows * qpr;
-    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < total4; e0 += (int64_t)gridDim.x * 64) {
-      const int64_t e = e0 + lane;
-      const bool valid = e < total4;
-      const int i = valid ? (int)(e / qpr) : 0, j = valid ? (int)(e % qpr) * 4 : 0;
-      const float* src = a.slab + sg.src_off + (int64_t)i * sg.src_ld + j;
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (valid) {
-        int s = s_begin;
-        for (; s + 16 <= s_end; s += 16) {
-          float4 v[16];
+  const int sub = t >> 6, lane = t & 63;
+  const int epb = reduce_epb(sg.n_slabs), cpw = 64 / epb;  // elements per block, slab cuts per wave
+  const int n_cuts = kReduceWaves * cpw;
+  const int el = lane % epb, cut = sub * cpw + lane / epb;
+  const int per = (sg.n_slabs + n_cuts - 1) / n_cuts;
+  const int s_begin = min(cut * per, sg.n_slabs), s_end = min(sg.n_slabs, s_begin + per);
+  const int64_t e = (int64_t)(blk - map.blk_begin[seg_id]) * epb + el;
+  // The layer's bias gradient is column `cols` of the slab rows (the GEMM's ones column): it rides along as one more
+  // column and is stored to its own place (a segment of its own read one float per 1 KB row: 64 cache lines a load).
+  const int cols_x = sg.cols + (sg.bias_off1 ? 1 : 0);
+  auto store = [&](int i, int j, float v) {
+    if (j < sg.cols) a.dst[sg.dst_off + (int64_t)i * sg.dst_si + (int64_t)j * sg.dst_sj] = v;
+    else if (j < cols_x) a.dst[sg.bias_off1 - 1 + i] = v;
+  };
+  // the cuts' partial sums are combined in a fixed order (deterministic)
+  if (reduce_seg_vec(sg, a.slab)) {
+    __shared__ float4 part4[kReduceWaves][64];
+    const int qpr = (cols_x + 3) >> 2;  // float4 per row (the padding columns up to src_ld are readable)
+    const bool valid = e < (int64_t)sg.rows * qpr;
+    const int i = valid ? (int)(e / qpr) : 0, j = valid ? (int)(e % qpr) * 4 : 0;
+    const float* src = a.slab + sg.src_off + (int64_t)i * sg.src_ld + j;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+      for (int s = s_begin; s < s_end; s += 8) {
+        float4 v[8];
 #pragma unroll
-          for (int q = 0; q < 16; ++q) v[q] = *reinterpret_cast<const float4*>(src + (int64_t)(s + q) * sg.slab_stride);
+        for (int q = 0; q < 8; ++q)  // (clamped: a branch-free batch of eight loads in flight)
+          v[q] = *reinterpret_cast<const float4*>(src + (int64_t)min(s + q, s_end - 1) * sg.slab_stride);
 #pragma unroll
-          for (int q = 0; q < 16; ++q) { t.x += v[q].x; t.y += v[q].y; t.z += v[q].z; t.w += v[q].w; }
-        }
-        for (; s < s_end; ++s) {
-          const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * sg.slab_stride);
-          t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-        }
+        for (int q = 0; q < 8; ++q)
+          if (s + q < s_end) { acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w; }
       }
-      part4[sub][lane] = t;
-      __syncthreads();
-      if (sub == 0 && valid) {
-        const float4 p0 = part4[0][lane], p1 = part4[1][lane], p2 = part4[2][lane], p3 = part4[3][lane];
-        const float r[4] = {((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
-                            ((p0.w + p1.w) + p2.w) + p3.w};
-        float* d = a.dst + sg.dst_off + (int64_t)i * sg.dst_si + (int64_t)j * sg.dst_sj;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (j + c < sg.cols) d[(int64_t)c * sg.dst_sj] = r[c];
+    }
+    part4[sub][lane] = acc;
+    __syncthreads();
+    if (cut == 0 && valid) {
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int c = 0; c < n_cuts; ++c) {
+        const float4 pw = part4[c / cpw][(c % cpw) * epb + el];
+        r.x += pw.x; r.y += pw.y; r.z += pw.z; r.w += pw.w;
       }
-      __syncthreads();
+      store(i, j, r.x); store(i, j + 1, r.y); store(i, j + 2, r.z); store(i, j + 3, r.w);
     }
     return;
   }
-  for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < total; e0 += (int64_t)gridDim.x * 64) {
-    const int64_t e = e0 + lane;
-    const bool valid = e < total;
-    const int i = valid ? (int)(e / sg.cols) : 0, j = valid ? (int)(e % sg.cols) : 0;
-    const float* src = a.slab + sg.src_off + (int64_t)i * sg.src_ld + j;
-    float t = 0.f;
-    if (valid) {
-      int s = s_begin;
-      for (; s + 16 <= s_end; s += 16) {
-        float v[16];
+  __shared__ float part[kReduceWaves][64];
+  const bool valid = e < (int64_t)sg.rows * cols_x;
+  const int i = valid ? (int)(e / cols_x) : 0, j = valid ? (int)(e % cols_x) : 0;
+  const float* src = a.slab + sg.src_off + (int64_t)i * sg.src_ld + j;
+  float acc = 0.f;
+  if (valid) {
+    for (int s = s_begin; s < s_end; s += 16) {
+      float v[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = src[(int64_t)(s + q) * sg.slab_stride];
+      for (int q = 0; q < 16; ++q) v[q] = src[(int64_t)min(s + q, s_end - 1) * sg.slab_stride];  // (clamped: branch-free batch)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t += v[q];
-      }
-      for (; s < s_end; ++s) t += src[(int64_t)s * sg.slab_stride];
+      for (int q = 0; q < 16; ++q) acc += s + q < s_end ? v[q] : 0.f;
     }
-    part[sub][lane] = t;
-    __syncthreads();
-    if (sub == 0 && valid)
-      a.dst[sg.dst_off + (int64_t)i * sg.dst_si + (int64_t)j * sg.dst_sj] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-    __syncthreads();
+  }
+  part[sub][lane] = acc;
+  __syncthreads();
+  if (cut == 0 && valid) {
+    float r = 0.f;
+    for (int c = 0; c < n_cuts; ++c) r += part[c / cpw][(c % cpw) * epb + el];
+    store(i, j, r);
   }
 }
 
 int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s) {
-  int gx = std::max(1, std::min((max_elems + 63) / 64, 1024));
+  (void)max_elems;
+  ReduceMap map;
+  int blocks = 0;
+  for (int g = 0; g < a.n_segs; ++g) {
+    const ReduceSeg& sg = a.segs[g];
+    const int cols_x = sg.cols + (sg.bias_off1 ? 1 : 0);
+    const int64_t elems = reduce_seg_vec(sg, a.slab) ? (int64_t)sg.rows * ((cols_x + 3) >> 2) : (int64_t)sg.rows * cols_x;
+    const int epb = reduce_epb(sg.n_slabs);
+    map.blk_begin[g] = blocks;
+    blocks += (int)((elems + epb - 1) / epb);
+  }
+  for (int g = a.n_segs; g <= kMaxReduceSegs; ++g) map.blk_begin[g] = blocks;
   ProfScope prof_scope(kProfReduce, s);
-  hipLaunchKernelGGL(k_reduce, dim3(gx, a.n_segs + 1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_reduce, dim3(1 + blocks), dim3(kReduceWaves * 64), 0, s, a, map);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }
