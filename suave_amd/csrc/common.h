@@ -133,8 +133,11 @@ struct Philox {
     uint32_t k0 = key0, k1 = key1;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-      uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-      uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+      // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a mul_hi / mul_lo pair: both are
+      // quarter-rate instructions, and the generators are where the sampling kernels spend their VALU time
+      const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+      uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+      uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
       uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
       c0 = n0; c1 = n1; c2 = n2; c3 = n3;
       k0 += 0x9E3779B9u;

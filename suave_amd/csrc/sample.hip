@@ -10,16 +10,28 @@
 // the reference computes on placeholder batches and throws away
 // (sampling.py:79-100) is not computed at all.
 //
-// Every value that feeds a discrete decision (argmax / threshold) is computed
-// with the individually rounded binary32 operations of detmath.h, in the same
-// order as oracle/sampling_oracle.py, so sampled categories / levels / counts /
-// components are bit-identical to the oracle for identical inputs and noise.
+// Every discrete decision (argmax / threshold) comes out as the individually
+// rounded binary32 operations of detmath.h, in the order of
+// oracle/sampling_oracle.py, would take it, so sampled categories / levels /
+// counts / components are bit-identical to the oracle for identical inputs and
+// noise.  Categorical and ordinal races are first run with the hardware
+// transcendentals and fused dots; only a row whose winner leads by less than a
+// bound on the difference of the two evaluations (kCatMargin / kOrdDp below) is
+// decided again with detmath (about one race in 10^4).  Real and positive VALUES
+// owe the reference 1e-4 and take the hardware path outright; counts stay on
+// detmath (their inverse-CDF walk compares against every partial sum).
+#include <type_traits>
+
 #include "kernels.h"
 #include "detmath.h"
 
 namespace suave {
 
 namespace {
+
+// Decision margins of the two-stage races in k_sample_heads (see there).
+constexpr float kCatMargin = 2e-5f;
+constexpr float kOrdDp = 4e-5f;
 
 __device__ __forceinline__ float philox_u(const Philox& rng, uint32_t a, uint32_t b, uint32_t stream, uint32_t d) {
   return u01(rng(a, b, stream, d).x);
@@ -64,29 +76,40 @@ struct SampleArgs {
   int16_t* out_codes;
   int ld_disc;
   int ldy, ldon, ldoc;  // LDS row strides
+  int head_off, head_len;  // staged weights: the likelihood heads' range of the flat parameter vector (0: not staged)
 };
 
 // STAGED: the 64-row y tile and the outputs go through LDS (coalesced global accesses).  Schemas whose y row
 // does not fit (wide categoricals, BASELINE config #4) run unstaged: lane = row reads y from global memory.
+// A block is kSampleWaves wavefronts on one 64-row tile (lane = row, the waves take the columns in turn): eight
+// rather than four, because the LDS tile admits two blocks per CU and two waves per SIMD left the VALU idle half
+// of the time (54 % of the wave cycles were waits; PMC pass in profiles/).
+constexpr int kSampleWaves = 8;
+constexpr int kSampleThreads = kSampleWaves * 64;
 template <bool STAGED>
-__global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
+__global__ __launch_bounds__(kSampleThreads, STAGED ? 2 : 1) void k_sample_heads(SampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ytile = lds;                                      // [64][ldy]
   float* onum = ytile + 64 * a.ldy;                        // [64][ldon]
   int* ocode = reinterpret_cast<int*>(onum + 64 * a.ldon); // [64][ldoc]
   float* s_s = reinterpret_cast<float*>(ocode + 64 * a.ldoc);  // [64][K] (dense s only)
+  float* w_s = s_s + 64 * a.K;                                 // [head_len] the heads' weights
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = a.K;
   const Philox rng(a.seed);
   const int64_t n_tiles = (a.n + 63) / 64;
+  // Head weights: every dot below walks them with a wave-uniform index.  Out of global memory that is a dependent
+  // load (hundreds of cycles) per multiply; the block keeps them in LDS for all its tiles instead.
+  if (STAGED && a.head_len > 0)
+    for (int i = tid; i < a.head_len; i += kSampleThreads) w_s[i] = a.params[a.head_off + i];
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t r0 = tile * 64;
     const int nrows = (int)min((int64_t)64, a.n - r0);
     if (STAGED) {
       __syncthreads();
       const int nq = a.ldY / 4;
-      for (int idx = tid; idx < nrows * nq; idx += 256) {
+      for (int idx = tid; idx < nrows * nq; idx += kSampleThreads) {
         const int lr = idx / nq, q = idx % nq;
         const float4 v = *reinterpret_cast<const float4*>(a.y + (size_t)(r0 + lr) * a.ldY + q * 4);
         float* dst = ytile + lr * a.ldy + q * 4;
@@ -96,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
         if (q * 4 + 3 < a.Y) dst[3] = v.w;
       }
       if (a.s)
-        for (int idx = tid; idx < nrows * K; idx += 256) s_s[idx] = a.s[(size_t)r0 * K + idx];
+        for (int idx = tid; idx < nrows * K; idx += kSampleThreads) s_s[idx] = a.s[(size_t)r0 * K + idx];
       __syncthreads();
     }
     const bool valid = lane < nrows;
@@ -106,6 +129,17 @@ __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
     const float* yrow = STAGED ? ytile + lane * a.ldy : a.y + (size_t)r * a.ldY;
     const float* srow = STAGED ? s_s + lane * K : (a.s ? a.s + (size_t)r * K : nullptr);
 
+    // the same dot with fused multiply-adds (values, and the first run of a race)
+    auto dotf = [&](const float* w, const float* yb, int yd) {
+      float acc = 0.f;
+      for (int i = 0; i < yd; ++i) acc = fmaf(w[i], yb[i], acc);
+      if (a.s) {
+        for (int j = 0; j < K; ++j) acc = fmaf(w[yd + j], srow[j], acc);
+      } else {
+        acc += w[yd + kc];
+      }
+      return acc;
+    };
     // sequential, individually rounded dot of [y ; s] with [w_y ; w_s]
     auto dot = [&](const float* w, const float* yb, int yd) {
       float acc = 0.f;
@@ -118,11 +152,15 @@ __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
       return acc;
     };
 
-    for (int c = wave; c < a.n_cols; c += 4) {
+    for (int c = wave; c < a.n_cols; c += kSampleWaves) {
       const suave_col_t col = a.cols[c];
       const float* yb = yrow + col.y_off;
       const int yd = col.y_dim;
-      const float* w = a.params + col.w_off;
+      // (wide categorical columns keep their weights behind the staged range: they are read from global memory)
+      // (never form w_s - head_off: an LDS address below the window's start does not survive the cast to a flat pointer)
+      const bool in_lds = STAGED && col.w_off >= a.head_off && col.w_off < a.head_off + a.head_len;
+      const float* w = in_lds ? w_s + (col.w_off - a.head_off) : a.params + col.w_off;
+      const float* w2 = in_lds ? w_s + (max(col.w2_off, a.head_off) - a.head_off) : a.params + max(col.w2_off, 0);
       if (col.type <= SUAVE_TYPE_COUNT) {
         // one Philox block per (row, column): words x, y -> the normal draw, word z -> the uniform draw
         float nrm, uni = 0.f;
@@ -139,17 +177,18 @@ __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
           const float rate = detm::add(detm::softplus(rho), kEps);
           val = poisson_from_noise(rate, uni, nrm);
         } else {
-          const float am = dot(w, yb, yd);
-          const float bv = dot(a.params + col.w2_off, yb, 0);
-          const float v = detm::add(detm::softplus(bv), kEps);
+          // values, not decisions: hardware exp / log / sqrt (within 1e-5 of the oracle; the tests ask for 1e-4)
+          const float am = dotf(w, yb, yd);
+          const float bv = dotf(w2, yb, 0);
+          const float v = softplus_f(bv) + kEps;
           if (col.type == SUAVE_TYPE_REAL) {  // decoder.py:90-91
-            const float sd = detm::sqrt_rn(fmaxf(v, kEps));
-            val = detm::add(detm::mul(detm::add(am, detm::mul(nrm, sd)), col.scale), col.shift);
+            const float sd = sqrtf(fmaxf(v, kEps));
+            val = fmaf(fmaf(nrm, sd, am), col.scale, col.shift);
           } else {  // decoder.py:139
-            const float mean = detm::add(detm::mul(am, col.scale), col.shift);
-            const float vs = detm::mul(v, detm::mul(col.scale, col.scale));
-            const float sd = detm::sqrt_rn(fmaxf(vs, kEps));
-            val = detm::sub(detm::exp(detm::add(mean, detm::mul(nrm, sd))), 1.0f);
+            const float mean = fmaf(am, col.scale, col.shift);
+            const float vs = v * (col.scale * col.scale);
+            const float sd = sqrtf(fmaxf(vs, kEps));
+            val = __expf(fmaf(nrm, sd, mean)) - 1.0f;
           }
         }
         if (STAGED) onum[lane * a.ldon + col.x_index] = val;
@@ -168,30 +207,72 @@ __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
         int best_i = 0;
         if (col.type == SUAVE_TYPE_CAT) {  // Gumbel-max == exponential race on softmax(logits)
           const int ldw = cat_ldw(col, K);
-          float best = detm::sub(0.f, detm::log(draw_e(0)));
-          for (int cl = 1; cl < C; ++cl) {
-            const float L = dot(w + (cl - 1) * ldw, yb, yd);
-            const float sc = detm::sub(L, detm::log(draw_e(cl)));
-            if (sc > best) { best = sc; best_i = cl; }
-          }
-        } else {  // ordinal: race on the clipped cumulative-link probabilities
-          const float mo = dot(a.params + col.w2_off, yb, yd);
-          float thr = 0.f, prev = 0.f, best = -1.0f;
-          for (int cl = 0; cl < C; ++cl) {
-            float p;
-            if (cl < C - 1) {
-              const float part = dot(w + cl * K - 0, yb, 0);
-              thr = detm::add(thr, detm::add(detm::softplus(part), kEps));
-              const float sg = detm::sigmoid(detm::sub(thr, mo));
-              p = detm::sub(sg, prev);
-              prev = sg;
-            } else {
-              p = detm::sub(1.0f, prev);
+          // DET = false: fused dots and v_log_f32.  Against the detmath evaluation a score L - log(e) moves by at most
+          // (y_dim + K + 1) roundings of the dot's partial sums plus 2 ulp of the logarithm: far inside
+          // kCatMargin * (1 + |score|) for the few-term, O(1)..O(100) logits of a head.
+          auto race = [&](auto det, float& lead) {
+            constexpr bool DET = decltype(det)::value;
+            q4 = make_uint4(0u, 0u, 0u, 0u);
+            const float e0 = draw_e(0);
+            float best = DET ? detm::sub(0.f, detm::log(e0)) : -__logf(e0);
+            float second = -INFINITY;
+            int bi = 0;
+            for (int cl = 1; cl < C; ++cl) {
+              const float ecl = draw_e(cl);
+              float sc;
+              if (DET) sc = detm::sub(dot(w + (cl - 1) * ldw, yb, yd), detm::log(ecl));
+              else sc = dotf(w + (cl - 1) * ldw, yb, yd) - __logf(ecl);
+              if (sc > best) { second = best; best = sc; bi = cl; }
+              else second = fmaxf(second, sc);
             }
-            p = fminf(fmaxf(p, kEps), 1.0f);
-            const float sc = detm::dvd(p, draw_e(cl));
-            if (sc > best) { best = sc; best_i = cl; }
-          }
+            lead = (best - second) - kCatMargin * (1.0f + fabsf(best));
+            return bi;
+          };
+          float lead;
+          best_i = race(std::false_type{}, lead);
+          if (!(lead > 0.f)) best_i = race(std::true_type{}, lead);  // too close (or NaN): the reference arithmetic decides
+        } else {  // ordinal: race on the clipped cumulative-link probabilities
+          // DET = false: hardware softplus / sigmoid / reciprocal.  A clipped probability then differs from detmath's by
+          // at most kOrdDp (C <= 32 accumulated softplus errors through sigmoid' <= 1/4, plus the sigmoid's own), so two
+          // scores p / e compare the same way whenever they are further apart than kOrdDp (1/e_a + 1/e_b) plus the
+          // rounding of the quotients.
+          auto race = [&](auto det, float& lead) {
+            constexpr bool DET = decltype(det)::value;
+            q4 = make_uint4(0u, 0u, 0u, 0u);
+            const float mo = DET ? dot(w2, yb, yd) : dotf(w2, yb, yd);
+            float thr = 0.f, prev = 0.f, best = -1.0f, second = -1.0f, ie_max = 0.f;
+            int bi = 0;
+            for (int cl = 0; cl < C; ++cl) {
+              float pcl;
+              if (cl < C - 1) {
+                float sg;
+                if (DET) {
+                  thr = detm::add(thr, detm::add(detm::softplus(dot(w + cl * K, yb, 0)), kEps));
+                  sg = detm::sigmoid(detm::sub(thr, mo));
+                  pcl = detm::sub(sg, prev);
+                } else {
+                  thr += softplus_f(dotf(w + cl * K, yb, 0)) + kEps;
+                  sg = sigmoid_f(thr - mo);
+                  pcl = sg - prev;
+                }
+                prev = sg;
+              } else {
+                pcl = DET ? detm::sub(1.0f, prev) : 1.0f - prev;
+              }
+              pcl = fminf(fmaxf(pcl, kEps), 1.0f);
+              const float ecl = draw_e(cl);
+              float sc;
+              if (DET) sc = detm::dvd(pcl, ecl);
+              else { const float ie = __frcp_rn(ecl); sc = pcl * ie; ie_max = fmaxf(ie_max, ie); }
+              if (sc > best) { second = best; best = sc; bi = cl; }
+              else second = fmaxf(second, sc);
+            }
+            lead = (best - second) - (2.0f * kOrdDp * ie_max + 4e-6f * best);
+            return bi;
+          };
+          float lead;
+          best_i = race(std::false_type{}, lead);
+          if (!(lead > 0.f)) best_i = race(std::true_type{}, lead);
         }
         if (STAGED) ocode[lane * a.ldoc + col.x_index] = best_i;
         else if (valid) a.out_codes[(size_t)r * a.ld_disc + col.x_index] = (int16_t)best_i;
@@ -199,11 +280,11 @@ __global__ __launch_bounds__(256, 2) void k_sample_heads(SampleArgs a) {
     }
     if (STAGED) {
       __syncthreads();
-      for (int idx = tid; idx < nrows * a.n_num; idx += 256) {
+      for (int idx = tid; idx < nrows * a.n_num; idx += kSampleThreads) {
         const int lr = idx / a.n_num, j = idx % a.n_num;
         a.out_num[(size_t)(r0 + lr) * a.ld_num + j] = onum[lr * a.ldon + j];
       }
-      for (int idx = tid; idx < nrows * a.n_disc; idx += 256) {
+      for (int idx = tid; idx < nrows * a.n_disc; idx += kSampleThreads) {
         const int lr = idx / a.n_disc, j = idx % a.n_disc;
         a.out_codes[(size_t)(r0 + lr) * a.ld_disc + j] = (int16_t)ocode[lr * a.ldoc + j];
       }
@@ -411,6 +492,72 @@ __global__ __launch_bounds__(256) void k_posterior_draws(PostDrawArgs a) {
   }
 }
 
+// The same draws (same generator keys, same arithmetic: bit-identical outputs) with eight lanes per table row, for
+// D % 4 == 0 and K <= 32.  The one-thread-per-draw kernel above read its row of enc_out at a 2.6 KB lane stride and
+// wrote z as 64 scattered 4-byte stores per instruction (460 us per 524 288 draws, 20x its HBM time).  Here a group
+// of eight lanes owns ROW b for all L draws: its logits stay in registers, lane q of the group draws the Philox
+// block of components 4q .. 4q + 3 and the group's argmax is three shuffles; every lane then writes one float4 of z,
+// so a wave stores 1 KB of eight consecutive rows per draw, and the row's mu / logvar are re-read from L1 / L2 only.
+__global__ __launch_bounds__(256) void k_posterior_draws8(PostDrawArgs a) {
+  const Philox rng(a.seed);
+  const int K = a.K, D = a.D, dq = a.D >> 2;
+  const int E = K + 2 * K * D;
+  const int l8 = threadIdx.x & 7;
+  for (int64_t b = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); b < a.B; b += (int64_t)gridDim.x * 32) {
+    const float* row = a.enc_out + (size_t)b * E;
+    const bool has_k = 4 * l8 < K;
+    float lg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) lg[u] = 4 * l8 + u < K ? row[4 * l8 + u] : 0.f;
+    for (int l = 0; l < a.L; ++l) {
+      const int64_t v = (int64_t)l * a.B + b;
+      const uint64_t gid = (uint64_t)(a.row_offset + v);
+      const uint32_t glo = (uint32_t)gid, ghi = (uint32_t)(gid >> 32);
+      float best = -INFINITY;
+      int kb = has_k ? 4 * l8 : 0x7FFFFFFF;
+      if (has_k) {
+        uint4 q4 = make_uint4(0u, 0u, 0u, 0u);
+        if (!a.e) q4 = rng(glo, (uint32_t)l8, kStreamCondExp, ghi);
+        const uint32_t word[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = 4 * l8 + u;
+          if (j < K) {
+            const float e = a.e ? a.e[(size_t)v * K + j] : -__logf(u01(word[u]));
+            const float sc = detm::sub(lg[u], detm::log(e));
+            if (sc > best) { best = sc; kb = j; }
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1) {  // first maximum wins, as in the sequential scan
+        const float ob = __shfl_xor(best, off, 64);
+        const int ok = __shfl_xor(kb, off, 64);
+        if (ob > best || (ob == best && ok < kb)) { best = ob; kb = ok; }
+      }
+      if (l8 == 0) a.comp[v] = kb;
+      const float* mu = row + K + kb * D;
+      const float* lv = mu + K * D;
+      for (int q = l8; q < dq; q += 8) {
+        float ev[4];
+        if (a.eps) {
+          const float4 e4 = *reinterpret_cast<const float4*>(a.eps + (size_t)v * D + 4 * q);
+          ev[0] = e4.x; ev[1] = e4.y; ev[2] = e4.z; ev[3] = e4.w;
+        } else {
+          const uint4 w0 = rng(glo, (uint32_t)(2 * q), kStreamPriorEps, ghi);
+          const uint4 w1 = rng(glo, (uint32_t)(2 * q + 1), kStreamPriorEps, ghi);
+          const float2 n0 = normal2(w0.x, w0.y), n1 = normal2(w1.x, w1.y);
+          ev[0] = n0.x; ev[1] = n0.y; ev[2] = n1.x; ev[3] = n1.y;
+        }
+        float zz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) zz[u] = mu[4 * q + u] + ev[u] * __expf(0.5f * lv[4 * q + u]);
+        *reinterpret_cast<float4*>(a.z + (size_t)v * D + 4 * q) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+      }
+    }
+  }
+}
+
 // Parameters of ONE likelihood head (the ``params`` dict of the reference heads, decoder.py:89,
 // 134-138,173,215,259) for every row: real -> mean, var; pos -> mean_log, var_log, mean;
 // count -> rate; cat -> probs[C]; ordinal -> probs[C].
@@ -501,8 +648,12 @@ int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const f
   a.noise_normal = nn; a.noise_uniform = nu; a.noise_exp = ne; a.seed = seed; a.row_offset = row_offset;
   a.out_num = out_num; a.ld_num = ld_num; a.out_codes = out_codes; a.ld_disc = ld_disc;
   a.ldy = p->ldY | 1; a.ldon = std::max(m.n_num, 1) | 1; a.ldoc = std::max(m.n_disc, 1) | 1;
-  const size_t lds = sizeof(float) * ((size_t)64 * a.ldy + 64 * a.ldon + 64 * a.ldoc + 64 * m.n_components);
+  size_t lds = sizeof(float) * ((size_t)64 * a.ldy + 64 * a.ldon + 64 * a.ldoc + 64 * m.n_components);
   const bool staged = lds <= 64 * 1024;
+  if (staged && lds + sizeof(float) * m.head_len <= 78 * 1024) {  // two blocks per CU keep their 160 KB
+    a.head_off = m.head_off; a.head_len = m.head_len;
+    lds += sizeof(float) * m.head_len;
+  }
   static thread_local size_t lds_set = 0;
   if (staged && lds > 48 * 1024 && lds > lds_set) {
     SUAVE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sample_heads<true>),
@@ -513,10 +664,10 @@ int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const f
   ProfScope prof_scope(kProfSample, st);
   if (staged) {
     const int grid = (int)std::min<int64_t>(tiles, 2 * (int64_t)p->n_cu);
-    hipLaunchKernelGGL(k_sample_heads<true>, dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k_sample_heads<true>, dim3(grid), dim3(kSampleThreads), lds, st, a);
   } else {
     const int grid = (int)std::min<int64_t>(tiles, 8 * (int64_t)p->n_cu);
-    hipLaunchKernelGGL(k_sample_heads<false>, dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_sample_heads<false>, dim3(grid), dim3(kSampleThreads), 0, st, a);
   }
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
@@ -579,8 +730,13 @@ extern "C" int suave_posterior_draws(const suave_plan* p, const float* enc_out, 
   a.enc_out = enc_out; a.e = e; a.eps = eps; a.seed = seed; a.row_offset = row_offset; a.B = (int)n_rows; a.L = n_draws;
   a.K = p->model.n_components; a.D = p->model.latent_dim; a.z = z; a.comp = component;
   const int64_t total = n_rows * n_draws;
-  hipLaunchKernelGGL(k_posterior_draws, dim3((int)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), a);
+  const bool aligned = (reinterpret_cast<uintptr_t>(z) & 15) == 0 && (!eps || (reinterpret_cast<uintptr_t>(eps) & 15) == 0);
+  if (a.D % 4 == 0 && a.K <= 32 && aligned)
+    hipLaunchKernelGGL(k_posterior_draws8, dim3((int)std::min<int64_t>((n_rows + 31) / 32, 8192)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(k_posterior_draws, dim3((int)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -199,3 +199,31 @@ def test_overlap_entry_point_matches_and_its_event_marks_a_final_decoder_bucket(
         torch.cuda.synchronize()
         assert torch.equal(eng.grads, ref)
         assert torch.equal(early, ref[lo:hi])
+
+
+def test_posterior_draws_lane_group_kernel_equals_the_scalar_kernel(s64):
+    """suave_posterior_draws has two kernels with the same generator keys and arithmetic: eight lanes per row
+    (D % 4 == 0, K <= 32, 16-byte aligned z) and one thread per draw.  Same bits out of both (the scalar one is
+    reached here by handing the entry point a z buffer that is only 4-byte aligned), ragged row count included."""
+
+    import ctypes as C
+
+    import torch
+
+    from suave_amd import lib as slib
+
+    eng, table, layout = s64
+    B, L, D = 1003, 7, layout.latent_dim
+    enc = eng.encode(table, 5000, B)["enc_out"]
+    z_a, k_a = eng.posterior_draws(enc, L, seed=21, row_offset=12345)
+    buf = torch.empty(L * B * D + 1, dtype=torch.float32, device=eng.device)
+    z_b = buf[1:]
+    k_b = torch.empty(L * B, dtype=torch.int32, device=eng.device)
+    assert z_b.data_ptr() % 16 == 4
+    rc = eng.lib.suave_posterior_draws(eng._plan, enc.data_ptr(), B, L, None, None, 21, 12345, eng._stream(), z_b.data_ptr(),
+                                       k_b.data_ptr())
+    slib.check(rc, "suave_posterior_draws")
+    torch.cuda.synchronize()
+    assert torch.equal(k_a, k_b)
+    assert torch.equal(z_a.reshape(-1), z_b)
+    assert int(k_a.min()) >= 0 and int(k_a.max()) < layout.n_components
