@@ -152,11 +152,12 @@ def gemm_flops_executed_per_row(layout):
     return gemm_flops_per_row(layout) - 6 * skipped
 
 
-def cpu_baseline(spec, stats, dropout, budget_s=15.0, batch=4096):
+def cpu_baseline(spec, stats, dropout, budget_s=15.0, batch=4096, latent=None, hidden=None, label="S64"):
     """The CPU oracle (numpy restatement of the reference path, oracle/) timed on this host's cores."""
 
     from oracle import suave_oracle as orc
 
+    LATENT, HIDDEN = (latent or globals()["LATENT"]), tuple(hidden or globals()["HIDDEN"])
     cols = [orc.Column(n, s["type"], s.get("n_classes"), None, stats[n]) for n, s in spec.items()]
     om = orc.OracleModel(cols, n_components=K_COMP, latent_dim=LATENT, hidden=HIDDEN, dropout=dropout)
     P = om.init_params(seed=0)
@@ -189,10 +190,11 @@ def cpu_baseline(spec, stats, dropout, budget_s=15.0, batch=4096):
         cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
     med = float(np.median(times[1:]))
     return {"value": batch / med, "unit": "rows/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times) - 1} ELBO steps (fwd+bwd+Adam) of the numpy oracle on {batch} S64 rows, median"}
+            "sample": f"{len(times) - 1} ELBO steps (fwd+bwd+Adam) of the numpy oracle on {batch} {label} rows, median"}
 
 
-def generation_rates(eng, table, rows, gen_rows, device, rank, world, dist, fence, prof):
+def generation_rates(eng, table, rows, gen_rows, device, rank, world, dist, fence, prof, chunk=1 << 18, mc_chunk=1 << 14,
+                     n_imp_max=1_000_000):
     """sample() / impute() rows/sec (BASELINE.json config #5 on this rank's shard): device-side throughput with the
     outputs left in HBM in the packed columnar layout (host DataFrame assembly is not part of the kernels' rate).
     Rows are sharded over ranks with no collective; every generator is keyed by the global row index."""
@@ -202,7 +204,6 @@ def generation_rates(eng, table, rows, gen_rows, device, rank, world, dist, fenc
     from suave_amd import lib as slib
 
     K, D = eng.layout.n_components, eng.layout.latent_dim
-    chunk = 1 << 18
     # training-posterior cache of this rank's table (model.py:1669-1741), labels Bernoulli(0.3)
     n_cache = min(rows, 1_000_000)
     probs = torch.empty((n_cache, K), device=device)
@@ -224,8 +225,11 @@ def generation_rates(eng, table, rows, gen_rows, device, rank, world, dist, fenc
     res = {}
 
     def timed(fn, n_rows_done, name):
+        t_w = time.perf_counter()
         fn()  # warm-up pass (allocator, code objects)
         fence()
+        if rank == 0:
+            print(f"[bench] {name}: warm-up pass {time.perf_counter() - t_w:.2f} s", file=sys.stderr, flush=True)
         if prof:
             slib.load().suave_profile_enable(1)
         t0 = time.perf_counter()
@@ -263,7 +267,7 @@ def generation_rates(eng, table, rows, gen_rows, device, rank, world, dist, fenc
         gbs = bytes_row * gen_rows / (ms[6] * 1e-3) / 1e9
         res["roofline_sample_heads"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_row": bytes_row}
-    n_imp = min(rows, 1_000_000)
+    n_imp = min(rows, n_imp_max)
 
     def run_impute():  # reference-exact single pass at the posterior-mean latent, hard assignment (model.py:3627-3651)
         for s0 in range(0, n_imp, chunk):
@@ -274,7 +278,7 @@ def generation_rates(eng, table, rows, gen_rows, device, rank, world, dist, fenc
             eng.decode_sample(z, component=comp, seed=9, row_offset=rank * n_imp + s0)
 
     timed(run_impute, n_imp, "impute_single_pass")
-    Ldraws, mc_chunk = 32, 1 << 14
+    Ldraws = 32
 
     def run_impute_mc():  # posterior-predictive MC, 32 draws per row, every cell decoded (model.py:3304-3421 generalised)
         for s0 in range(0, n_imp, mc_chunk):
@@ -411,8 +415,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     sums = eng.sums.cpu().numpy()
-    gen = (generation_rates(eng, table, rows, args.gen_rows, device, rank, world, dist, fence, prof)
-           if args.gen_rows > 0 and not wide else None)
+    if rank == 0:
+        print(f"[bench] training: {1e3 * elapsed / max(args.steps, 1):.4f} ms/step", file=sys.stderr, flush=True)
+    gen = None
+    if args.gen_rows > 0 and not wide:
+        gen = generation_rates(eng, table, rows, args.gen_rows, device, rank, world, dist, fence, prof)
+    elif args.gen_rows > 0:  # W1024: y_full is 68 KB a row -- smaller chunks, 1M generated rows, the table's rows imputed
+        gen = generation_rates(eng, table, rows, min(args.gen_rows, 1 << 20), device, rank, world, dist, fence, prof,
+                               chunk=1 << 16, mc_chunk=1 << 11, n_imp_max=1 << 17)
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -450,6 +460,12 @@ def main():
                                 "algorithmic_flops_per_launch": gemm_flops / cnt[0],
                                 "executed_tflops": executed,
                                 "bf16_pipe_frac": 6.0 * executed / PEAK_BF16_MFMA_TFLOPS}
+            # the same launches priced on what the matrix pipe executes: every fp32 product is six bf16 plane products,
+            # so the pipe's ceiling for this arithmetic is the dense bf16 peak / 6 -- the figure to read as "how much of
+            # the machine", next to the algorithmic fp32 line above (which counts skipped head FLOPs as done)
+            line["roofline_executed"] = {"bound": "mfma", "achieved": executed, "peak": PEAK_BF16_MFMA_TFLOPS / 6.0,
+                                         "unit": "TFLOP/s", "frac": executed / (PEAK_BF16_MFMA_TFLOPS / 6.0),
+                                         "kernel": "same GEMM launches; executed fp32 FLOPs against dense bf16 peak / 6"}
             line["kernel_ms_per_step"] = {PROF_CLASSES[i]: ms[i] / steps for i in range(8) if cnt[i] > 0}
             line["kernel_timing"] = ("HIP events around every launch, on the launch stream, " +
                                      ("inside the timed region" if args.profile_timed else
@@ -464,16 +480,20 @@ def main():
                                                   "traffic": None}
         if gen is not None:
             line["generation"] = gen
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if "roofline" in line and os.path.exists(pmc) and not wide and B == 65536:  # HBM bytes per launch from the committed rocprofv3 --pmc passes
+        pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in
+                                (("r02_pmc_traffic_w1024.json",) if wide else ("r02_pmc_traffic.json", "r01_pmc_traffic.json")))
+                    if os.path.exists(f)), "")
+        if "roofline" in line and pmc and B == (32768 if wide else 65536):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
             with open(pmc) as fh:
                 t = json.load(fh)
             line["roofline"]["traffic"] = t.get("gemm", {}).get("hbm_bytes_per_launch")
             line["roofline"]["traffic_source"] = t.get("source")
             if "roofline_likelihood_kl" in line:
                 line["roofline_likelihood_kl"]["traffic"] = t.get("likelihood_kl", {}).get("hbm_bytes_per_launch")
-        if world == 1 and not args.no_cpu_baseline and not wide:
-            line["cpu_baseline"] = cpu_baseline(spec, stats, args.dropout)
+        if world == 1 and not args.no_cpu_baseline:
+            print("[bench] cpu baseline (numpy oracle) ...", file=sys.stderr, flush=True)
+            line["cpu_baseline"] = (cpu_baseline(spec, stats, args.dropout, batch=128, latent=latent, hidden=hidden, label="W1024")
+                                    if wide else cpu_baseline(spec, stats, args.dropout))
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -1428,6 +1428,7 @@ struct DecodeScratch {
   float* z;
   float* hd[SUAVE_MAX_HIDDEN];
   float* y;
+  float* wideL;              // [rows, ldL] logits of the wide categorical columns (null: the schema has none)
   unsigned char* chain_img;  // weight images of the fused decoder chain (null: per-layer path)
 };
 
@@ -1443,6 +1444,7 @@ size_t carve_decode(const suave_plan* p, int64_t rows, void* base, DecodeScratch
     for (int i = 0; i < p->model.n_hidden; ++i) d->hd[i] = c.take<float>(R * p->ldH[i]);
   }
   d->y = c.take<float>(R * p->ldY);
+  d->wideL = p->wide_host.empty() ? nullptr : c.take<float>(R * p->ldL);
   return (c.off + 255) & ~size_t(255);
 }
 
@@ -1476,8 +1478,19 @@ int decode_sample_impl(const suave_plan* p, const float* params, const float* z,
   if (y_full_out)
     SUAVE_CHECK_HIP(hipMemcpy2DAsync(y_full_out, sizeof(float) * m.y_rows, w.y, sizeof(float) * p->ldY,
                                      sizeof(float) * m.y_rows, B, hipMemcpyDeviceToDevice, st));
+  if (w.wideL != nullptr) {  // wide categorical heads: assignment slots + logits GEMM, as in the training forward
+    WideRowArgs a{};
+    a.wide = p->wide_dev; a.n_wide = (int)p->wide_host.size(); a.n_rows = B; a.vdiv = 1; a.K = m.n_components; a.ldK = p->ldK;
+    a.y = w.y; a.ldY = p->ldY; a.L = w.wideL; a.ldL = p->ldL; a.kidx = s_dense ? nullptr : component; a.s_dense = s_dense;
+    if (int rc = launch_wide_fill(a, st)) return rc;
+    WideGemmArgs g{};
+    g.cols = p->wide_dev; g.cum = p->wide_cum_dev[0]; g.n_wide = a.n_wide; g.cum_total = p->wide_cum_total[0];
+    g.params = params; g.y = w.y; g.ldY = p->ldY; g.L = w.wideL; g.ldL = p->ldL; g.rows = B; g.K = m.n_components;
+    g.splits = 1; g.slab_stride = p->wide_len; g.wide_w0 = p->wide_w0;
+    if (int rc = launch_gemm_wide(g, 0, st)) return rc;
+  }
   return launch_sample_heads(p, p->cls_off_dev, params, w.y, s_dense, component, B, noise_normal, noise_uniform,
-                             noise_exp, seed, row_offset, out_num, ld_num, out_codes, ld_disc, st);
+                             noise_exp, seed, row_offset, out_num, ld_num, out_codes, ld_disc, st, w.wideL);
 }
 
 int check_decode_args(const suave_plan* p, const float* params, const float* z, const float* s_dense,

@@ -215,7 +215,7 @@ int launch_posterior_stats(const float* encout, int ldE, int K, int D, int n_row
 int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const float* params, const float* y,
                         const float* s, const int32_t* comp, int64_t n, const float* nn, const float* nu,
                         const float* ne, uint64_t seed, int64_t row_offset, float* out_num, int ld_num,
-                        int16_t* out_codes, int ld_disc, hipStream_t st);
+                        int16_t* out_codes, int ld_disc, hipStream_t st, const float* wide_logits = nullptr);
 int launch_head_params(const suave_plan* p, int col_index, const float* params, const float* y, const float* s,
                        const int32_t* comp, int64_t n, float* out, int width, hipStream_t st);
 int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s);

@@ -77,6 +77,7 @@ struct SampleArgs {
   int ld_disc;
   int ldy, ldon, ldoc;  // LDS row strides
   int head_off, head_len;  // staged weights: the likelihood heads' range of the flat parameter vector (0: not staged)
+  int skip_wide;           // the wide categorical columns are drawn by k_wide_sample from GEMM logits
 };
 
 // STAGED: the 64-row y tile and the outputs go through LDS (coalesced global accesses).  Schemas whose y row
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(kSampleThreads, STAGED ? 2 : 1) void k_sample_heads
 
     for (int c = wave; c < a.n_cols; c += kSampleWaves) {
       const suave_col_t col = a.cols[c];
+      if (a.skip_wide && col_is_wide(col)) continue;
       const float* yb = yrow + col.y_off;
       const int yd = col.y_dim;
       // (wide categorical columns keep their weights behind the staged range: they are read from global memory)
@@ -288,6 +290,122 @@ __global__ __launch_bounds__(kSampleThreads, STAGED ? 2 : 1) void k_sample_heads
         const int lr = idx / a.n_disc, j = idx % a.n_disc;
         a.out_codes[(size_t)(r0 + lr) * a.ld_disc + j] = (int16_t)ocode[lr * a.ldoc + j];
       }
+    }
+  }
+}
+
+// Wide categorical columns (32 .. 32 767 classes) of the decode: the race over a column's classes with the LOGITS
+// ALREADY COMPUTED by the MFMA GEMM of the wide heads (gemm_wide_kernel, the training step's forward).  One wavefront
+// per row walks the wide columns; lane q owns classes 4q .. 4q + 3 (+ 256 ...): the Philox block of those four
+// classes, their scores L - log(e), then two wave reductions give the winner (first maximum, as the sequential scan)
+// and the runner-up.  The GEMM's logits differ from the reference's individually rounded dot by summation order only
+// (measured 4e-7 of the largest |logit| at 266 terms), so a lead above kWideMargin (1 + |score|) is decided; below it
+// the wave evaluates the column again with detmath dots straight from [y ; s] and the weights -- the arithmetic of
+// the narrow-column kernel and of oracle/sampling_oracle.py -- about one (row, column) in 10^4.
+// (The lane = row kernel it replaces for these columns spent 2.5 M scalar multiply-adds per row of BASELINE config
+// #4 on uncoalesced operands: 18 us a row.)
+constexpr float kWideMargin = 5e-5f;
+struct WideSampleArgs {
+  const WideCol* wide;
+  int n_wide;
+  const suave_col_t* cols;
+  const int32_t* cls_off;
+  const float* params;
+  const float* y;   // [n, ldY] slots [y ; s] filled (k_wide_fill)
+  int ldY;
+  const float* L;   // [n, ldL] logits of classes 1 .. C-1
+  int ldL;
+  const float* s;        // dense assignments or null
+  const int32_t* comp;   // component per row (s == null)
+  int K;
+  const float* noise_exp;
+  int total_classes;
+  uint64_t seed;
+  int64_t row_offset, n;
+  int16_t* out_codes;
+  int ld_disc;
+};
+
+__global__ __launch_bounds__(256) void k_wide_sample(WideSampleArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const Philox rng(a.seed);
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < a.n; r += (int64_t)gridDim.x * 4) {
+    const uint64_t gid = (uint64_t)(a.row_offset + r);
+    const uint32_t rid = (uint32_t)gid, rid_hi = (uint32_t)(gid >> 32);
+    const int kc = a.s ? 0 : a.comp[r];
+    for (int c = 0; c < a.n_wide; ++c) {
+      const WideCol wc = a.wide[c];
+      const int C = wc.C;
+      const int coff = a.cls_off[wc.col];
+      const float* Lc = a.L + (size_t)r * a.ldL + wc.l_off;
+      auto draw4 = [&](int c0, float (&e)[4]) {  // the exponential draws of classes c0 .. c0 + 3 (generator keys of k_sample_heads)
+        uint4 q4 = make_uint4(0u, 0u, 0u, 0u);
+        if (!a.noise_exp) q4 = rng(rid, ((uint32_t)wc.col << 13) | (uint32_t)(c0 >> 2), kStreamSampleExp, rid_hi);
+        const uint32_t word[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          e[u] = a.noise_exp ? (c0 + u < C ? a.noise_exp[(size_t)r * a.total_classes + coff + c0 + u] : 1.0f) : -__logf(u01(word[u]));
+      };
+      auto wave_argmax = [&](float& b, int& i) {  // first maximum wins
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const float ob = __shfl_xor(b, off, 64);
+          const int oi = __shfl_xor(i, off, 64);
+          if (ob > b || (ob == b && oi < i)) { b = ob; i = oi; }
+        }
+      };
+      float best = -INFINITY, second = -INFINITY;
+      int bi = 0x7FFFFFFF;
+      for (int c0 = 4 * lane; c0 < C; c0 += 256) {
+        float e[4];
+        draw4(c0, e);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int cl = c0 + u;
+          if (cl < C) {
+            const float sc = (cl == 0 ? 0.f : Lc[cl - 1]) - __logf(e[u]);
+            if (sc > best) { second = best; best = sc; bi = cl; }
+            else second = fmaxf(second, sc);
+          }
+        }
+      }
+      float wb = best;
+      int wi = bi;
+      wave_argmax(wb, wi);
+      float runner = bi == wi ? second : best;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) runner = fmaxf(runner, __shfl_xor(runner, off, 64));
+      if (!((wb - runner) - kWideMargin * (1.0f + fabsf(wb)) > 0.f)) {  // (uniform) too close: the reference arithmetic decides
+        const float* yb = a.y + (size_t)r * a.ldY + wc.y_off;
+        const float* srow = a.s ? a.s + (size_t)r * a.K : nullptr;
+        best = -INFINITY;
+        bi = 0x7FFFFFFF;
+        for (int c0 = 4 * lane; c0 < C; c0 += 256) {
+          float e[4];
+          draw4(c0, e);
+#pragma unroll 1
+          for (int u = 0; u < 4; ++u) {
+            const int cl = c0 + u;
+            if (cl >= C) break;
+            float acc = 0.f;
+            if (cl > 0) {  // sequential, individually rounded dot of [y ; s] with the class's weight row
+              const float* w = a.params + wc.w_off + (size_t)(cl - 1) * wc.ldw;
+              for (int i = 0; i < wc.yd; ++i) acc = detm::add(acc, detm::mul(w[i], yb[i]));
+              if (srow) {
+                for (int j = 0; j < a.K; ++j) acc = detm::add(acc, detm::mul(w[wc.yd + j], srow[j]));
+              } else {
+                acc = detm::add(acc, w[wc.yd + kc]);
+              }
+            }
+            const float sc = detm::sub(acc, detm::log(e[u]));
+            if (sc > best) { best = sc; bi = cl; }
+          }
+        }
+        wb = best;
+        wi = bi;
+        wave_argmax(wb, wi);
+      }
+      if (lane == 0) a.out_codes[(size_t)r * a.ld_disc + a.cols[wc.col].x_index] = (int16_t)wi;
     }
   }
 }
@@ -638,7 +756,7 @@ int launch_head_params(const suave_plan* p, int col_index, const float* params, 
 int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const float* params, const float* y,
                         const float* s, const int32_t* comp, int64_t n, const float* nn, const float* nu,
                         const float* ne, uint64_t seed, int64_t row_offset, float* out_num, int ld_num,
-                        int16_t* out_codes, int ld_disc, hipStream_t st) {
+                        int16_t* out_codes, int ld_disc, hipStream_t st, const float* wide_logits) {
   if (n <= 0) return 0;
   const suave_model_t& m = p->model;
   SampleArgs a{};
@@ -662,6 +780,9 @@ int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const f
   }
   const int64_t tiles = (n + 63) / 64;
   ProfScope prof_scope(kProfSample, st);
+  const int n_wide = (int)p->wide_host.size();
+  const bool wide_race = wide_logits != nullptr && n_wide > 0;
+  if (wide_race) a.skip_wide = 1;
   if (staged) {
     const int grid = (int)std::min<int64_t>(tiles, 2 * (int64_t)p->n_cu);
     hipLaunchKernelGGL(k_sample_heads<true>, dim3(grid), dim3(kSampleThreads), lds, st, a);
@@ -670,6 +791,16 @@ int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const f
     hipLaunchKernelGGL(k_sample_heads<false>, dim3(grid), dim3(kSampleThreads), 0, st, a);
   }
   SUAVE_CHECK_HIP(hipGetLastError());
+  if (wide_race) {  // the wide categorical columns: race on the GEMM's logits.  AFTER the row kernel: its staged variant
+    // writes every code column of a tile from LDS, the skipped ones included
+    WideSampleArgs wa{};
+    wa.wide = p->wide_dev; wa.n_wide = n_wide; wa.cols = p->cols_dev; wa.cls_off = cls_off_dev; wa.params = params;
+    wa.y = y; wa.ldY = p->ldY; wa.L = wide_logits; wa.ldL = p->ldL; wa.s = s; wa.comp = comp; wa.K = m.n_components;
+    wa.noise_exp = ne; wa.total_classes = p->total_classes; wa.seed = seed; wa.row_offset = row_offset; wa.n = n;
+    wa.out_codes = out_codes; wa.ld_disc = ld_disc;
+    hipLaunchKernelGGL(k_wide_sample, dim3((int)std::min<int64_t>((n + 3) / 4, 16 * (int64_t)p->n_cu)), dim3(256), 0, st, wa);
+    SUAVE_CHECK_HIP(hipGetLastError());
+  }
   return 0;
 }
 
