@@ -150,6 +150,12 @@ typedef struct suave_elbo_out_t {
   int32_t* component;    /* [B] selected component (supervised) */
   float* enc_out;        /* [B, K + 2*K*D]: component_logits | component_mu | component_logvar (clamped) */
   double* sums;          /* [4]: sum recon, sum cat_kl, sum gauss_kl, n_rows -- accumulated (+=) */
+  /* Per-column terms of the decoder output dict (decoder.py:348-379: "log_px" / "log_px_missing" of every head):
+   * [B, n_cols] row-major, schema column order.  log_px[b,c] is the column's log-likelihood where the cell is
+   * observed and 0 where it is masked; log_px_missing the complement (the likelihood of the masked cell's
+   * placeholder value, 0 where observed).  reconstruction[b] == sum_c log_px[b,c].  Supervised branch only. */
+  float* log_px;
+  float* log_px_missing;
 } suave_elbo_out_t;
 
 typedef struct suave_plan suave_plan; /* opaque */
@@ -202,6 +208,14 @@ int suave_elbo_backward_overlap(const suave_plan* plan, const float* params, con
                                 int64_t global_rows, void* workspace, size_t workspace_bytes, void* stream,
                                 const suave_elbo_out_t* out, float* grads, const float* dlatent,
                                 void* decoder_ready_event);
+
+/* Decoder.forward's per-column log-likelihoods at a GIVEN latent (decoder.py:333-379 as called by the reference's
+ * decode-side code and tests): y_full = trunk(z), then every head scores the batch's cells with the row's
+ * component as the assignment one-hot.  log_px / log_px_missing: [n, n_cols], laid out as the fields of that name in the ELBO output struct (either may
+ * be NULL).  batch->n_rows rows; z [n, D]; component [n]. */
+int suave_decode_log_px(const suave_plan* plan, const float* params, const float* z, const int32_t* component,
+                        const suave_batch_t* batch, void* workspace, size_t workspace_bytes, void* stream,
+                        float* log_px, float* log_px_missing);
 
 /* torch.optim.Adam step (defaults betas=(0.9,0.999), eps=1e-8, no weight decay;
  * model.py:1443) on the flat buffers.  group_begin[g]..group_begin[g+1] is the

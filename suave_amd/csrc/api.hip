@@ -106,6 +106,7 @@ struct Workspace {
   float *recon_part, *ds_part, *catkl, *gausskl, *gkl_logit, *gkl_mu, *gkl_lv, *prior_terms, *recon;
   float* onehot;
   int32_t* cells;  // [rows, n_cols] packed cells of the batch rows, mask folded in
+  float *log_px = nullptr, *log_px_missing = nullptr;  // caller's per-column outputs of this call (not carved)
   // selected-component encoder head (supervised branch)
   float *sel, *dsel, *gslab;
   int32_t *perm, *lrank, *blk_cnt, *blk_base, *chunk_comp, *chunk_begin;
@@ -483,6 +484,7 @@ WideRowArgs wide_row_args(const suave_plan* p, const Workspace& w, int rows) {
   a.wide = p->wide_dev; a.n_wide = (int)p->wide_host.size(); a.n_rows = rows; a.vdiv = 1;
   a.K = p->model.n_components; a.ldK = p->ldK; a.y = w.y; a.ldY = p->ldY; a.L = w.wideL; a.ldL = p->ldL;
   a.cells = w.cells; a.n_cols = p->model.n_cols;
+  a.log_px = w.log_px; a.log_px_missing = w.log_px_missing;
   return a;
 }
 
@@ -802,6 +804,9 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     if (ready_event) SUAVE_CHECK_HIP(hipEventRecord(ready_event, s));
     return 0;
   }
+  SUAVE_REQUIRE(m.behaviour == 0 || out == nullptr || (out->log_px == nullptr && out->log_px_missing == nullptr),
+                "per-column log_px / log_px_missing are outputs of the supervised branch (the unsupervised one scores "
+                "every column once per component)");
   if (m.behaviour == 1) {
     if (int rc = elbo_unsup_impl(p, params, batch, noise, beta_scale, tau, training, global_rows, workspace, workspace_bytes,
                                  s, out, grads))
@@ -818,6 +823,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   Workspace w;
   carve(p, B, workspace, &w);
   SUAVE_REQUIRE(workspace_bytes >= w.total_bytes, "workspace too small (see suave_workspace_bytes)");
+  if (out) { w.log_px = out->log_px; w.log_px_missing = out->log_px_missing; }
   const float tau_c = std::max(tau, 1e-6f);  // model.py:1587
   const float drop_p = training ? m.dropout : 0.f;
   const int nh = m.n_hidden;
@@ -922,6 +928,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     a.prior_terms = w.prior_terms; a.head_slab = grad ? head_slab : nullptr; a.sums_slab = w.sums_slab;
     a.head_off = m.head_off; a.head_len = m.head_len; a.hw_max = p->hw_max;
     a.xsrc = p->xsrc_dev; a.ldx = p->loss_ldx; a.ldm = p->loss_ldm; a.cells = w.cells; a.n_cols = m.n_cols;
+    a.log_px = w.log_px; a.log_px_missing = w.log_px_missing;
     if (n_chunks > 0)
       if (int rc = launch_loss(a, grad, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
   }
@@ -1568,6 +1575,50 @@ extern "C" int suave_decode_sample_static(const suave_plan* p, const float* para
   }
   return decode_sample_impl(p, params, z, s_dense, component, (int)n, noise_normal, noise_uniform, noise_exp, seed,
                             row_offset, d, static_cast<hipStream_t>(stream), out_num, ld_num, out_codes, ld_disc, y_full_out);
+}
+
+extern "C" int suave_decode_log_px(const suave_plan* p, const float* params, const float* z, const int32_t* component,
+                                   const suave_batch_t* batch, void* workspace, size_t workspace_bytes, void* stream,
+                                   float* log_px, float* log_px_missing) {
+  suave::drop_stale_hip_error();
+  SUAVE_REQUIRE(p && params, "decode_log_px: null plan/params");
+  if (int rc = check_batch(p, batch)) return rc;
+  const suave_model_t& m = p->model;
+  const int B = batch->n_rows;
+  if (B == 0) return 0;
+  SUAVE_REQUIRE(z && component, "decode_log_px: z / component is null");
+  SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(params) & 15) == 0, "params must be 16-byte aligned");
+  SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace w;
+  carve(p, B, workspace, &w);
+  SUAVE_REQUIRE(workspace_bytes >= w.total_bytes, "workspace too small (see suave_workspace_bytes)");
+  w.log_px = log_px; w.log_px_missing = log_px_missing;
+  // y_full = trunk(z), eval mode (per-layer path: the training carving has the hidden buffers)
+  SUAVE_CHECK_HIP(hipMemcpy2DAsync(w.z, sizeof(float) * p->ldD, z, sizeof(float) * m.latent_dim,
+                                   sizeof(float) * m.latent_dim, B, hipMemcpyDeviceToDevice, st));
+  DecodeScratch d{};
+  d.z = w.z; d.y = w.y; d.wideL = nullptr; d.chain_img = nullptr;
+  for (int i = 0; i < m.n_hidden; ++i) d.hd[i] = w.hd[i];
+  if (int rc = decoder_trunk_eval(p, params, d, B, st)) return rc;
+  if (int rc = launch_expand(p, *batch, w.x, w.cells, st)) return rc;  // the packed cells of the batch rows
+  const int n_chunks = (int)p->chunks_host.size();
+  const int lgrid = loss_grid(p, B), lworkers = loss_workers(p, B);
+  LossArgs a{};
+  a.cols = p->cols_dev; a.chunks = p->chunks_dev; a.params = params; a.y = w.y; a.batch = *batch;
+  a.n_rows = B; a.vdiv = 1; a.kidx = component; a.c_up = 0.f; a.bk = 0.f;
+  a.K = m.n_components; a.D = m.latent_dim; a.ldY = p->ldY; a.ldy = p->max_chunk_y | 1; a.ldK = p->ldK;
+  a.ldD = p->ldD; a.ldE = p->ldE; a.max_classes = p->max_classes;
+  a.recon_part = w.recon_part; a.sums_slab = w.sums_slab;
+  a.head_off = m.head_off; a.head_len = m.head_len; a.hw_max = p->hw_max;
+  a.xsrc = p->xsrc_dev; a.ldx = p->loss_ldx; a.ldm = p->loss_ldm; a.cells = w.cells; a.n_cols = m.n_cols;
+  a.log_px = log_px; a.log_px_missing = log_px_missing;
+  if (n_chunks > 0)
+    if (int rc = launch_loss(a, false, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, st)) return rc;
+  if (!p->wide_host.empty())
+    return wide_forward(p, params, w, B, 1, component, nullptr, nullptr, 0.f, false, w.recon_part + (size_t)n_chunks * B,
+                        w.sums_slab + (size_t)lworkers * n_chunks * 4, st);
+  return 0;
 }
 
 extern "C" int suave_gemm_arithmetic_set(int mode) { return gemm_split_mode_set(mode); }

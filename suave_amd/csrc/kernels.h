@@ -20,6 +20,8 @@ struct LossArgs {
   float bk;            // d loss / d KL_row
   int K, D, ldY, ldy, ldK, ldD, ldE, ldT;
   int max_classes;
+  float* log_px;          // [n_rows, n_cols] per-column terms on request (vdiv == 1), else null
+  float* log_px_missing;  // [n_rows, n_cols] or null
   float* recon_part;   // [n_chunks, n_rows]
   float* ds_part;      // [n_chunks, ldK, n_rows]  (plane-major)
   int do_kl;
@@ -184,6 +186,8 @@ struct WideRowArgs {
   float* recon_out;     // [n_rows]
   float* ds_out;        // [ldK, n_rows] (plane-major) or null
   double* sums_slab;    // [grid, 4] or null
+  float* log_px;          // [n_rows, n_cols] per-column terms on request, else null
+  float* log_px_missing;
 };
 int launch_wide_fill(const WideRowArgs& a, hipStream_t s);
 int wide_softmax_grid(int n_rows);

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
   // gradient are independent DPP chains the scheduler interleaves.  (The operand-at-a-time loops they replace
   // waited for an LDS round trip per multiply and ran the reductions one after the other.)
   auto cat_col = [&](auto tag, const suave_col_t& col, int cell, bool obs, float u, float* yb, const float* wl, float* hw,
-                     int k, float& recon, float (&ds)[KMAX]) {
+                     int k, float& recon, float (&ds)[KMAX], float& lp_out) {
     constexpr int YB = decltype(tag)::value;
     const int yd = col.y_dim, C = col.n_classes, ldw = yd + K;
     const int code = obs ? cell : -1;
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
     }
     const float lse = mx + __logf(se);
     const bool has = code >= 0 && code < C;
-    recon += (obs && has) ? (lcode - lse) : 0.f;
+    lp_out = has ? (lcode - lse) : 0.f;  // (a masked cell is an all-zero one-hot: 0)
+    recon += lp_out;
     if (GRAD) {
       const bool live = obs && has;  // all-zero one-hot: sum(x) = 0 -> zero gradient
       float dy[YB];
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
     }
   };
   auto ord_col = [&](auto tag, const suave_col_t& col, int cell, bool obs, float u, float* yb, const float* wl, float* hw,
-                     int k, float& recon, float (&ds)[KMAX]) {
+                     int k, float& recon, float (&ds)[KMAX], float& lp_out) {
     constexpr int YB = decltype(tag)::value;
     const int yd = col.y_dim, C = col.n_classes;
     const float* wml = wsm + (col.w2_off - hw_begin);  // mean_layer [yd + K]
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
     }
     const float p_raw = sg_t - sg_tm1;
     const float p = fminf(fmaxf(p_raw, kEps), 1.0f);
-    recon += obs ? __logf(p) : 0.f;
+    lp_out = __logf(p);
+    recon += obs ? lp_out : 0.f;
     if (GRAD) {
       const float gp = (obs && p_raw >= kEps && p_raw <= 1.0f) ? u / p : 0.f;
       const float du_t = (gp != 0.f && t < C - 1) ? gp * sg_t * (1.0f - sg_t) : 0.f;
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
       const float* wl = wsm + (col.w_off - hw_begin);
       const float* w = wl;
       float* hw = hw_acc + (col.w_off - hw_begin);
+      float lp_cell = 0.f;  // the column's log-likelihood of this row's cell value (placeholder value when masked)
       if ((col.type == SUAVE_TYPE_REAL || col.type == SUAVE_TYPE_POS) && yd == 1) {
         // y_dim == 1 (the default; decoder.py:87-99): every LDS operand of the column is read before the arithmetic starts, the
         // K assignment weights unconditionally up to KMAX (the weight image is padded), so one wait covers them all
@@ -370,7 +373,8 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
         const float rr = xr - mean;
         float nll = 0.5f * (kLog2Pi + __logf(cc) + rr * rr / cc);
         if (col.type == SUAVE_TYPE_POS) nll += xr;
-        recon += obs ? -nll : 0.f;
+        lp_cell = -nll;
+        recon += obs ? lp_cell : 0.f;
         if (GRAD) {
           // masked / out-of-tile lanes get an exact zero (select, not 0 * x: x may be inf or NaN there)
           const float ga = obs ? u * (rr / cc) * col.scale : 0.f;
@@ -397,6 +401,7 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
         const float cnt = fmaxf(__expf(x) - col.shift, 0.f);
         const float rc = fmaxf(rate, kEps);
         const float lp = (cnt == 0.f ? 0.f : cnt * __logf(rc)) - rc - lgammaf(cnt + 1.0f);
+        lp_cell = lp;
         recon += obs ? lp : 0.f;
         if (GRAD) {
           const float gr = obs ? u * (cnt / rc - 1.0f) * softplus_grad_f(rho) : 0.f;
@@ -424,7 +429,8 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
         const float rr = xr - mean;
         float nll = 0.5f * (kLog2Pi + __logf(cc) + rr * rr / cc);
         if (col.type == SUAVE_TYPE_POS) nll += xr;
-        recon += obs ? -nll : 0.f;
+        lp_cell = -nll;
+        recon += obs ? lp_cell : 0.f;
         if (GRAD) {
           // masked / out-of-tile lanes get an exact zero (select, not 0 * x: x may be inf or NaN there)
           const float ga = obs ? u * (rr / cc) * col.scale : 0.f;
@@ -453,6 +459,7 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
         const float cnt = fmaxf(__expf(x) - col.shift, 0.f);
         const float rc = fmaxf(rate, kEps);
         const float lp = (cnt == 0.f ? 0.f : cnt * __logf(rc)) - rc - lgammaf(cnt + 1.0f);
+        lp_cell = lp;
         recon += obs ? lp : 0.f;
         if (GRAD) {
           const float gr = obs ? u * (cnt / rc - 1.0f) * softplus_grad_f(rho) : 0.f;
@@ -470,9 +477,9 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
           acc_add_lanes(hw + yd + k, gr);
         }
       } else if (col.type == SUAVE_TYPE_CAT) {
-        if (yd <= 2) cat_col(std::integral_constant<int, 2>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds);
-        else if (yd <= 4) cat_col(std::integral_constant<int, 4>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds);
-        else if (yd <= 8) cat_col(std::integral_constant<int, 8>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds);
+        if (yd <= 2) cat_col(std::integral_constant<int, 2>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
+        else if (yd <= 4) cat_col(std::integral_constant<int, 4>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
+        else if (yd <= 8) cat_col(std::integral_constant<int, 8>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
         else {  // more classes than the register-blocked paths take: one LDS round trip per operand
   const int C = col.n_classes;
           const int ldw = yd + K;
@@ -490,7 +497,8 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
           }
           const float lse = mx + __logf(se);
           const bool has = code >= 0 && code < C;
-          recon += (obs && has) ? (lcode - lse) : 0.f;
+          lp_cell = has ? (lcode - lse) : 0.f;
+          recon += lp_cell;
           if (GRAD) {
             const bool live = obs && has;     // all-zero one-hot: sum(x) = 0 -> zero gradient
             // sweep 2: g_c = u * (x_c - softmax_c); weight gradients while y is intact
@@ -522,8 +530,8 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
         }
       } else {  // ordinal: cumulative link
         const int need = max(yd, col.n_classes - 1);  // y features and thresholds both live in YB registers
-        if (need <= 4) ord_col(std::integral_constant<int, 4>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds);
-        else if (need <= 8) ord_col(std::integral_constant<int, 8>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds);
+        if (need <= 4) ord_col(std::integral_constant<int, 4>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
+        else if (need <= 8) ord_col(std::integral_constant<int, 8>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
         else {
   const int C = col.n_classes;
           const float* wml = wsm + (col.w2_off - hw_begin);  // mean_layer [yd + K]
@@ -542,7 +550,8 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
           }
           const float p_raw = sg_t - sg_tm1;
           const float p = fminf(fmaxf(p_raw, kEps), 1.0f);
-          recon += obs ? __logf(p) : 0.f;
+          lp_cell = __logf(p);
+          recon += obs ? lp_cell : 0.f;
           if (GRAD) {
             const float gp = (obs && p_raw >= kEps && p_raw <= 1.0f) ? u / p : 0.f;
             const float du_t = (gp != 0.f && t < C - 1) ? gp * sg_t * (1.0f - sg_t) : 0.f;
@@ -574,6 +583,8 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
           }
         }
       }
+      if (a.log_px && valid) a.log_px[(size_t)(r0 + lane) * a.n_cols + c] = obs ? lp_cell : 0.f;
+      if (a.log_px_missing && valid) a.log_px_missing[(size_t)(r0 + lane) * a.n_cols + c] = obs ? 0.f : lp_cell;
       LOSS_T(tc1);
       LOSS_ACC(1 + col.type, tc1 - tc0);
       LOSS_ACC(8 + col.type, 1);

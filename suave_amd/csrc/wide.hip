@@ -59,7 +59,10 @@ __global__ __launch_bounds__(256) void k_wide_softmax(WideRowArgs a) {
       for (int i = lane; i < n; i += 64) se += __expf(Lc[i] - mx);
       se = wave_sum(se) + __expf(-mx);
       const float lse = mx + __logf(se);
-      if (live) recon += (code >= 1 ? Lc[code - 1] : 0.f) - lse;
+      const float lp = live ? (code >= 1 ? Lc[code - 1] : 0.f) - lse : 0.f;  // (masked cell: all-zero one-hot, 0)
+      recon += lp;
+      if (lane == 0 && a.log_px) a.log_px[(size_t)r * a.n_cols + wc.col] = lp;
+      if (lane == 0 && a.log_px_missing) a.log_px_missing[(size_t)r * a.n_cols + wc.col] = 0.f;
       if (GRAD) {
         for (int i = lane; i < n; i += 64) {
           const float p = __expf(Lc[i] - lse);

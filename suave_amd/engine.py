@@ -133,7 +133,7 @@ class Engine:
              ) -> Dict[str, torch.Tensor]:
         """One ELBO forward (+ backward into ``self.grads``).  ``want`` selects
         per-row outputs among reconstruction, categorical_kl, gaussian_kl,
-        latent, component, enc_out.  ``ready_event`` (grad only): recorded by the library once the
+        latent, component, enc_out, and (supervised branch) the per-column log_px / log_px_missing [B, n_cols].  ``ready_event`` (grad only): recorded by the library once the
         decoder-side gradient bucket is final, before the encoder backward (suave_elbo_backward_overlap)."""
 
         B = int(n_rows)
@@ -149,7 +149,9 @@ class Engine:
         K, D = self.layout.n_components, self.layout.latent_dim
         shapes = {"reconstruction": ((B,), torch.float32), "categorical_kl": ((B,), torch.float32),
                   "gaussian_kl": ((B,), torch.float32), "latent": ((B, D), torch.float32),
-                  "component": ((B,), torch.int32), "enc_out": ((B, K + 2 * K * D), torch.float32)}
+                  "component": ((B,), torch.int32), "enc_out": ((B, K + 2 * K * D), torch.float32),
+                  "log_px": ((B, self.layout.model.n_cols), torch.float32),
+                  "log_px_missing": ((B, self.layout.model.n_cols), torch.float32)}
         for name in want:
             shape, dt = shapes[name]
             res[name] = torch.empty(shape, dtype=dt, device=self.device)
@@ -285,6 +287,24 @@ class Engine:
                                             int(row_offset), self._stream(), z.data_ptr(), comp.data_ptr())
         _lib.check(rc, "suave_posterior_draws")
         return z, comp
+
+    def decode_log_px(self, z: torch.Tensor, component: torch.Tensor, table: PackedTable, row_begin: int = 0, *,
+                      row_index: Optional[torch.Tensor] = None):
+        """Decoder.forward's per-column ``log_px`` / ``log_px_missing`` (decoder.py:348-379) of the table rows at
+        the given latents and components: two [n, n_cols] tensors in schema column order."""
+
+        n = int(z.shape[0])
+        ws = self.workspace(n)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        nbytes = ws.numel() - (base - ws.data_ptr())
+        batch = table.batch(row_begin, n, row_index)
+        n_cols = int(self.layout.model.n_cols)
+        lp = torch.empty((n, n_cols), dtype=torch.float32, device=self.device)
+        lpm = torch.empty((n, n_cols), dtype=torch.float32, device=self.device)
+        rc = self.lib.suave_decode_log_px(self._plan, self.params.data_ptr(), z.data_ptr(), component.data_ptr(),
+                                          C.byref(batch), base, nbytes, self._stream(), lp.data_ptr(), lpm.data_ptr())
+        _lib.check(rc, "suave_decode_log_px")
+        return lp, lpm
 
     def head_params_width(self, col_index: int) -> int:
         w = C.c_int32()

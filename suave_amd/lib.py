@@ -32,6 +32,7 @@ EXPORTS = (
     "suave_posterior_draws",
     "suave_head_params_width",
     "suave_decode_params",
+    "suave_decode_log_px",
     "suave_gemm_arithmetic_set",
     "suave_gemm_arithmetic_get",
     "suave_profile_enable",
@@ -89,6 +90,7 @@ def load():
     lib.suave_posterior_draws.argtypes = [vp, vp, i64, i32, vp, vp, u64, i64, vp, vp, vp]
     lib.suave_head_params_width.argtypes = [vp, i32, C.POINTER(i32)]
     lib.suave_decode_params.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, sz, vp, vp]
+    lib.suave_decode_log_px.argtypes = [vp, vp, vp, vp, C.POINTER(BatchT), vp, sz, vp, vp, vp]
     lib.suave_gemm_arithmetic_set.argtypes = [C.c_int]
     lib.suave_gemm_arithmetic_get.argtypes = [C.POINTER(C.c_int)]
     lib.suave_profile_enable.argtypes = [C.c_int]

@@ -62,7 +62,8 @@ class NoiseT(C.Structure):
 
 class ElboOutT(C.Structure):
     _fields_ = [("reconstruction", C.c_void_p), ("categorical_kl", C.c_void_p), ("gaussian_kl", C.c_void_p),
-                ("latent", C.c_void_p), ("component", C.c_void_p), ("enc_out", C.c_void_p), ("sums", C.c_void_p)]
+                ("latent", C.c_void_p), ("component", C.c_void_p), ("enc_out", C.c_void_p), ("sums", C.c_void_p),
+                ("log_px", C.c_void_p), ("log_px_missing", C.c_void_p)]
 
 
 def _r4(x: int) -> int:
