@@ -40,6 +40,7 @@ _DEFAULTS = dict(latent_dim=32, n_components=1, beta=1.5, hidden_dims=(256, 128)
                  gumbel_temperature=1.0, head_epochs=5, finetune_epochs=10, joint_decoder_lr_scale=0.1,
                  early_stop_patience=5)  # model.py:51-68
 _REFINE_MODES = ("decoder_only", "decoder_prior", "prior_em_only", "prior_em_decoder")
+_ROW_CHUNK = 262144  # rows per device call of the inference methods (bounds the workspace; results do not depend on it)
 
 
 class DrawReplay:
@@ -685,17 +686,21 @@ class SUAVE:
             return {"mean": empty, "assignments": np.empty((0, K), np.float32), "component_mu": empty.copy(),
                     "component_logvar": empty.copy()}
         tau = self._inference_tau if self.behaviour == "unsupervised" else None
-        out = self._engine.encode(table, 0, table.n_rows, temperature=tau)
-        mean = out["mean"].cpu().numpy()
+        parts: Dict[str, list] = {"mean": [], "assignments": [], "component_mu": [], "component_logvar": []}
+        for s0 in range(0, table.n_rows, _ROW_CHUNK):  # the workspace is sized by the chunk, not by the table
+            out = self._engine.encode(table, s0, min(_ROW_CHUNK, table.n_rows - s0), temperature=tau)
+            parts["mean"].append(out["mean"].cpu().numpy())
+            if not return_components:
+                continue
+            enc = out["enc_out"]
+            k = enc[:, :K].argmax(dim=1)  # hard assignment on softmax(logits) (model.py:4254-4258)
+            rows = torch.arange(enc.shape[0], device=enc.device)
+            parts["assignments"].append(torch.nn.functional.one_hot(k, K).float().cpu().numpy())
+            parts["component_mu"].append(enc[:, K:K + K * D].reshape(-1, K, D)[rows, k].cpu().numpy())
+            parts["component_logvar"].append(enc[:, K + K * D:].reshape(-1, K, D)[rows, k].cpu().numpy())
         if not return_components:
-            return mean
-        enc = out["enc_out"]
-        k = enc[:, :K].argmax(dim=1)  # hard assignment on softmax(logits) (model.py:4254-4258)
-        rows = torch.arange(enc.shape[0], device=enc.device)
-        mu = enc[:, K:K + K * D].reshape(-1, K, D)[rows, k]
-        lv = enc[:, K + K * D:].reshape(-1, K, D)[rows, k]
-        return {"mean": mean, "assignments": torch.nn.functional.one_hot(k, K).float().cpu().numpy(),
-                "component_mu": mu.cpu().numpy(), "component_logvar": lv.cpu().numpy()}
+            return np.concatenate(parts["mean"])
+        return {key: np.concatenate(v) for key, v in parts.items()}
 
     # ------------------------------------------------------------------
     def _prior_cdf(self) -> torch.Tensor:
@@ -801,35 +806,48 @@ class SUAVE:
         table = PackedTable(xnum, codes, mask, eng.device)
         K, D = self.n_components, self.latent_dim
         tau = self._inference_tau if self.behaviour == "unsupervised" else None
-        out = eng.encode(table, 0, table.n_rows, temperature=tau)
-        enc, probs = out["enc_out"], out["probs"]
-        mu = enc[:, K:K + K * D].reshape(-1, K, D)
-        comp = assign = None
-        if strategy == "hard":  # model.py:3627-3634
-            comp = probs.argmax(dim=1).to(torch.int32)
-            z = mu[torch.arange(mu.shape[0], device=mu.device), comp.long()].contiguous()
-        elif strategy == "soft":  # model.py:3635-3637
-            assign = probs.contiguous()
-            z = out["mean"]
-        else:  # relaxed Gumbel-softmax weights, model.py:3638-3644
-            t = max(float(self._inference_tau if self.behaviour == "unsupervised" else self.gumbel_temperature), 1e-6)
-            if _noise is not None and _noise.get("assign_exp") is not None:
-                e = _noise["assign_exp"].to(eng.device)
+        nz = _noise or {}
+        e_all = None
+        if strategy == "sample":
+            if nz.get("assign_exp") is not None:
+                e_all = nz["assign_exp"].to(eng.device)
             else:
                 g = torch.Generator(device=eng.device)
                 g.manual_seed(seed)
-                e = torch.empty_like(probs).exponential_(generator=g)
-            assign = torch.softmax((enc[:, :K] - torch.log(e)) / t, dim=1).contiguous()
-            z = (assign.unsqueeze(-1) * mu).sum(dim=1).contiguous()
+                e_all = torch.empty((table.n_rows, K), device=eng.device).exponential_(generator=g)
+        rows_of = lambda key, s0, nb: None if nz.get(key) is None else nz[key][s0:s0 + nb].contiguous()
+        nums, cods, lat, asg = [], [], [], []
+        for s0 in range(0, table.n_rows, _ROW_CHUNK):  # row chunks: the generators are keyed by the table row
+            nb = min(_ROW_CHUNK, table.n_rows - s0)
+            out = eng.encode(table, s0, nb, temperature=tau)
+            enc, probs = out["enc_out"], out["probs"]
+            mu = enc[:, K:K + K * D].reshape(-1, K, D)
+            comp = assign = None
+            if strategy == "hard":  # model.py:3627-3634
+                comp = probs.argmax(dim=1).to(torch.int32)
+                z = mu[torch.arange(mu.shape[0], device=mu.device), comp.long()].contiguous()
+            elif strategy == "soft":  # model.py:3635-3637
+                assign = probs.contiguous()
+                z = out["mean"]
+            else:  # relaxed Gumbel-softmax weights, model.py:3638-3644
+                t = max(float(self._inference_tau if self.behaviour == "unsupervised" else self.gumbel_temperature), 1e-6)
+                assign = torch.softmax((enc[:, :K] - torch.log(e_all[s0:s0 + nb])) / t, dim=1).contiguous()
+                z = (assign.unsqueeze(-1) * mu).sum(dim=1).contiguous()
+            if _routing is not None:
+                lat.append(z)
+                asg.append(assign if assign is not None else torch.nn.functional.one_hot(comp.long(), K).float())
+            onum, ocodes = eng.decode_sample(z, component=comp, assignments=assign, seed=seed + 1, row_offset=s0,
+                                             noise_normal=rows_of("normal", s0, nb), noise_uniform=rows_of("uniform", s0, nb),
+                                             noise_exp=rows_of("exp", s0, nb))
+            nums.append(onum.cpu().numpy())
+            cods.append(ocodes.cpu().numpy())
         if _routing is not None:
-            _routing["latent"] = z
-            _routing["assignments"] = assign if assign is not None else torch.nn.functional.one_hot(comp.long(), K).float()
-        nz = _noise or {}
-        onum, ocodes = eng.decode_sample(z, component=comp, assignments=assign, seed=seed + 1,
-                                         noise_normal=nz.get("normal"), noise_uniform=nz.get("uniform"),
-                                         noise_exp=nz.get("exp"))
-        recon = data_utils.frame_from_packed(onum.cpu().numpy(), ocodes.cpu().numpy(), self.schema,
-                                             self._norm_stats_per_col)
+            _routing["latent"] = torch.cat(lat) if lat else torch.empty((0, D), device=eng.device)
+            _routing["assignments"] = torch.cat(asg) if asg else torch.empty((0, K), device=eng.device)
+        n_num = sum(1 for n in self.schema.feature_names if self.schema[n].type in ("real", "pos", "count"))
+        onum_all = np.concatenate(nums) if nums else np.empty((0, n_num), np.float32)
+        ocodes_all = np.concatenate(cods) if cods else np.empty((0, len(self.schema.feature_names) - n_num), np.int16)
+        recon = data_utils.frame_from_packed(onum_all, ocodes_all, self.schema, self._norm_stats_per_col)
         return self._merge_observed(X, aligned, recon, mask, only_missing)
 
     # ------------------------------------------------------------------
@@ -907,12 +925,16 @@ class SUAVE:
         n_classes = int(spec.n_classes)
         if table.n_rows == 0:
             return torch.empty((0, n_classes), dtype=torch.float32)
-        enc = eng.encode(table, 0, table.n_rows)["enc_out"]
-        z, comp = eng.posterior_draws(enc, int(L), seed=seed)
-        probs = eng.decode_params(z, j, component=comp)
-        probs = probs.view(int(L), table.n_rows, -1).mean(dim=0).clamp(min=1e-8)
-        probs = probs / probs.sum(dim=-1, keepdim=True).clamp_min(1e-8)
-        return probs.cpu()
+        outs = []
+        chunk = max(1, (1 << 20) // int(L))  # at most ~1M decoded rows at a time, as predict_confidence_interval
+        for s0 in range(0, table.n_rows, chunk):
+            nb = min(chunk, table.n_rows - s0)
+            enc = eng.encode(table, s0, nb)["enc_out"]
+            z, comp = eng.posterior_draws(enc, int(L), seed=seed, row_offset=s0 * int(L))
+            probs = eng.decode_params(z, j, component=comp)
+            probs = probs.view(int(L), nb, -1).mean(dim=0).clamp(min=1e-8)
+            outs.append((probs / probs.sum(dim=-1, keepdim=True).clamp_min(1e-8)).cpu())
+        return torch.cat(outs)
 
     def predict_confidence_interval(self, X: pd.DataFrame, attr, *, mask=None, L: int = 1000, ci: float = 0.95,
                                     statistic: Optional[str] = None, return_samples: bool = False,

@@ -160,3 +160,70 @@ def test_unfitted_and_validation_errors():
         SUAVE(_schema(), behaviour="supervised").fit(df)  # targets required
     with pytest.raises(ValueError):
         SUAVE(_schema(), n_components=0)
+
+
+def test_m20_shaped_fit_with_reference_defaults():
+    """BASELINE.json config #1 in shape: a MIMIC-mortality-demo-like table -- 10 000 rows x 20 mixed columns (6 real,
+    4 positive, 3 count, 4 categorical, 3 ordinal, ~8 % missing), a binary outcome that depends on the features --
+    through the whole supervised ``fit`` schedule with the reference's architectural defaults (latent 32,
+    hidden (256, 128), batch 128, dropout 0.1; suave/defaults.py) and shortened phases.  A smoke test of the product
+    at the reference's own scale: every phase runs, the ELBO improves, the classifier separates the outcome on
+    held-out rows, generation / imputation / encoding return well-formed frames."""
+
+    from suave_amd import supervised as sup
+    from suave_amd.model import SUAVE
+    from suave_amd.types import Schema
+
+    rng = np.random.default_rng(20)
+    n = 10_000
+    risk = rng.normal(size=n)
+    cols, spec = {}, {}
+    for i in range(6):
+        cols[f"vital{i}"] = rng.normal(60 + 5 * i + 6 * risk * (i % 2), 10 + i, n); spec[f"vital{i}"] = {"type": "real"}
+    for i in range(4):
+        cols[f"lab{i}"] = rng.lognormal(0.5 + 0.3 * i + 0.25 * risk, 0.5, n); spec[f"lab{i}"] = {"type": "pos"}
+    for i in range(3):
+        cols[f"count{i}"] = rng.poisson(np.exp(0.8 + 0.3 * risk)).astype(float); spec[f"count{i}"] = {"type": "count"}
+    for i, c in enumerate((2, 3, 5, 7)):
+        cols[f"cat{i}"] = rng.integers(0, c, n).astype(float); spec[f"cat{i}"] = {"type": "cat", "n_classes": c}
+    for i, c in enumerate((3, 4, 5)):
+        cols[f"ord{i}"] = np.clip(np.rint(rng.normal(c / 2 + 0.6 * risk, 1.0, n)), 0, c - 1); spec[f"ord{i}"] = {"type": "ordinal", "n_classes": c}
+    df = pd.DataFrame(cols)
+    for c in df.columns:
+        df.loc[rng.random(n) < 0.08, c] = np.nan
+    y = (risk + 0.5 * rng.normal(size=n) > 0.8).astype(int)  # ~25 % positives
+    train, test = df.iloc[:8000], df.iloc[8000:]
+    model = SUAVE(Schema(spec), n_components=2, random_state=0)  # everything else: the reference's defaults
+    assert (model.latent_dim, model.hidden_dims, model.batch_size, model.dropout) == (32, (256, 128), 128, 0.1)
+    model.fit(train, y[:8000], warmup_epochs=4, kl_warmup_epochs=2, head_epochs=2, finetune_epochs=3,
+              decoder_refine_epochs=2)
+    assert len(model._train_history) == 4 and 1 <= len(model._joint_history) <= 3 and len(model._refine_history) >= 1
+    assert model._train_history[-1]["reconstruction"] > model._train_history[0]["reconstruction"]
+    assert np.isfinite([h["nll"] for h in model._warmup_val_history]).all()
+    proba = model.predict_proba(test)
+    assert proba.shape == (2000, 2) and np.allclose(proba.sum(1), 1.0, atol=1e-5)
+    assert sup.compute_auroc(proba, y[8000:]) > 0.8
+    z = model.encode(test)
+    assert z.shape == (2000, 32) and np.isfinite(z).all()
+    gen = model.sample(3000, seed=1)
+    assert list(gen.columns) == list(df.columns) and len(gen) == 3000
+    assert (gen["count0"] >= 0).all() and gen["lab0"].min() > -1.0 and int(gen["cat3"].cat.codes.max()) <= 6
+    cond = model.sample(500, conditional=True, y=np.ones(500, int), seed=2)
+    assert len(cond) == 500
+    filled = model.impute(test)
+    assert not filled.isna().any().any()
+    keep = test.notna()
+    assert np.allclose(filled["vital0"][keep["vital0"]], test["vital0"][keep["vital0"]])  # observed cells are kept
+    # the inference methods walk the table in row chunks; the chunk size must not show in the results
+    import suave_amd.model as sm
+
+    imp = model.impute(test, seed=5)
+    pp = model.predict_proba(test.iloc[:600], attr="cat2", L=20, seed=4)
+    old = sm._ROW_CHUNK
+    sm._ROW_CHUNK = 300
+    try:
+        assert np.array_equal(model.encode(test), z)
+        pd.testing.assert_frame_equal(model.impute(test, seed=5), imp)
+    finally:
+        sm._ROW_CHUNK = old
+    assert pp.shape == (600, 5) and np.allclose(pp.sum(1), 1.0, atol=1e-5)

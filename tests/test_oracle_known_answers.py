@@ -197,3 +197,29 @@ def test_sampled_elbo_equals_expectation_at_zero_temperature():
     g_exp = orc.kl_normal_mixture(mu, lv, zero2, zero2, probs)
     elbo_exp = recon_exp - (cat_kl + g_exp)
     np.testing.assert_allclose(elbo_new, elbo_exp, atol=1e-5, rtol=1e-4)
+
+
+def test_poisson_map_moments_both_branches():
+    """The build-defined (rate, u, n) -> count map (oracle/sampling_oracle.poisson_from_noise == sample.hip
+    poisson_from_noise; torch.poisson cannot be replayed).  Below rate 64: CDF inversion, an exact Poisson draw up to
+    binary32 CDF resolution -- mean, variance and skewness 1/sqrt(rate) are reproduced.  From rate 64 on: the
+    rounded normal floor(rate + sqrt(rate) n + 1/2) -- mean and variance (+1/12 from the rounding) are Poisson's,
+    the skewness is 0 where Poisson's is 1/sqrt(rate) <= 0.125: the documented approximation of that branch
+    (INTEGRATION.md).  No reference fixture pins the large-rate branch: parity unpinned there."""
+
+    from oracle import sampling_oracle as sorc
+
+    rng = np.random.default_rng(12)
+    n = 400_000
+    u, z = rng.random(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+
+    def moments(rate):
+        k = sorc.poisson_from_noise(np.full(n, rate, np.float32), u, z).astype(np.float64)
+        m, v = k.mean(), k.var()
+        return m, v, ((k - m) ** 3).mean() / v ** 1.5
+
+    m, v, sk = moments(20.0)
+    assert abs(m - 20.0) < 0.05 and abs(v - 20.0) < 0.25 and abs(sk - 20.0 ** -0.5) < 0.02
+    m, v, sk = moments(100.0)
+    assert abs(m - 100.0) < 0.1 and abs(v - (100.0 + 1.0 / 12.0)) < 1.0
+    assert abs(sk) < 0.02  # symmetric: Poisson(100) has skewness 0.1
