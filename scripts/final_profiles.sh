@@ -4,7 +4,7 @@
 #   passes (separate runs, counters only), one-step timelines of S64 and W1024, and the W1024 bench line.
 # Every GPU step has its own time limit and the chain stops at the first failure.
 set -e -o pipefail
-R=${1:-r01}
+R=${1:-r02}
 O=gpurun_out
 export TMPDIR=/tmp
 RAW="$O/${R}_stats $O/${R}_stats_train $O/${R}_fetch $O/${R}_write $O/${R}_fetch_t $O/${R}_write_t $O/${R}_tl_s64 $O/${R}_tl_w"
@@ -30,12 +30,21 @@ echo "[summaries]"
 mkdir -p $O/${R}_out
 python scripts/trim_prof.py $(find $O/${R}_stats -name '*kernel_stats.csv' | tail -1) $O/${R}_out/${R}_bench_kernel_stats.csv > /dev/null
 python scripts/trim_prof.py $(find $O/${R}_stats_train -name '*kernel_stats.csv' | tail -1) $O/${R}_out/${R}_bench_train_kernel_stats.csv > /dev/null
-python scripts/pmc_traffic.py $O/${R}_fetch_t $O/${R}_write_t > $O/${R}_out/${R}_pmc_traffic_train.json
+python scripts/pmc_traffic.py $O/${R}_fetch_t $O/${R}_write_t 7 > $O/${R}_out/${R}_pmc_traffic_train.json
 python scripts/pmc_traffic.py $O/${R}_fetch $O/${R}_write > $O/${R}_out/${R}_pmc_traffic_gen.json
 python scripts/step_timeline.py $(find $O/${R}_tl_s64 -name '*kernel_trace.csv' | tail -1) > $O/${R}_out/${R}_step_timeline.txt
 python scripts/step_timeline.py $(find $O/${R}_tl_w -name '*kernel_trace.csv' | tail -1) > $O/${R}_out/${R}_w1024_step_timeline.txt
 tail -1 $O/${R}_bench_stats.log > $O/${R}_out/${R}_bench_default_under_rocprof.json || true
 rm -rf $O/${R}_stats $O/${R}_stats_train $O/${R}_fetch $O/${R}_write $O/${R}_fetch_t $O/${R}_write_t $O/${R}_tl_s64 $O/${R}_tl_w
+echo "[8b] PMC FETCH_SIZE / WRITE_SIZE, W1024 training only"
+rm -rf $O/${R}_fetch_w $O/${R}_write_w
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/${R}_fetch_w --output-format csv -o pmc -- python bench.py --config w1024 --steps 3 --warmup 1 --no-cpu-baseline --no-profile --gen-rows 0 > $O/${R}_fetch_w.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/${R}_write_w --output-format csv -o pmc -- python bench.py --config w1024 --steps 3 --warmup 1 --no-cpu-baseline --no-profile --gen-rows 0 > $O/${R}_write_w.log 2>&1
+python scripts/pmc_traffic.py $O/${R}_fetch_w $O/${R}_write_w 4 > $O/${R}_out/${R}_pmc_traffic_w1024.json
+rm -rf $O/${R}_fetch_w $O/${R}_write_w
+echo "[8c] SQ counter passes (VALU / LDS / MFMA / waits per kernel), S64 training step"
+bash scripts/pmc_kernels.sh ${R}_pmc_sq
+cp $O/${R}_pmc_sq_summary.txt $O/${R}_out/${R}_pmc_sq_summary.txt
 echo "[9/9] W1024 bench line"
-timeout -k 10 300 python bench.py --config w1024 --no-cpu-baseline --gen-rows 0 > $O/${R}_bench_w1024.json 2> $O/${R}_bench_w1024.err
+timeout -k 10 600 python bench.py --config w1024 > $O/${R}_bench_w1024.json 2> $O/${R}_bench_w1024.err
 echo done

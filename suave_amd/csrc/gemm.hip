@@ -651,11 +651,32 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   }
 }
 
+// Weight-gradient launches are (tiles, K splits) grids of a few tiles: the tiles of ONE split read the same rows of
+// both operands (dC and the layer input), so they should meet in one L2.  Workgroups go to the XCDs round-robin by
+// dispatch order; this maps dispatch position `lin` of a (T tiles, S splits) launch to (tile, split) so that the T
+// tiles of a split share an XCD and are dispatched within 8 T positions of each other.  (Dispatched tile-fastest,
+// the tiles of a split sat on T different XCDs and each operand came out of HBM once per tile: 260 MB read for
+// the 121 MB of the first encoder layer's weight gradient.)
+__device__ __forceinline__ void xcd_split_order(int lin, int T, int S, int* tile, int* split) {
+  const int full = S / 8 * 8;  // splits in whole groups of eight
+  if (lin < full * T) {
+    const int g = lin / (8 * T), j = lin - g * 8 * T;
+    *split = g * 8 + (j & 7);
+    *tile = j >> 3;
+  } else {  // the last, partial group: plain order
+    const int r = lin - full * T;
+    *split = full + r / T;
+    *tile = r % T;
+  }
+}
+
 template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int GRP, int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<WAVES_M, WAVES_N, SPLIT, A_KM>()];
   __shared__ int perm_s[GRP == 2 ? kGroupRows : 1];
-  gemm_body<WAVES_M, WAVES_N, A_KM, B_KM, GRP, EPI, SPLIT>(a, blockIdx.x, blockIdx.z, smem, perm_s);
+  int tile = blockIdx.x, split = blockIdx.z;
+  if (EPI == kEpiSlab && GRP == 0 && gridDim.z > 1) xcd_split_order(blockIdx.z * gridDim.x + blockIdx.x, gridDim.x, gridDim.z, &tile, &split);
+  gemm_body<WAVES_M, WAVES_N, A_KM, B_KM, GRP, EPI, SPLIT>(a, tile, split, smem, perm_s);
 }
 
 // The two backward GEMMs of one layer in one launch: they read the same dC and do not depend on each
@@ -671,7 +692,11 @@ __global__ __launch_bounds__(256, (D_SPLIT > 0 || WG_SPLIT > 0) ? 2 : 1) void ge
   __shared__ __attribute__((aligned(16))) float smem[kSmem];
   __shared__ int perm_s[W_GRP == 2 ? kGroupRows : 1];
   const int b = blockIdx.x;
-  if (b < w_blocks) gemm_body<WM, WN, true, true, W_GRP, kEpiSlab, W_SPLIT>(w, b % w_tiles, b / w_tiles, smem, perm_s);
+  if (b < w_blocks) {
+    int tile = b % w_tiles, split = b / w_tiles;
+    if (W_GRP == 0) xcd_split_order(b, w_tiles, w_blocks / w_tiles, &tile, &split);
+    gemm_body<WM, WN, true, true, W_GRP, kEpiSlab, W_SPLIT>(w, tile, split, smem, perm_s);
+  }
   else gemm_body<DM, DN, false, D_SPLIT == 0, D_GRP, D_EPI, D_SPLIT>(d, b - w_blocks, 0, smem, perm_s);  // split: row-major W^T
 }
 
