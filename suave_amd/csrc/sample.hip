@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kSampleThreads, STAGED ? 2 : 1) void k_sample_heads
   }
 }
 
-// Wide categorical columns (32 .. 32 767 classes) of the decode: the race over a column's classes with the LOGITS
+// Wide categorical columns (SUAVE_WIDE_CAT_MIN_CLASSES .. 32 767 classes) of the decode: the race over a column's classes with the LOGITS
 // ALREADY COMPUTED by the MFMA GEMM of the wide heads (gemm_wide_kernel, the training step's forward).  One wavefront
 // per row walks the wide columns; lane q owns classes 4q .. 4q + 3 (+ 256 ...): the Philox block of those four
 // classes, their scores L - log(e), then two wave reductions give the winner (first maximum, as the sequential scan)
