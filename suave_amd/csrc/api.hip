@@ -286,7 +286,7 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
   slab += (size_t)lg * m.head_len + 4;
   {
     const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components;
-    slab += (size_t)prior_colsum_blocks((int)rows) * Mt * round_up(Nt + 1, 4);
+    slab += (size_t)std::max(prior_colsum_blocks((int)rows), reparam_grid((int)rows)) * Mt * round_up(Nt + 1, 4);
   }
   if (m.behaviour == 1) slab += (size_t)lg * (m.n_components * m.latent_dim + m.latent_dim);
   if (any_wide) slab += (size_t)wide_splits(p, rows) * p->wide_len + 4;
@@ -856,7 +856,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   la.sel = w.sel; la.ldS = ldS; la.K = K; la.D = D; la.ldK = p->ldK; la.ldD = p->ldD;
   la.n_rows = B; la.row_index = batch->row_index; la.row_begin = batch->row_begin;
   la.exp_noise = nz->exp_noise; la.eps_in = nz->eps; la.seed = nz->seed; la.step = nz->step; la.tau = tau_c;
-  la.ysoft = w.ysoft; la.kidx = w.kidx; la.z = w.z; la.eps_buf = w.eps;
+  la.ysoft = w.ysoft; la.kidx = w.kidx; la.z = w.z;
   la.latent_out = out ? out->latent : nullptr;
   la.comp_out = out ? out->component : nullptr;
   la.lrank = w.lrank; la.blk_cnt = w.blk_cnt;
@@ -890,8 +890,21 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   const int ldT = round_up(2 * m.latent_dim + m.n_components, 4);
   la.params = params; la.prior_logits_off = m.prior_logits_off; la.prior_mu_off = m.prior_mu_off;
   la.prior_logvar_off = m.prior_logvar_off; la.bk = beta_scale / (float)global_rows; la.grad = grad ? 1 : 0; la.ldT = ldT;
-  la.catkl = w.catkl; la.gausskl = w.gausskl; la.gkl_logit = w.gkl_logit; la.gkl_mu = w.gkl_mu; la.gkl_lv = w.gkl_lv;
+  la.catkl = w.catkl; la.gausskl = w.gausskl; la.gkl_logit = w.gkl_logit;
   la.prior_terms = w.prior_terms; la.sums_slab = w.sums_slab + (size_t)lworkers * n_chunks * 4;
+  // The prior-gradient column sums are taken inside k_reparam (slab below: no prior_terms round trip, no
+  // k_prior_colsum launch) unless K x D is beyond its LDS tile; k_latent_bwd recomputes eps and the Gaussian-KL
+  // gradients instead of reading three [B, ldD] buffers back.
+  const bool fuse_colsum = grad && reparam_colsum_ok(K, D);
+  const int prior_Mt = 2 * m.latent_dim + m.n_components, prior_ldc = round_up(m.n_components + 1, 4);
+  size_t slab_off = 0;
+  float* head_slab = w.slab;
+  slab_off += ((size_t)lworkers * m.head_len + 3) & ~size_t(3);  // GEMM slabs start 16-byte aligned
+  const size_t prior_slab_off = slab_off;  // [reparam_grid(B)][2D + K][prior_ldc], right behind the head slab
+  if (fuse_colsum) {
+    la.prior_slab = w.slab + prior_slab_off; la.prior_ldc = prior_ldc; la.prior_terms = nullptr;
+    slab_off += (size_t)reparam_grid(B) * prior_Mt * prior_ldc;
+  }
   if (int rc = launch_reparam(la, s)) return rc;
   // ---- decoder trunk ----
   if (decoder_chain_ok(p)) {
@@ -911,9 +924,6 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
       return rc;
   }
   // ---- fused likelihood (+ gradients) ----
-  size_t slab_off = 0;
-  float* head_slab = w.slab;
-  slab_off += ((size_t)lworkers * m.head_len + 3) & ~size_t(3);  // GEMM slabs start 16-byte aligned
   {
     LossArgs a{};
     a.cols = p->cols_dev; a.chunks = p->chunks_dev; a.params = params; a.y = w.y; a.batch = *batch;
@@ -981,13 +991,15 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     }
     // ---- prior gradients: per-component column sums of prior_terms, out[c][k] (k_prior_colsum) ----
     {
-      const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components;
-      const int ldc = round_up(Nt + 1, 4);
-      const int splits = prior_colsum_blocks(B);
-      if (int rc = launch_prior_colsum(w.prior_terms, ldT, w.kidx, B, Mt, Nt, ldc, w.slab + slab_off, s)) return rc;
+      const int Mt = prior_Mt, Nt = m.n_components;
+      const int ldc = prior_ldc;
+      const int splits = fuse_colsum ? reparam_grid(B) : prior_colsum_blocks(B);
+      const size_t src_off = fuse_colsum ? prior_slab_off : slab_off;  // fused: k_reparam wrote the slabs already
+      if (!fuse_colsum)
+        if (int rc = launch_prior_colsum(w.prior_terms, ldT, w.kidx, B, Mt, Nt, ldc, w.slab + slab_off, s)) return rc;
       SUAVE_REQUIRE(red.n_segs + 4 <= kMaxReduceSegs, "too many reduction segments");
       ReduceSeg sm{};  // prior.mu[k][d] = out[d][k]
-      sm.src_off = (int64_t)slab_off; sm.slab_stride = (int64_t)Mt * ldc; sm.n_slabs = splits;
+      sm.src_off = (int64_t)src_off; sm.slab_stride = (int64_t)Mt * ldc; sm.n_slabs = splits;
       sm.rows = D; sm.cols = K; sm.src_ld = ldc; sm.dst_off = m.prior_mu_off; sm.dst_si = 1; sm.dst_sj = D;
       red.segs[red.n_segs++] = sm;
       ReduceSeg sv = sm;  // prior.logvar[k][d] = out[D + d][k]
@@ -997,7 +1009,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
       sl.src_off += (int64_t)2 * D * ldc + K; sl.rows = K; sl.cols = 1; sl.dst_off = m.prior_logits_off;
       sl.dst_si = 1; sl.dst_sj = 1;
       red.segs[red.n_segs++] = sl;
-      slab_off += (size_t)splits * Mt * ldc;
+      if (!fuse_colsum) slab_off += (size_t)splits * Mt * ldc;
     }
     // ---- likelihood-head weights ----
     {
@@ -1025,9 +1037,12 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     {
       LatentBwdArgs a{};
       a.sel = w.sel; a.ldS = ldS; a.K = K; a.D = D; a.ldK = p->ldK; a.ldD = p->ldD;
-      a.n_rows = B; a.n_chunks = n_parts; a.ysoft = w.ysoft; a.kidx = w.kidx; a.eps_buf = w.eps; a.dz = w.dz;
-      a.ds_part = w.ds_part; a.gkl_logit = w.gkl_logit; a.gkl_mu = w.gkl_mu; a.gkl_lv = w.gkl_lv; a.tau = tau_c;
+      a.n_rows = B; a.n_chunks = n_parts; a.ysoft = w.ysoft; a.kidx = w.kidx; a.dz = w.dz;
+      a.ds_part = w.ds_part; a.gkl_logit = w.gkl_logit; a.tau = tau_c;
       a.dsel = w.dsel;
+      a.params = params; a.prior_mu_off = m.prior_mu_off; a.prior_logvar_off = m.prior_logvar_off;
+      a.bk = beta_scale / (float)global_rows; a.row_index = batch->row_index; a.row_begin = batch->row_begin;
+      a.eps_in = nz->eps; a.seed = nz->seed; a.step = nz->step;
       if (int rc = launch_latent_bwd(a, s)) return rc;
     }
     // ---- encoder head backward (grouped by component) ----

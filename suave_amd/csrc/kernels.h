@@ -57,7 +57,6 @@ struct LatentFwdArgs {
   float* ysoft;   // [B, ldK]
   int32_t* kidx;  // [B]
   float* z;       // [B, ldD]
-  float* eps_buf; // [B, ldD] (eps actually used; read back by the backward)
   float* latent_out;    // [B, D] or null
   int32_t* comp_out;    // [B] or null
   // rows sorted by component (stable): rank of the row inside its 256-row block, per-block counts
@@ -72,9 +71,9 @@ struct LatentFwdArgs {
   float* catkl;         // [B]
   float* gausskl;       // [B]
   float* gkl_logit;     // [B, ldK]
-  float* gkl_mu;        // [B, ldD]
-  float* gkl_lv;        // [B, ldD]
   float* prior_terms;   // [B, ldT]: d/d prior_mu_k | d/d prior_logvar_k | d/d prior_logits
+  float* prior_slab;    // [gridDim.x, 2D + K, prior_ldc]: the block's per-component column sums of the prior terms
+  int prior_ldc;        //   (column k: rows of component k, column K: all rows), replacing prior_terms + k_prior_colsum
   double* sums_slab;    // [gridDim.x, 4]: (0, sum cat KL, sum gauss KL, 0) per block
 };
 
@@ -104,14 +103,19 @@ struct LatentBwdArgs {
   int ldS, K, D, ldK, ldD, n_rows, n_chunks;
   const float* ysoft;
   const int32_t* kidx;
-  const float* eps_buf;
   const float* dz;         // [B, ldD]
   const float* ds_part;    // [n_chunks, ldK, B]  (plane-major)
   const float* gkl_logit;  // [B, ldK]  d loss/d logits from the categorical KL
-  const float* gkl_mu;     // [B, ldD]
-  const float* gkl_lv;     // [B, ldD]
   float tau;
   float* dsel;             // [B, ldS] gradient in the compact head layout (pads zero)
+  // eps and both Gaussian-KL gradients are recomputed (k_reparam's generator call and expressions), not stored
+  const float* params;
+  int prior_mu_off, prior_logvar_off;
+  float bk;
+  const int32_t* row_index;
+  int64_t row_begin;
+  const float* eps_in;     // [B, D] injected eps or null -> the counter generator of k_reparam
+  uint64_t seed, step;
 };
 
 // dst[dst_off + i*dst_si + j*dst_sj] = sum_s src[src_off + s*slab_stride + i*src_ld + j]
@@ -200,6 +204,8 @@ int launch_mix_fwd(const MixFwdArgs& a, hipStream_t s);
 int launch_mix_finalize(const MixFinArgs& a, bool grad, int grid, hipStream_t s);
 int launch_colsum(const float* src, int ld, int n_rows, int n_cols, float* slab, int n_blocks, hipStream_t s);
 int prior_colsum_blocks(int n_rows);
+bool reparam_colsum_ok(int K, int D);    // prior column sums inside k_reparam (LDS tile fits)
+
 int launch_prior_colsum(const float* terms, int ldT, const int32_t* kidx, int n_rows, int n_cols, int K, int ldc, float* slab,
                         hipStream_t s);  // per-component column sums, slabs [blocks][n_cols][ldc]
 

@@ -195,25 +195,28 @@ __global__ __launch_bounds__(256) void k_assign(LatentFwdArgs a) {
   if (tid < a.K) a.blk_cnt[(size_t)blockIdx.x * a.K + tid] = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
 }
 
-// Counting sort, pass 2 (one block): per-component totals -> chunk table (every component's rows start on
-// a chunk boundary) and the first sorted position of each (block, component) run.
+// Counting sort, pass 2 (one block): the exclusive prefix of every component's counts over the blocks (the start of
+// each (block, component) run WITHIN the component) and, from the totals, the chunk table (every component's rows
+// start on a chunk boundary).  One block, so the kernel is a latency chain: it is one load round (sixteen
+// components' counts of 256 blocks in flight per round), the shuffles, one store round -- the component's first
+// sorted position, chunk_begin[c] * kGroupRows, is added by the scatter pass instead of a second read-modify-write
+// sweep over blk_base here (13 -> 7 us).
 __global__ __launch_bounds__(256) void k_group_scan(GroupArgs a) {
-  __shared__ int tot[SUAVE_MAX_COMPONENTS], seg[SUAVE_MAX_COMPONENTS];
-  __shared__ int wtot[8][4];
+  constexpr int KU = 16;
+  __shared__ int tot[SUAVE_MAX_COMPONENTS];
+  __shared__ int wtot[KU][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // exclusive prefix over the blocks, 8 components at a time (their count loads are independent: one memory round
-  // trip per 8 components instead of one per component), 256 blocks per round
-  for (int c0 = 0; c0 < a.K; c0 += 8) {
-    int carry[8];
+  for (int c0 = 0; c0 < a.K; c0 += KU) {
+    int carry[KU];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) carry[u] = 0;
+    for (int u = 0; u < KU; ++u) carry[u] = 0;
     for (int b0 = 0; b0 < a.n_blocks; b0 += 256) {
       const int b = b0 + tid;
-      int v[8], incl[8];
+      int v[KU], incl[KU];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (c0 + u < a.K && b < a.n_blocks) ? a.blk_cnt[(size_t)b * a.K + c0 + u] : 0;
+      for (int u = 0; u < KU; ++u) v[u] = (c0 + u < a.K && b < a.n_blocks) ? a.blk_cnt[(size_t)b * a.K + c0 + u] : 0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < KU; ++u) {
         int x = v[u];
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void k_group_scan(GroupArgs a) {
       }
       __syncthreads();
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < KU; ++u) {
         int woff = 0;
         for (int w = 0; w < wave; ++w) woff += wtot[u][w];
         if (c0 + u < a.K && b < a.n_blocks) a.blk_base[(size_t)b * a.K + c0 + u] = carry[u] + woff + incl[u] - v[u];
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void k_group_scan(GroupArgs a) {
     }
     if (tid == 0) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < KU; ++u)
         if (c0 + u < a.K) tot[c0 + u] = carry[u];
     }
   }
@@ -246,43 +249,29 @@ __global__ __launch_bounds__(256) void k_group_scan(GroupArgs a) {
     for (int c = 0; c < a.K; ++c) {
       cb[c] = ch;
       a.chunk_begin[c] = ch;
-      seg[c] = ch * kGroupRows;
       ch = min(ch + (tot[c] + kGroupRows - 1) / kGroupRows, a.n_chunks_max);
     }
     cb[a.K] = ch;
     a.chunk_begin[a.K] = ch;
   }
   __syncthreads();
-  // chunk -> component table, one chunk per thread (a single thread writing it entry by entry was most of this
-  // kernel's time)
+  // chunk -> component table, one chunk per thread
   for (int ch = tid; ch < a.n_chunks_max; ch += 256) {
     int comp = -1;
     for (int c = 0; c < a.K; ++c)
       if (ch >= cb[c] && ch < cb[c + 1]) comp = c;
     a.chunk_comp[ch] = comp;
   }
-  // 16 independent read-modify-writes per thread and pass (a plain loop waits for every load before its store:
-  // one memory round trip per 256 entries)
-  const int total = a.n_blocks * a.K;
-  for (int base = 0; base < total; base += 256 * 16) {
-    int v[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int i = base + q * 256 + tid;
-      v[q] = i < total ? a.blk_base[i] : 0;
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int i = base + q * 256 + tid;
-      if (i < total) a.blk_base[i] = v[q] + seg[i % a.K];
-    }
-  }
 }
 
-// Counting sort, pass 3: sorted position of every row.
+// Counting sort, pass 3: sorted position of every row = first position of its component's chunks + start of its
+// block's run within the component + rank within the run.
 __global__ __launch_bounds__(256) void k_group_scatter(GroupArgs a) {
   const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r < a.n_rows) a.perm[a.blk_base[(size_t)blockIdx.x * a.K + a.kidx[r]] + a.lrank[r]] = r;
+  if (r < a.n_rows) {
+    const int k = a.kidx[r];
+    a.perm[a.chunk_begin[k] * kGroupRows + a.blk_base[(size_t)blockIdx.x * a.K + k] + a.lrank[r]] = r;
+  }
 }
 
 // supervised, step 2 (4 lanes per row): z = mu_k + eps * exp(lv_k / 2) from the selected component's head
@@ -290,6 +279,21 @@ __global__ __launch_bounds__(256) void k_group_scatter(GroupArgs a) {
 __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
   extern __shared__ float prior_s[];  // [K*D] prior mu | [K*D] prior logvar | [K*D] +-1 / max(exp(logvar), 1e-6)
   __shared__ float red_s[8];
+  // Prior gradients without the [B, 2D + K] round trip through HBM: the 64 rows' terms go to an LDS tile; thread
+  // (row group g, term column c) walks its rows in order and adds each term to the LDS accumulator of the row's
+  // component (a thread owns its accumulators: no atomics, fixed order); the row groups are combined in order into
+  // the block's slab, and the per-block slabs are summed by the fixed-order reduction, as k_prior_colsum's were.
+  __shared__ int kk_s[64];
+  const bool colsum = a.grad && a.prior_slab != nullptr;
+  const int n_terms = 2 * a.D + a.K;
+  const int kTS = n_terms | 1;                     // odd row stride of the tile
+  const int KP = a.K | 1;                          // odd accumulator stride
+  const int RG = max(1, 256 / n_terms);            // row groups
+  float* terms_s = prior_s + 3 * a.K * a.D;        // [64][kTS], present when colsum (launch_reparam sizes the LDS)
+  float* acc_s = terms_s + 64 * kTS;               // [RG][n_terms][KP]
+  float* slab = colsum ? a.prior_slab + (size_t)blockIdx.x * n_terms * a.prior_ldc : nullptr;
+  if (colsum)
+    for (int i = threadIdx.x; i < RG * n_terms * KP; i += 256) acc_s[i] = 0.f;  // (the combine re-zeroes what it reads)
   const Philox rng(a.seed);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K, D = a.D;
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
             if (q * 4 + e < D) ev[e] = a.eps_in[(size_t)r * D + q * 4 + e];
         }
         const float mv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, lvv[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
-        float zz[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {0.f, 0.f, 0.f, 0.f}, gl[4] = {0.f, 0.f, 0.f, 0.f}, pl2[4] = {0.f, 0.f, 0.f, 0.f};
+        float zz[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {0.f, 0.f, 0.f, 0.f}, pl2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int d = q * 4 + e;
@@ -355,17 +359,21 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
           const float quad = (elv + diff * diff) * ivp;
           gk += 0.5f * (plvd - lvc + quad - 1.0f);
           gm[e] = a.bk * diff * ivp;
-          gl[e] = a.bk * 0.5f * (elv * ivp - 1.0f);
           pl2[e] = a.bk * 0.5f * (1.0f - (ivp_sg > 0.f ? quad : 0.f));  // max(exp(lv_p), 1e-6) passes gradient above its floor only
         }
         if (vec) {
           *reinterpret_cast<float4*>(a.z + (size_t)r * a.ldD + q * 4) = make_float4(zz[0], zz[1], zz[2], zz[3]);
-          *reinterpret_cast<float4*>(a.eps_buf + (size_t)r * a.ldD + q * 4) = make_float4(ev[0], ev[1], ev[2], ev[3]);
           if (a.grad) {
-            *reinterpret_cast<float4*>(a.gkl_mu + (size_t)r * a.ldD + q * 4) = make_float4(gm[0], gm[1], gm[2], gm[3]);
-            *reinterpret_cast<float4*>(a.gkl_lv + (size_t)r * a.ldD + q * 4) = make_float4(gl[0], gl[1], gl[2], gl[3]);
-            *reinterpret_cast<float4*>(a.prior_terms + (size_t)r * a.ldT + q * 4) = make_float4(-gm[0], -gm[1], -gm[2], -gm[3]);
-            *reinterpret_cast<float4*>(a.prior_terms + (size_t)r * a.ldT + D + q * 4) = make_float4(pl2[0], pl2[1], pl2[2], pl2[3]);
+            if (colsum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                terms_s[lr * kTS + q * 4 + e] = -gm[e];
+                terms_s[lr * kTS + D + q * 4 + e] = pl2[e];
+              }
+            } else {
+              *reinterpret_cast<float4*>(a.prior_terms + (size_t)r * a.ldT + q * 4) = make_float4(-gm[0], -gm[1], -gm[2], -gm[3]);
+              *reinterpret_cast<float4*>(a.prior_terms + (size_t)r * a.ldT + D + q * 4) = make_float4(pl2[0], pl2[1], pl2[2], pl2[3]);
+            }
           }
         } else {
 #pragma unroll
@@ -373,12 +381,14 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
             const int d = q * 4 + e;
             if (d >= D) break;
             a.z[(size_t)r * a.ldD + d] = zz[e];
-            a.eps_buf[(size_t)r * a.ldD + d] = ev[e];
             if (a.grad) {
-              a.gkl_mu[(size_t)r * a.ldD + d] = gm[e];
-              a.gkl_lv[(size_t)r * a.ldD + d] = gl[e];
-              a.prior_terms[(size_t)r * a.ldT + d] = -gm[e];
-              a.prior_terms[(size_t)r * a.ldT + D + d] = pl2[e];
+              if (colsum) {
+                terms_s[lr * kTS + d] = -gm[e];
+                terms_s[lr * kTS + D + d] = pl2[e];
+              } else {
+                a.prior_terms[(size_t)r * a.ldT + d] = -gm[e];
+                a.prior_terms[(size_t)r * a.ldT + D + d] = pl2[e];
+              }
             }
           }
         }
@@ -409,7 +419,8 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
           const float logq = lg[j] - lq, logp = pl[j] - lp;
           const float q = __expf(logq);
           a.gkl_logit[(size_t)r * a.ldK + j] = a.bk * q * ((logq - logp) - ck);
-          a.prior_terms[(size_t)r * a.ldT + 2 * D + j] = a.bk * (__expf(logp) - q);
+          if (colsum) terms_s[lr * kTS + 2 * D + j] = a.bk * (__expf(logp) - q);
+          else a.prior_terms[(size_t)r * a.ldT + 2 * D + j] = a.bk * (__expf(logp) - q);
         }
       }
       a.catkl[r] = ck;
@@ -417,9 +428,47 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
     }
     const float t_c = wave_sum((v4 && qd == 0) ? ck : 0.f);
     const float t_g = wave_sum((v4 && qd == 0) ? gk : 0.f);
+    if (colsum && qd == 0) kk_s[lr] = v4 ? kk : -1;
     __syncthreads();
     if (lane == 0) { red_s[wave * 2] = t_c; red_s[wave * 2 + 1] = t_g; }
+    if (colsum) {
+      const int g = tid / n_terms;
+      if (g < RG) {
+        for (int c = tid - g * n_terms; c < n_terms; c += 256) {  // (more than 256 term columns: RG = 1, several per thread)
+          float* my = acc_s + ((size_t)g * n_terms + c) * KP;
+          for (int rr = g; rr < 64; rr += RG) {
+            const int kr = kk_s[rr];
+            if (kr >= 0) my[kr] += terms_s[rr * kTS + c];
+          }
+        }
+      }
+    }
     __syncthreads();
+    if (colsum) {  // row groups in order -> slab[c][k] (c < 2 D: per component; the K logits terms: all rows, column K)
+      const bool first = r0 == (int)blockIdx.x * 64;  // later tiles of the block add to its slab (same thread, same address)
+      for (int o = tid; o < 2 * D * K + K; o += 256) {
+        const bool per_comp = o < 2 * D * K;
+        const int c = per_comp ? o / K : 2 * D + (o - 2 * D * K);
+        float t = 0.f;
+        if (per_comp) {
+          const int kq = o - c * K;
+          for (int q = 0; q < RG; ++q) {
+            float* src = acc_s + ((size_t)q * n_terms + c) * KP + kq;
+            t += *src;
+            *src = 0.f;
+          }
+        } else {
+          for (int kq = 0; kq < K; ++kq)
+            for (int q = 0; q < RG; ++q) {
+              float* src = acc_s + ((size_t)q * n_terms + c) * KP + kq;
+              t += *src;
+              *src = 0.f;
+            }
+        }
+        float* dst = slab + (size_t)c * a.prior_ldc + (per_comp ? o - c * K : K);
+        *dst = first ? t : *dst + t;
+      }
+    }
     if (tid == 0) {
       sum_cat += (double)red_s[0] + (double)red_s[2] + (double)red_s[4] + (double)red_s[6];
       sum_gauss += (double)red_s[1] + (double)red_s[3] + (double)red_s[5] + (double)red_s[7];
@@ -439,8 +488,19 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
   __shared__ float ds_s[64 * kDsStride];
   __shared__ float ys_s[64 * kDsStride];
   __shared__ float inner_s[64];
+  extern __shared__ float lprior_s[];  // recompute: [K*D] prior mu | [K*D] 1 / max(exp(prior logvar), 1e-6)
   const int tid = threadIdx.x;
   const int K = a.K;
+  // eps and the two Gaussian-KL gradients are recomputed here (same generator call, same expressions as k_reparam)
+  // instead of being stored by the forward and read back: 6 x [B, ldD] floats of traffic for one more read of mu.
+  const float* pm_s = lprior_s;
+  const float* ivp_s = lprior_s + K * a.D;
+  const Philox rng(a.seed);
+  for (int i = tid; i < K * a.D; i += 256) {
+    lprior_s[i] = a.params[a.prior_mu_off + i];
+    const float vp_raw = __expf(a.params[a.prior_logvar_off + i]);
+    lprior_s[K * a.D + i] = vp_raw >= 1e-6f ? 1.0f / vp_raw : 1e6f;
+  }
   for (int r0 = blockIdx.x * 64; r0 < a.n_rows; r0 += gridDim.x * 64) {
     const int nrows = min(64, a.n_rows - r0);
     __syncthreads();
@@ -485,12 +545,13 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
       const int lr = idx / nqd, d = (idx - lr * nqd) * 4;
       const int r = r0 + lr;
       const float4 g4 = *reinterpret_cast<const float4*>(a.dz + (size_t)r * a.ldD + d);
-      const float4 m4 = *reinterpret_cast<const float4*>(a.gkl_mu + (size_t)r * a.ldD + d);
-      const float g[4] = {g4.x, g4.y, g4.z, g4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+      const float4 mu4 = *reinterpret_cast<const float4*>(a.sel + (size_t)r * a.ldS + a.ldK + d);
+      const int pk = a.kidx[r] * a.D + d;
+      const float g[4] = {g4.x, g4.y, g4.z, g4.w}, mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
       float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (d + e < a.D) v[e] = g[e] + mm[e];
+        if (d + e < a.D) v[e] = g[e] + a.bk * (mu[e] - pm_s[pk + e]) * ivp_s[pk + e];
       *reinterpret_cast<float4*>(a.dsel + (size_t)r * a.ldS + a.ldK + d) = make_float4(v[0], v[1], v[2], v[3]);
     }
     for (int idx = tid; idx < nrows * nqd; idx += 256) {  // ---- selected logvar: dz * eps * exp(lv / 2) / 2 + KL
@@ -499,10 +560,24 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
       const int q = a.ldK + a.ldD + d;
       const float4 g4 = *reinterpret_cast<const float4*>(a.dz + (size_t)r * a.ldD + d);
       const float4 raw4 = *reinterpret_cast<const float4*>(a.sel + (size_t)r * a.ldS + q);
-      const float4 eps4 = *reinterpret_cast<const float4*>(a.eps_buf + (size_t)r * a.ldD + d);
-      const float4 l4 = *reinterpret_cast<const float4*>(a.gkl_lv + (size_t)r * a.ldD + d);
       const float g[4] = {g4.x, g4.y, g4.z, g4.w}, raw[4] = {raw4.x, raw4.y, raw4.z, raw4.w};
-      const float eps[4] = {eps4.x, eps4.y, eps4.z, eps4.w}, ll[4] = {l4.x, l4.y, l4.z, l4.w};
+      float eps[4] = {0.f, 0.f, 0.f, 0.f}, ll[4] = {0.f, 0.f, 0.f, 0.f};
+      {
+        if (a.eps_in == nullptr) {
+          const uint32_t rid = a.row_index ? (uint32_t)a.row_index[r] : (uint32_t)(a.row_begin + r);
+          const uint4 w = rng(rid, (uint32_t)(d >> 2), kStreamEps, (uint32_t)a.step);
+          const float2 n0 = normal2(w.x, w.y), n1 = normal2(w.z, w.w);
+          eps[0] = n0.x; eps[1] = n0.y; eps[2] = n1.x; eps[3] = n1.y;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (d + e < a.D) eps[e] = a.eps_in[(size_t)r * a.D + d + e];
+        }
+        const int pk = a.kidx[r] * a.D + d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)  // inside the clamp range (the only place ll is used) the clamped logvar is raw
+          if (d + e < a.D) ll[e] = a.bk * 0.5f * (__expf(raw[e]) * ivp_s[pk + e] - 1.0f);
+      }
       float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int e = 0; e < 4; ++e)  // clamp passes gradient inside its range only
@@ -971,10 +1046,23 @@ int launch_group(const GroupArgs& a, hipStream_t s) {
 
 int reparam_grid(int n_rows) { return std::max(1, std::min((n_rows + 63) / 64, 1024)); }
 
+// LDS budgets of the fused paths (48 KB of dynamic LDS without a function attribute); beyond them the step stores
+// prior_terms / eps / the KL gradients and runs k_prior_colsum, as before
+static size_t reparam_colsum_floats(int K, int D) {
+  const int n_terms = 2 * D + K;
+  return 64 * (size_t)(n_terms | 1) + (size_t)std::max(1, 256 / n_terms) * n_terms * (K | 1);
+}
+bool reparam_colsum_ok(int K, int D) { return sizeof(float) * (3 * (size_t)K * D + reparam_colsum_floats(K, D)) <= 48 * 1024; }
+
 int launch_reparam(const LatentFwdArgs& a, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
   ProfScope prof_scope(kProfLatent, s);
-  hipLaunchKernelGGL(k_reparam, dim3(reparam_grid(a.n_rows)), dim3(256), sizeof(float) * 3 * a.K * a.D, s, a);
+  size_t lds = sizeof(float) * 3 * a.K * a.D;
+  if (a.grad && a.prior_slab) {
+    SUAVE_REQUIRE(reparam_colsum_ok(a.K, a.D) && a.prior_ldc >= a.K + 1, "reparam: prior column sums do not fit the LDS tile");
+    lds += sizeof(float) * reparam_colsum_floats(a.K, a.D);
+  }
+  hipLaunchKernelGGL(k_reparam, dim3(reparam_grid(a.n_rows)), dim3(256), lds, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -993,7 +1081,9 @@ int launch_latent_bwd(const LatentBwdArgs& a, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
   const int grid = std::min((a.n_rows + 63) / 64, 2048);
   ProfScope prof_scope(kProfLatent, s);
-  hipLaunchKernelGGL(k_latent_bwd, dim3(grid), dim3(256), 0, s, a);
+  const size_t lds = sizeof(float) * 2 * a.K * a.D;  // prior mean and reciprocal variance tables
+  SUAVE_REQUIRE(lds <= 48 * 1024, "latent backward: the prior tables (2 K D floats) do not fit in LDS");
+  hipLaunchKernelGGL(k_latent_bwd, dim3(grid), dim3(256), lds, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -181,6 +181,55 @@ def test_w1024_miniature_step_matches_oracle(behaviour):
     _grad_check(eng.grad_state(), ref["grads"])
 
 
+@pytest.mark.parametrize("K,D,B", [(32, 100, 200), (7, 13, 333), (3, 4, 70000)])
+def test_latent_paths_match_oracle(K, D, B):
+    """The latent kernels' shapes against the CPU oracle: K x D beyond the LDS tile of the fused prior column sums
+    (prior terms stored, k_prior_colsum), everything fused with a latent width that is no multiple of four, and a
+    batch of more than 1024 tiles (a block of k_reparam then adds several tiles into its prior slab)."""
+
+    import torch
+    from suave_amd.engine import PackedTable
+
+    cols = s64_columns(8, real_variant="scaled")
+    hidden = (16,) if B > 1000 else (48, 32)
+    om = orc.OracleModel(cols, n_components=K, latent_dim=D, hidden=hidden, dropout=0.0)
+    P = om.init_params(seed=3)
+    rng = np.random.default_rng(11)
+    for k in P:
+        if ".heads." in k or "prior" in k:
+            P[k] = (0.3 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    xnum, codes, mask = synth_packed(cols, B, 0.1, seed=99)
+    x_enc, data, masks = orc.dense_from_packed(om, xnum, codes, mask)
+    noise = {"exp": rng.exponential(size=(B, K)).astype(np.float32), "eps": rng.standard_normal((B, D)).astype(np.float32)}
+    ref = orc.elbo_supervised(om, P, x_enc, data, masks, noise, beta_scale=1.5, tau=0.7, training=True)
+    eng = _engine(om, P)
+    table = PackedTable(xnum, codes, mask, eng.device)
+    res = eng.elbo(table, 0, B, beta_scale=1.5, tau=0.7, grad=True, noise=torch_noise(noise, eng.device),
+                   want=("reconstruction", "categorical_kl", "gaussian_kl", "latent", "component"))
+    torch.cuda.synchronize()
+    assert np.array_equal(res["component"].cpu().numpy().astype(np.int64), ref["component_indices"])
+    assert rel_err(res["categorical_kl"].cpu().numpy(), ref["categorical_kl"]) < TOL
+    assert rel_err(res["gaussian_kl"].cpu().numpy(), ref["gaussian_kl"]) < TOL
+    assert rel_err(res["latent"].cpu().numpy(), ref["latent"]) < TOL
+    _grad_check(eng.grad_state(), ref["grads"])
+    # In-kernel noise: the backward regenerates eps instead of reading it back.  Recover the forward's eps from
+    # z = mu_k + eps * exp(lv_k / 2) and inject it (Gumbel noise still from the generator, same seed / step): the
+    # gradients must agree with the all-in-kernel step.
+    if B <= 1000:
+        r1 = eng.elbo(table, 0, B, beta_scale=1.5, tau=0.7, grad=True, seed=5, step=3, want=("latent", "component", "enc_out"))
+        g1 = eng.grads.clone()
+        comp = r1["component"].long()
+        enc = r1["enc_out"]
+        rows = torch.arange(B, device=enc.device)
+        mu = enc[:, K:K + K * D].reshape(B, K, D)[rows, comp]
+        lv = enc[:, K + K * D:].reshape(B, K, D)[rows, comp].clamp(-15.0, 15.0)
+        eps = ((r1["latent"] - mu) * torch.exp(-0.5 * lv)).contiguous()
+        eng.elbo(table, 0, B, beta_scale=1.5, tau=0.7, grad=True, seed=5, step=3, noise={"eps": eps})
+        g2 = eng.grads.clone()
+        scale = g1.abs().max().item()
+        assert (g1 - g2).abs().max().item() < 2e-4 * scale
+
+
 def test_row_index_gather_and_determinism():
     """A permuted batch through row_index equals the contiguous batch of the permuted table, bit for bit,
     and two identical launches give bit-identical gradients (no float atomics anywhere)."""
