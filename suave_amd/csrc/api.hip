@@ -109,7 +109,7 @@ struct Workspace {
   float *log_px = nullptr, *log_px_missing = nullptr;  // caller's per-column outputs of this call (not carved)
   // selected-component encoder head (supervised branch)
   float *sel, *dsel, *gslab;
-  int32_t *perm, *lrank, *blk_cnt, *blk_base, *chunk_comp, *chunk_begin;
+  int32_t *perm, *lrank, *blk_cnt, *chunk_comp, *chunk_begin;
   int n_blocks, n_chunks_max;
   float* wideL;  // [rows, ldL] logits / logit gradients of the wide categorical columns
   float* wideT;  // row-major transposed copies of the wide heads' weights (WideCol::t_off), rewritten every backward
@@ -271,7 +271,6 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
     w->perm = c.take<int32_t>((size_t)w->n_chunks_max * kGroupRows);
     w->lrank = c.take<int32_t>(Rg);
     w->blk_cnt = c.take<int32_t>((size_t)w->n_blocks * m.n_components);
-    w->blk_base = c.take<int32_t>((size_t)w->n_blocks * m.n_components);
     w->chunk_comp = c.take<int32_t>(w->n_chunks_max);
     w->chunk_begin = c.take<int32_t>(m.n_components + 1);
     w->gslab = c.take<float>(sup ? (size_t)w->n_chunks_max * ldS * round_up(m.enc_head.n_in + 1, 4) : 1);
@@ -862,7 +861,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   la.lrank = w.lrank; la.blk_cnt = w.blk_cnt;
   GroupArgs ga{};
   ga.K = K; ga.n_rows = B; ga.n_blocks = w.n_blocks; ga.n_chunks_max = w.n_chunks_max; ga.kidx = w.kidx;
-  ga.lrank = w.lrank; ga.blk_cnt = w.blk_cnt; ga.blk_base = w.blk_base; ga.chunk_comp = w.chunk_comp;
+  ga.lrank = w.lrank; ga.blk_cnt = w.blk_cnt; ga.chunk_comp = w.chunk_comp;
   ga.chunk_begin = w.chunk_begin; ga.perm = w.perm;
   auto head_geometry = [&](GemmArgs& g) {
     g.perm = w.perm; g.chunk_comp = w.chunk_comp; g.hK = K; g.hD = D; g.hldK = p->ldK; g.hldD = p->ldD;
@@ -950,7 +949,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
                               w.sums_slab + ((size_t)lworkers * n_chunks + reparam_grid(B)) * 4, s))
       return rc;
   const float* recon_final = w.recon_part;
-  if (n_parts > 1) {
+  if (n_parts > 1 && out && out->reconstruction) {  // per-row reconstruction only on request (the sums have their own slabs)
     hipLaunchKernelGGL(k_sum_chunks, dim3(std::min((B + 255) / 256, 1024)), dim3(256), 0, s, w.recon_part, n_parts, B,
                        w.recon);
     SUAVE_CHECK_HIP(hipGetLastError());

@@ -83,7 +83,6 @@ struct GroupArgs {
   const int32_t* kidx;
   const int32_t* lrank;
   const int32_t* blk_cnt;
-  int32_t* blk_base;     // [n_blocks, K] first sorted position of block b's rows of component c
   int32_t* chunk_comp;   // [n_chunks_max] component of each chunk, -1 past the last one
   int32_t* chunk_begin;  // [K + 1] first chunk of each component
   int32_t* perm;         // [n_chunks_max * kGroupRows] sorted position -> row (pre-filled with -1)

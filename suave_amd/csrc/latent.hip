@@ -195,82 +195,61 @@ __global__ __launch_bounds__(256) void k_assign(LatentFwdArgs a) {
   if (tid < a.K) a.blk_cnt[(size_t)blockIdx.x * a.K + tid] = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
 }
 
-// Counting sort, pass 2 (one block): the exclusive prefix of every component's counts over the blocks (the start of
-// each (block, component) run WITHIN the component) and, from the totals, the chunk table (every component's rows
-// start on a chunk boundary).  One block, so the kernel is a latency chain: it is one load round (sixteen
-// components' counts of 256 blocks in flight per round), the shuffles, one store round -- the component's first
-// sorted position, chunk_begin[c] * kGroupRows, is added by the scatter pass instead of a second read-modify-write
-// sweep over blk_base here (13 -> 7 us).
-__global__ __launch_bounds__(256) void k_group_scan(GroupArgs a) {
-  constexpr int KU = 16;
-  __shared__ int tot[SUAVE_MAX_COMPONENTS];
-  __shared__ int wtot[KU][4];
+// Counting sort, passes 2 + 3 in one launch.  Every block works out for itself where its runs start: wave w takes
+// components w, w + 4, ..., its lanes the blocks' counts (one strided load round per component, all hits in L2:
+// the table is n_blocks x K ints), two shuffles trees give the component's rows below this block and its total.  From
+// the totals every block derives the same chunk table (each component's rows start on a chunk boundary); block 0
+// writes it out for the grouped GEMMs.  The sorted position of a row = first position of its component's chunks +
+// its block's start within the component + its rank within the block's run.  (This replaced a one-block scan
+// kernel, an 11 us latency chain, and its [n_blocks, K] table of starts.)
+__global__ __launch_bounds__(256) void k_group_scatter(GroupArgs a) {
+  __shared__ int below_s[SUAVE_MAX_COMPONENTS], tot_s[SUAVE_MAX_COMPONENTS], cb[SUAVE_MAX_COMPONENTS + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c0 = 0; c0 < a.K; c0 += KU) {
-    int carry[KU];
-#pragma unroll
-    for (int u = 0; u < KU; ++u) carry[u] = 0;
+  for (int c = wave; c < a.K; c += 4) {
+    int below = 0, tot = 0;
     for (int b0 = 0; b0 < a.n_blocks; b0 += 256) {
-      const int b = b0 + tid;
-      int v[KU], incl[KU];
+      int v[4];
 #pragma unroll
-      for (int u = 0; u < KU; ++u) v[u] = (c0 + u < a.K && b < a.n_blocks) ? a.blk_cnt[(size_t)b * a.K + c0 + u] : 0;
-#pragma unroll
-      for (int u = 0; u < KU; ++u) {
-        int x = v[u];
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const int t = __shfl_up(x, off, 64);
-          if (lane >= off) x += t;
-        }
-        incl[u] = x;
-        if (lane == 63) wtot[u][wave] = x;
+      for (int u = 0; u < 4; ++u) {
+        const int b = b0 + lane + 64 * u;
+        v[u] = b < a.n_blocks ? a.blk_cnt[(size_t)b * a.K + c] : 0;
       }
-      __syncthreads();
 #pragma unroll
-      for (int u = 0; u < KU; ++u) {
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wtot[u][w];
-        if (c0 + u < a.K && b < a.n_blocks) a.blk_base[(size_t)b * a.K + c0 + u] = carry[u] + woff + incl[u] - v[u];
-        carry[u] += wtot[u][0] + wtot[u][1] + wtot[u][2] + wtot[u][3];
+      for (int u = 0; u < 4; ++u) {
+        tot += v[u];
+        below += (b0 + lane + 64 * u) < (int)blockIdx.x ? v[u] : 0;
       }
-      __syncthreads();
     }
-    if (tid == 0) {
 #pragma unroll
-      for (int u = 0; u < KU; ++u)
-        if (c0 + u < a.K) tot[c0 + u] = carry[u];
+    for (int off = 32; off >= 1; off >>= 1) {
+      below += __shfl_xor(below, off, 64);
+      tot += __shfl_xor(tot, off, 64);
     }
+    if (lane == 0) { below_s[c] = below; tot_s[c] = tot; }
   }
   __syncthreads();
-  __shared__ int cb[SUAVE_MAX_COMPONENTS + 1];
   if (tid == 0) {
     int ch = 0;
     for (int c = 0; c < a.K; ++c) {
       cb[c] = ch;
-      a.chunk_begin[c] = ch;
-      ch = min(ch + (tot[c] + kGroupRows - 1) / kGroupRows, a.n_chunks_max);
+      ch = min(ch + (tot_s[c] + kGroupRows - 1) / kGroupRows, a.n_chunks_max);
     }
     cb[a.K] = ch;
-    a.chunk_begin[a.K] = ch;
   }
   __syncthreads();
-  // chunk -> component table, one chunk per thread
-  for (int ch = tid; ch < a.n_chunks_max; ch += 256) {
-    int comp = -1;
-    for (int c = 0; c < a.K; ++c)
-      if (ch >= cb[c] && ch < cb[c + 1]) comp = c;
-    a.chunk_comp[ch] = comp;
+  if (blockIdx.x == 0) {
+    if (tid <= a.K) a.chunk_begin[tid] = cb[tid];
+    for (int ch = tid; ch < a.n_chunks_max; ch += 256) {  // chunk -> component table
+      int comp = -1;
+      for (int c = 0; c < a.K; ++c)
+        if (ch >= cb[c] && ch < cb[c + 1]) comp = c;
+      a.chunk_comp[ch] = comp;
+    }
   }
-}
-
-// Counting sort, pass 3: sorted position of every row = first position of its component's chunks + start of its
-// block's run within the component + rank within the run.
-__global__ __launch_bounds__(256) void k_group_scatter(GroupArgs a) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.x * 256 + tid;
   if (r < a.n_rows) {
     const int k = a.kidx[r];
-    a.perm[a.chunk_begin[k] * kGroupRows + a.blk_base[(size_t)blockIdx.x * a.K + k] + a.lrank[r]] = r;
+    a.perm[cb[k] * kGroupRows + below_s[k] + a.lrank[r]] = r;
   }
 }
 
@@ -483,39 +462,116 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
 
 // Straight-through Gumbel path + the selected component's mu / logvar gradients in the compact head
 // layout: every other entry of d(enc_out) is zero and is never materialised.
+// The kernel is a latency chain (one 64-row tile per block at the bench batch), so every global load of a tile is
+// issued before anything waits: the assignment-gradient partials (four items x four chunks in flight per thread
+// instead of one load at a time), y_soft, the KL logits gradient, and the dz / mu / logvar quads of the two
+// Gaussian passes, which run as one pass (same quad, one dz load) ahead of the barriers of the softmax part.
 __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
   constexpr int kDsStride = SUAVE_MAX_COMPONENTS + 1;  // odd stride: lane = row accesses hit distinct banks
   __shared__ float ds_s[64 * kDsStride];
   __shared__ float ys_s[64 * kDsStride];
   __shared__ float inner_s[64];
-  extern __shared__ float lprior_s[];  // recompute: [K*D] prior mu | [K*D] 1 / max(exp(prior logvar), 1e-6)
+  extern __shared__ float lprior_s[];  // [K*D] prior mu | [K*D] 1 / max(exp(prior logvar), 1e-6)
   const int tid = threadIdx.x;
-  const int K = a.K;
+  const int K = a.K, D = a.D;
   // eps and the two Gaussian-KL gradients are recomputed here (same generator call, same expressions as k_reparam)
   // instead of being stored by the forward and read back: 6 x [B, ldD] floats of traffic for one more read of mu.
   const float* pm_s = lprior_s;
-  const float* ivp_s = lprior_s + K * a.D;
+  const float* ivp_s = lprior_s + K * D;
   const Philox rng(a.seed);
-  for (int i = tid; i < K * a.D; i += 256) {
+  for (int i = tid; i < K * D; i += 256) {
     lprior_s[i] = a.params[a.prior_mu_off + i];
     const float vp_raw = __expf(a.params[a.prior_logvar_off + i]);
-    lprior_s[K * a.D + i] = vp_raw >= 1e-6f ? 1.0f / vp_raw : 1e6f;
+    lprior_s[K * D + i] = vp_raw >= 1e-6f ? 1.0f / vp_raw : 1e6f;
   }
+  const float inv_tau = 1.0f / a.tau;
+  const int nqk = a.ldK >> 2, nqd = a.ldD >> 2;  // ldK and ldD are multiples of 4: a float4 never straddles regions
   for (int r0 = blockIdx.x * 64; r0 < a.n_rows; r0 += gridDim.x * 64) {
     const int nrows = min(64, a.n_rows - r0);
-    __syncthreads();
-    // ds_part is plane-major [chunk][j][row]: lane = row within a plane (coalesced), chunks summed in fixed order
-    for (int idx = tid; idx < 64 * K; idx += 256) {
-      const int j = idx >> 6, lr = idx & 63;
-      if (lr < nrows) {
-        float v = 0.f;
-        for (int c = 0; c < a.n_chunks; ++c) v += a.ds_part[((size_t)c * a.ldK + j) * a.n_rows + r0 + lr];
-        ds_s[lr * kDsStride + j] = v;
+    __syncthreads();  // prior tables staged; previous tile's LDS reads done
+    // ---- assignment-gradient partials: ds_part is plane-major [chunk][j][row], lane = row within a plane
+    // (coalesced), chunks summed in fixed order
+    for (int i0 = 0; i0 < 64 * K; i0 += 1024) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int c0 = 0; c0 < a.n_chunks; c0 += 4) {
+        float v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = i0 + tid + 256 * u;
+          const int j = idx >> 6, lr = idx & 63;
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const bool ok = idx < 64 * K && lr < nrows && c0 + cc < a.n_chunks;
+            v[u][cc] = ok ? a.ds_part[((size_t)(c0 + cc) * a.ldK + j) * a.n_rows + r0 + lr] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) acc[u] += v[u][cc];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + tid + 256 * u;
+        if (idx < 64 * K) ds_s[(idx & 63) * kDsStride + (idx >> 6)] = acc[u];
       }
     }
     for (int idx = tid; idx < nrows * K; idx += 256) {
       const int lr = idx / K, j = idx - lr * K;
       ys_s[lr * kDsStride + j] = a.ysoft[(size_t)(r0 + lr) * a.ldK + j];
+    }
+    // ---- selected mu: dz + KL;  selected logvar: dz * eps * exp(lv / 2) / 2 + KL -- two quads per trip, loads first
+    for (int i0 = 0; i0 < nrows * nqd; i0 += 512) {
+      float4 g4[2], mu4[2], raw4[2];
+      int kk[2], rr[2], dd[2];
+      uint32_t rid[2];
+      bool ok[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = i0 + tid + 256 * u;
+        ok[u] = idx < nrows * nqd;
+        const int lr = ok[u] ? idx / nqd : 0;
+        dd[u] = ok[u] ? (idx - lr * nqd) * 4 : 0;
+        rr[u] = r0 + lr;
+        g4[u] = *reinterpret_cast<const float4*>(a.dz + (size_t)rr[u] * a.ldD + dd[u]);
+        mu4[u] = *reinterpret_cast<const float4*>(a.sel + (size_t)rr[u] * a.ldS + a.ldK + dd[u]);
+        raw4[u] = *reinterpret_cast<const float4*>(a.sel + (size_t)rr[u] * a.ldS + a.ldK + a.ldD + dd[u]);
+        kk[u] = a.kidx[rr[u]];
+        rid[u] = a.row_index ? (uint32_t)a.row_index[rr[u]] : (uint32_t)(a.row_begin + rr[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = rr[u], d = dd[u];
+        const float g[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w}, mu[4] = {mu4[u].x, mu4[u].y, mu4[u].z, mu4[u].w};
+        const float raw[4] = {raw4[u].x, raw4[u].y, raw4[u].z, raw4[u].w};
+        float eps[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.eps_in == nullptr) {
+          const uint4 w = rng(rid[u], (uint32_t)(d >> 2), kStreamEps, (uint32_t)a.step);
+          const float2 n0 = normal2(w.x, w.y), n1 = normal2(w.z, w.w);
+          eps[0] = n0.x; eps[1] = n0.y; eps[2] = n1.x; eps[3] = n1.y;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (d + e < D) eps[e] = a.eps_in[(size_t)r * D + d + e];
+        }
+        const int pk = kk[u] * D + d;
+        float vm[4] = {0.f, 0.f, 0.f, 0.f}, vl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (d + e < D) {
+            const float ivp = ivp_s[pk + e];
+            vm[e] = g[e] + a.bk * (mu[e] - pm_s[pk + e]) * ivp;
+            // clamp passes gradient inside its range only (where the clamped logvar is the raw one)
+            if (raw[e] >= kLogvarMin && raw[e] <= kLogvarMax)
+              vl[e] = g[e] * eps[e] * 0.5f * __expf(0.5f * raw[e]) + a.bk * 0.5f * (__expf(raw[e]) * ivp - 1.0f);
+          }
+        }
+        if (ok[u]) {
+          float* dst = a.dsel + (size_t)r * a.ldS + a.ldK + d;
+          *reinterpret_cast<float4*>(dst) = make_float4(vm[0], vm[1], vm[2], vm[3]);
+          *reinterpret_cast<float4*>(dst + a.ldD) = make_float4(vl[0], vl[1], vl[2], vl[3]);
+        }
+      }
     }
     __syncthreads();
     if (tid < nrows) {
@@ -524,12 +580,6 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
       inner_s[tid] = inner;
     }
     __syncthreads();
-    const float inv_tau = 1.0f / a.tau;
-    // One float4 of one row per step (ldK and ldD are multiples of 4, so a float4 never straddles regions), one
-    // REGION per pass -- logits, mu, logvar -- so that a wave never diverges between the three load patterns (in a
-    // single pass over the 19 quads of a row the three branches ran one after the other, each waiting for its own
-    // global loads).
-    const int nqk = a.ldK >> 2, nqd = a.ldD >> 2;
     for (int idx = tid; idx < nrows * nqk; idx += 256) {  // ---- component logits: straight-through softmax + KL
       const int lr = idx / nqk, q = (idx - lr * nqk) * 4;
       const int r = r0 + lr;
@@ -539,50 +589,6 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (q + e < K) v[e] = ys_s[lr * kDsStride + q + e] * (ds_s[lr * kDsStride + q + e] - inner_s[lr]) * inv_tau + g4[e];
-      *reinterpret_cast<float4*>(a.dsel + (size_t)r * a.ldS + q) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    for (int idx = tid; idx < nrows * nqd; idx += 256) {  // ---- selected mu: dz + KL
-      const int lr = idx / nqd, d = (idx - lr * nqd) * 4;
-      const int r = r0 + lr;
-      const float4 g4 = *reinterpret_cast<const float4*>(a.dz + (size_t)r * a.ldD + d);
-      const float4 mu4 = *reinterpret_cast<const float4*>(a.sel + (size_t)r * a.ldS + a.ldK + d);
-      const int pk = a.kidx[r] * a.D + d;
-      const float g[4] = {g4.x, g4.y, g4.z, g4.w}, mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (d + e < a.D) v[e] = g[e] + a.bk * (mu[e] - pm_s[pk + e]) * ivp_s[pk + e];
-      *reinterpret_cast<float4*>(a.dsel + (size_t)r * a.ldS + a.ldK + d) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    for (int idx = tid; idx < nrows * nqd; idx += 256) {  // ---- selected logvar: dz * eps * exp(lv / 2) / 2 + KL
-      const int lr = idx / nqd, d = (idx - lr * nqd) * 4;
-      const int r = r0 + lr;
-      const int q = a.ldK + a.ldD + d;
-      const float4 g4 = *reinterpret_cast<const float4*>(a.dz + (size_t)r * a.ldD + d);
-      const float4 raw4 = *reinterpret_cast<const float4*>(a.sel + (size_t)r * a.ldS + q);
-      const float g[4] = {g4.x, g4.y, g4.z, g4.w}, raw[4] = {raw4.x, raw4.y, raw4.z, raw4.w};
-      float eps[4] = {0.f, 0.f, 0.f, 0.f}, ll[4] = {0.f, 0.f, 0.f, 0.f};
-      {
-        if (a.eps_in == nullptr) {
-          const uint32_t rid = a.row_index ? (uint32_t)a.row_index[r] : (uint32_t)(a.row_begin + r);
-          const uint4 w = rng(rid, (uint32_t)(d >> 2), kStreamEps, (uint32_t)a.step);
-          const float2 n0 = normal2(w.x, w.y), n1 = normal2(w.z, w.w);
-          eps[0] = n0.x; eps[1] = n0.y; eps[2] = n1.x; eps[3] = n1.y;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (d + e < a.D) eps[e] = a.eps_in[(size_t)r * a.D + d + e];
-        }
-        const int pk = a.kidx[r] * a.D + d;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)  // inside the clamp range (the only place ll is used) the clamped logvar is raw
-          if (d + e < a.D) ll[e] = a.bk * 0.5f * (__expf(raw[e]) * ivp_s[pk + e] - 1.0f);
-      }
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int e = 0; e < 4; ++e)  // clamp passes gradient inside its range only
-        if (d + e < a.D && raw[e] >= kLogvarMin && raw[e] <= kLogvarMax)
-          v[e] = g[e] * eps[e] * 0.5f * __expf(0.5f * raw[e]) + ll[e];
       *reinterpret_cast<float4*>(a.dsel + (size_t)r * a.ldS + q) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
@@ -1038,7 +1044,6 @@ int launch_group(const GroupArgs& a, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
   ProfScope prof_scope(kProfLatent, s);
   SUAVE_CHECK_HIP(hipMemsetAsync(a.perm, 0xFF, sizeof(int32_t) * (size_t)a.n_chunks_max * kGroupRows, s));
-  hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_group_scatter, dim3(a.n_blocks), dim3(256), 0, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
