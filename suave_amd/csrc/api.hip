@@ -505,7 +505,9 @@ int wide_forward(const suave_plan* p, const float* params, const Workspace& w, i
   if (int rc = launch_wide_fill(a, s)) return rc;
   if (int rc = launch_gemm_wide(wide_gemm_args(p, params, w, rows, 0), 0, s)) return rc;
   if (recon_out == nullptr) return 0;
-  return launch_wide_softmax(a, grad, s);
+  int wide_max_classes = 2;
+  for (const suave::WideCol& wc : p->wide_host) wide_max_classes = std::max(wide_max_classes, (int)wc.C);
+  return launch_wide_softmax(a, grad, wide_max_classes, s);
 }
 
 // Backward part: weight-gradient slabs (one reduction segment mirroring the weight region), data gradient into

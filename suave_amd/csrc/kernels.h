@@ -194,7 +194,7 @@ struct WideRowArgs {
 };
 int launch_wide_fill(const WideRowArgs& a, hipStream_t s);
 int wide_softmax_grid(int n_rows);
-int launch_wide_softmax(const WideRowArgs& a, bool grad, hipStream_t s);
+int launch_wide_softmax(const WideRowArgs& a, bool grad, int max_classes, hipStream_t s);  // max_classes: over the wide columns
 int launch_wide_ds(const WideRowArgs& a, hipStream_t s);
 // wT[t_off + n * round_up(C-1, 4) + k] = W[k][n] for every wide column (pad columns zero)
 int launch_wide_transpose(const WideCol* cols, int n_wide, const float* params, float* wT, hipStream_t s);

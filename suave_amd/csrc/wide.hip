@@ -86,6 +86,113 @@ __global__ __launch_bounds__(256) void k_wide_softmax(WideRowArgs a) {
   }
 }
 
+// The same, register-resident and software-pipelined (every wide column of the schema has at most 1024 * NS / 4
+// classes): a lane owns classes 4 lane .. 4 lane + 3 of each 256-class slot, so a column's logits are ONE 16-byte
+// load per lane and slot, read once, kept in registers for the maximum, the exponential sum and the gradient, and
+// written once (the first kernel read them three times, each a dependent round trip: 4.2 us per row and column).
+// The next column's descriptor, cell, logits and observed-class logit are loaded before the current column's
+// reductions start.  Pad classes of a column's 4-aligned slot are written as zeros.
+template <bool GRAD, int NS>
+__global__ __launch_bounds__(256) void k_wide_softmax_reg(WideRowArgs a) {
+  __shared__ double blk_sum[4];
+  extern __shared__ int wtab_s[];  // [n_wide][3]: schema column, classes, logits offset
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < a.n_wide; i += 256) {
+    wtab_s[3 * i] = a.wide[i].col;
+    wtab_s[3 * i + 1] = a.wide[i].C;
+    wtab_s[3 * i + 2] = a.wide[i].l_off;
+  }
+  __syncthreads();
+  const float4 ninf4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  double wsum = 0.0;
+  for (int r = blockIdx.x * 4 + wave; r < a.n_rows; r += gridDim.x * 4) {
+    const int drow = a.vdiv == 1 ? r : r / a.vdiv;
+    const int32_t* cell_ptr = a.cells + ((size_t)(drow >> 6) * a.n_cols) * 64 + (drow & 63);
+    const float up = GRAD ? a.c_up * (a.row_weight ? a.row_weight[r] : 1.0f) : 0.f;
+    float* Lrow = a.L + (size_t)r * a.ldL;
+    float recon = 0.f;
+    // column 0 in flight; every trip sends the next column's loads before its own reductions (the last trip re-reads
+    // its own column).  Two columns ahead was slower (1.65 vs 1.42 ms at W1024): the kernel is then on the memory
+    // system, 4.4 GB at 3.1 TB/s of mixed reads and writes in 600-byte pieces.
+    int col, C, loff, code, ncol, nC, nloff, ncode;
+    float xs, nxs;
+    float4 cur[NS], nxt[NS];
+#define SUAVE_WIDE_FETCH(cc, col_, C_, loff_, code_, xs_, buf_)                                          \
+    {                                                                                                    \
+      const int ci_ = min((cc), a.n_wide - 1);                                                           \
+      col_ = wtab_s[3 * ci_]; C_ = wtab_s[3 * ci_ + 1]; loff_ = wtab_s[3 * ci_ + 2];                      \
+      const int cell_ = cell_ptr[(size_t)col_ * 64];                                                     \
+      code_ = cell_ != kCellMissing ? cell_ : -1;                                                        \
+      xs_ = (code_ >= 1 && code_ < C_) ? Lrow[loff_ + code_ - 1] : 0.f;                                  \
+      _Pragma("unroll") for (int sl = 0; sl < NS; ++sl) {                                                \
+        const int i4 = 256 * sl + 4 * lane;                                                              \
+        buf_[sl] = i4 < C_ - 1 ? *reinterpret_cast<const float4*>(Lrow + loff_ + i4) : ninf4;            \
+      }                                                                                                  \
+    }
+    SUAVE_WIDE_FETCH(0, col, C, loff, code, xs, cur)
+    for (int c = 0; c < a.n_wide; ++c) {
+      SUAVE_WIDE_FETCH(c + 1, ncol, nC, nloff, ncode, nxs, nxt)
+      const bool live = code >= 0 && code < C;
+      const int n = C - 1;
+      float v[NS][4];
+      float mx = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) {
+        const int i4 = 256 * sl + 4 * lane;
+        v[sl][0] = cur[sl].x; v[sl][1] = cur[sl].y; v[sl][2] = cur[sl].z; v[sl][3] = cur[sl].w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (i4 + e >= n) v[sl][e] = -INFINITY;  // pad classes of the last quad
+          mx = fmaxf(mx, v[sl][e]);
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      float se = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) se += __expf(v[sl][e] - mx);
+      se = wave_sum(se) + __expf(-mx);
+      const float lse = mx + __logf(se);
+      const float lp = live ? xs - lse : 0.f;  // (class 0: logit 0; masked cell: all-zero one-hot, 0)
+      recon += lp;
+      if (lane == 0 && a.log_px) a.log_px[(size_t)r * a.n_cols + col] = lp;
+      if (lane == 0 && a.log_px_missing) a.log_px_missing[(size_t)r * a.n_cols + col] = 0.f;
+      if (GRAD) {
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+          const int i4 = 256 * sl + 4 * lane;
+          float g[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float p = __expf(v[sl][e] - lse);
+            g[e] = (live && i4 + e < n) ? up * ((i4 + e + 1 == code ? 1.0f : 0.f) - p) : 0.f;
+          }
+          if (i4 < n) *reinterpret_cast<float4*>(Lrow + loff + i4) = make_float4(g[0], g[1], g[2], g[3]);
+        }
+      }
+      col = ncol; C = nC; loff = nloff; code = ncode; xs = nxs;
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) cur[sl] = nxt[sl];
+    }
+#undef SUAVE_WIDE_FETCH
+    if (lane == 0) {
+      a.recon_out[r] = recon;
+      wsum += (double)recon;
+    }
+  }
+  if (a.sums_slab) {
+    if (lane == 0) blk_sum[wave] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double* s = a.sums_slab + (size_t)blockIdx.x * 4;
+      s[0] = ((blk_sum[0] + blk_sum[1]) + blk_sum[2]) + blk_sum[3];
+      s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+    }
+  }
+}
+
 // After the data-gradient GEMM the slots hold d loss / d [y_col ; s].  The assignment part is summed over
 // the wide columns into ds_out[r, 0..K) (the straight-through path needs the full K-vector, SURVEY.md
 // Appendix A) and cleared, so that the slots' pad rows of y_projection see a zero gradient.
@@ -132,12 +239,23 @@ int launch_wide_fill(const WideRowArgs& a, hipStream_t s) {
 
 int wide_softmax_grid(int n_rows) { return wide_grid(n_rows, 4, 4096); }
 
-int launch_wide_softmax(const WideRowArgs& a, bool grad, hipStream_t s) {
+int launch_wide_softmax(const WideRowArgs& a, bool grad, int max_classes, hipStream_t s) {
   if (a.n_rows <= 0 || a.n_wide <= 0) return 0;
   ProfScope prof_scope(kProfLoss, s);
   const dim3 grid(wide_softmax_grid(a.n_rows)), block(256);
-  if (grad) hipLaunchKernelGGL(k_wide_softmax<true>, grid, block, 0, s, a);
+  const int nmax = a.n_wide <= 4000 ? max_classes - 1 : 1 << 30;  // logits per column (column table: 12 bytes each in LDS)
+  const size_t tab = sizeof(int) * 3 * a.n_wide;
+#define SUAVE_WIDE_SOFTMAX(NS)                                                              \
+  do {                                                                                      \
+    if (grad) hipLaunchKernelGGL((k_wide_softmax_reg<true, NS>), grid, block, tab, s, a);   \
+    else hipLaunchKernelGGL((k_wide_softmax_reg<false, NS>), grid, block, tab, s, a);       \
+  } while (0)
+  if (nmax <= 256) SUAVE_WIDE_SOFTMAX(1);
+  else if (nmax <= 512) SUAVE_WIDE_SOFTMAX(2);
+  else if (nmax <= 1024) SUAVE_WIDE_SOFTMAX(4);
+  else if (grad) hipLaunchKernelGGL(k_wide_softmax<true>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(k_wide_softmax<false>, grid, block, 0, s, a);
+#undef SUAVE_WIDE_SOFTMAX
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -230,6 +230,37 @@ def test_latent_paths_match_oracle(K, D, B):
         assert (g1 - g2).abs().max().item() < 2e-4 * scale
 
 
+@pytest.mark.parametrize("classes", [(40, 300), (700, 17), (1200, 260)])
+def test_wide_softmax_class_counts_match_oracle(classes):
+    """Wide categorical columns beyond 256 classes: the register-resident log-softmax holds one, two or four quads of
+    logits per lane (<= 256 / 512 / 1024 logits per column); wider columns take the streaming kernel."""
+
+    import torch
+    from suave_amd.engine import PackedTable
+
+    cols = [orc.Column("r0", "real", stats={"mean": 0.0, "std": 1.0})]
+    cols += [orc.Column(f"c{i}", "cat", n_classes=c) for i, c in enumerate(classes)]
+    cols += [orc.Column("o0", "ordinal", n_classes=5)]
+    K, D, B = 4, 8, 150
+    om = orc.OracleModel(cols, n_components=K, latent_dim=D, hidden=(32, 24), dropout=0.0)
+    P = om.init_params(seed=3)
+    rng = np.random.default_rng(8)
+    for k in P:
+        if ".heads." in k:
+            P[k] = (0.3 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    xnum, codes, mask = synth_packed(cols, B, 0.1, seed=31)
+    x_enc, data, masks = orc.dense_from_packed(om, xnum, codes, mask)
+    noise = {"exp": rng.exponential(size=(B, K)).astype(np.float32), "eps": rng.standard_normal((B, D)).astype(np.float32)}
+    ref = orc.elbo_supervised(om, P, x_enc, data, masks, noise, beta_scale=1.0, tau=1.0, training=True)
+    eng = _engine(om, P)
+    table = PackedTable(xnum, codes, mask, eng.device)
+    res = eng.elbo(table, 0, B, beta_scale=1.0, tau=1.0, grad=True, noise=torch_noise(noise, eng.device),
+                   want=("reconstruction", "log_px"))
+    torch.cuda.synchronize()
+    assert rel_err(res["reconstruction"].cpu().numpy(), ref["reconstruction"]) < TOL
+    _grad_check(eng.grad_state(), ref["grads"])
+
+
 def test_row_index_gather_and_determinism():
     """A permuted batch through row_index equals the contiguous batch of the permuted table, bit for bit,
     and two identical launches give bit-identical gradients (no float atomics anywhere)."""
