@@ -308,12 +308,16 @@ int suave_decode_params(const suave_plan* plan, const float* params, const float
 
 /* Arithmetic of the matrix products (no counterpart in the reference, which
  * multiplies in fp32 through torch: suave/modules/encoder.py:49-53,
- * decoder.py:300-318).  Mode 3 (default): every fp32 operand is cut into three
- * bf16 planes and six plane products accumulate in fp32 on the bf16 MFMA --
- * fp32-grade results.  Mode 0: the exact-fp32 MFMA
- * everywhere.  Process-wide; the environment variable SUAVE_GEMM_SPLIT gives
- * the initial value.  Do not switch while a call of this library is running on
- * another thread. */
+ * decoder.py:300-318).  All modes take fp32 in, accumulate in fp32 and give
+ * fp32-grade results.  Mode 4 (default): every fp32
+ * operand is cut into two fp16 planes, x = hi + lo * 2^-11, and three plane
+ * products run on the fp16 MFMA; operands must stay within fp16's range,
+ * |x| <= 65504 (a larger activation gives inf / NaN outputs, never a silently
+ * wrong number).  Mode 3: three bf16 planes, six products on the bf16 MFMA
+ * (fp32's full exponent range, twice the matrix-pipe time).  Mode 0: the
+ * exact-fp32 MFMA everywhere.  Process-wide; the environment variable
+ * SUAVE_GEMM_SPLIT gives the initial value.  Do not switch while a call of this
+ * library is running on another thread. */
 int suave_gemm_arithmetic_set(int mode);
 int suave_gemm_arithmetic_get(int* mode);
 

@@ -311,7 +311,17 @@ GemmArgs gemm_base() {
   std::memset(&g, 0, sizeof(g));
   g.ones_col = -1;
   g.splits = 1;
+  g.a_scale = 1.0f;
   return g;
+}
+
+// Arithmetic mode 4 (fp16 planes): gradient operands are ~1 / batch rows; the backward GEMMs multiply them by this
+// power of two before the split (GemmArgs::a_scale) so that they stay clear of the fp16 subnormals.  Set per step.
+thread_local float t_grad_scale = 1.0f;
+float grad_scale_for(int64_t global_rows) {
+  int e = 0;
+  while (e < 16 && (int64_t(2) << e) <= global_rows) ++e;
+  return std::ldexp(1.0f, e);
 }
 
 // forward layer: C = epi(A * W^T + b)
@@ -400,6 +410,7 @@ GemmArgs bwd_data_args(const float* params, const suave_layer_t& l, const float*
   g.epi = H ? kEpiMaskBwd : kEpiBias;
   g.H = H;
   g.drop_p = drop_p;
+  g.a_scale = t_grad_scale;
   return g;
 }
 
@@ -409,6 +420,7 @@ int bwd_weight_args(const suave_plan* p, const suave_layer_t& l, const float* dC
   const int ldc = round_up(l.n_in + 1, 4);
   const int splits = tn_splits(p, l.n_out, l.n_in, rows);
   GemmArgs g = gemm_base();
+  g.a_scale = t_grad_scale;
   g.A = dC; g.B = A; g.C = slab_base + *slab_off;
   g.M = l.n_out; g.N = l.n_in; g.K = rows;
   g.lda = lddc; g.ldb = lda; g.ldc = ldc;
@@ -492,6 +504,7 @@ WideGemmArgs wide_gemm_args(const suave_plan* p, const float* params, const Work
   g.cols = p->wide_dev; g.cum = p->wide_cum_dev[mode]; g.n_wide = (int)p->wide_host.size();
   g.cum_total = p->wide_cum_total[mode]; g.params = params; g.y = w.y; g.ldY = p->ldY; g.L = w.wideL; g.ldL = p->ldL;
   g.rows = rows; g.K = p->model.n_components; g.splits = 1; g.slab_stride = p->wide_len; g.wide_w0 = p->wide_w0;
+  g.grad_scale = t_grad_scale;
   return g;
 }
 
@@ -800,6 +813,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   const suave_model_t& m = p->model;
   SUAVE_REQUIRE(dlatent == nullptr || m.behaviour == 0, "dlatent is only defined for the supervised branch (model.py:1987-1991)");
   SUAVE_REQUIRE(global_rows >= 1, "global_rows must be positive");
+  t_grad_scale = grad_scale_for(global_rows);
   if (batch->n_rows == 0) {  // an empty shard still owes its gradient (zero) and its event to the all-reduce
     if (grads) SUAVE_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * m.n_params, s));
     if (ready_event) SUAVE_CHECK_HIP(hipEventRecord(ready_event, s));
@@ -1054,7 +1068,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
       g.A = w.dsel; g.B = hlast_e; g.C = w.gslab;
       g.M = ldS; g.N = l.n_in; g.K = Vg; g.lda = ldS; g.ldb = ldhe_last; g.ldc = ldc;
       g.a_kmajor = 1; g.b_kmajor = 1; g.epi = kEpiSlab; g.splits = w.n_chunks_max;
-      g.slab_stride = (int64_t)ldS * ldc; g.ones_col = l.n_in; g.grouped = 2;
+      g.slab_stride = (int64_t)ldS * ldc; g.ones_col = l.n_in; g.grouped = 2; g.a_scale = t_grad_scale;
       head_geometry(g);
       GemmArgs d = gemm_base();  // d h = dsel * W[rows of the row's component], relu/dropout mask of h
       if (nh > 0) {

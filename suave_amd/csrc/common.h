@@ -228,6 +228,9 @@ struct GemmArgs {
   const int32_t* perm;        // sorted position -> batch row, -1 = padding
   const int32_t* chunk_comp;  // chunk of kGroupRows sorted positions -> component, -1 = unused chunk
   int hK, hD, hldK, hldD, q0;
+  float a_scale;              // arithmetic mode 4 (fp16 planes): power of two the A operand is multiplied by before it is
+                              // cut into planes (gradient operands are ~1 / batch rows: keeps them clear of the fp16
+                              // subnormals); the product is scaled back in the epilogue.  <= 0 means 1.
 };
 
 // Sorted positions are handed out in chunks of kGroupRows rows of one component (multiple of every GEMM row tile).
@@ -264,6 +267,7 @@ struct WideGemmArgs {
   int splits;
   int wide_w0;
   const float* wT;      // mode 1, split arithmetic: transposed weights (WideCol::t_off)
+  float grad_scale;     // modes 1 and 2: GemmArgs::a_scale of the logit gradients
 };
 int launch_gemm_wide(const WideGemmArgs& a, int mode, hipStream_t stream);
 int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t stream);

@@ -8,7 +8,10 @@
 //   data grad    dA[B,K]  = dC[B,N]  * W[N,K]     (B operand k-major)
 //   weight grad  dW[N,K]  = dC[B,N]^T * A[B,K]    (both operands k-major, split over B)
 // Arithmetic (suave_gemm_arithmetic_set), fp32 in / fp32 accumulate / fp32 out either way:
-//   mode 3 (default): every fp32 operand element is cut into three bf16 planes when its tile is stored to LDS and
+//   mode 4 (default): two fp16 planes, x = hi + lo' * 2^-11, three plane products on v_mfma_f32_32x32x16_f16, the two
+//           cross products in a second accumulator set added with weight 2^-11 (see split_planes() below): half the
+//           matrix-pipe time of mode 3 at the same measured accuracy; operands within fp16's range;
+//   mode 3: every fp32 operand element is cut into three bf16 planes when its tile is stored to LDS and
 //           the six plane products with i + j <= 2 run on v_mfma_f32_32x32x16_bf16 -- the error of an fp32 FMA
 //           chain (the parity bar is 1e-4 on gradients, which plain bf16 inputs do not hold) at 6/16 of the fp32
 //           MFMA's matrix-pipe time; row-major forms read [row][16 k] plane images with one ds_read_b128 per
@@ -30,6 +33,8 @@ namespace suave {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -68,11 +73,21 @@ __device__ __forceinline__ uint32_t drop_row_hash(uint32_t key, uint32_t row_id)
 // ds_read_b64_tr_b16 (compute()).  split_row_bytes sizes that image: (128 + 128) x 40 = 2 x 16 x 320 bytes a plane.
 // (Tried and dropped: an unpadded, XOR-swizzled image -- 48 KB, three blocks per CU -- needs the 168-register
 // budget, where these kernels spill 108 bytes per lane.)
+//
+// SPLIT = 4 (arithmetic mode 4): TWO fp16 planes, x = hi + lo' * 2^-11 with hi = fp16(x) and lo' = fp16((x - hi) * 2^11)
+// (22 significand bits; the residual is scaled so that it does not fall into the fp16 subnormals), and THREE products
+// on v_mfma_f32_32x32x16_f16: hi*hi into the main accumulators, hi*lo' + lo'*hi into a second set that is added with
+// weight 2^-11 after the K loop -- half the matrix-pipe time of the three-plane bf16 split, two thirds of its LDS
+// traffic, at the same measured accuracy (scripts/split_emulate.py: worst gradient error 4e-7 .. 1e-6 of the tensor
+// scale on the S64 step, where the two-plane bf16 split is 5e-2 off).  fp16's range is the price: |x| <= 65504 (a larger
+// operand gives inf / NaN, loudly), and gradient operands are pre-scaled by a power of two (GemmArgs::a_scale).
+constexpr int split_planes(int split) { return split == 4 ? 2 : split; }
+constexpr float kF16LoScale = 2048.0f, kF16LoInv = 1.0f / 2048.0f;
 constexpr int split_row_bytes(bool any_km) { return any_km ? 2 * BK + 8 : 2 * BK; }
 template <int WAVES_M, int WAVES_N, int SPLIT = 0, bool KM = false>
 constexpr int gemm_smem_floats() {
   constexpr int f32 = 2 * BK * ((WAVES_M * 64 + PAD) + (WAVES_N * 64 + PAD));
-  constexpr int spl = 2 * SPLIT * (WAVES_M * 64 + WAVES_N * 64) * split_row_bytes(KM) / 4;
+  constexpr int spl = 2 * split_planes(SPLIT) * (WAVES_M * 64 + WAVES_N * 64) * split_row_bytes(KM) / 4;
   return f32 > spl ? f32 : spl;
 }
 
@@ -87,8 +102,21 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const unsigned char* p) {
 }
 
 template <int NS>
-__device__ __forceinline__ void split4(const float4 v, bf16x4 (&p)[NS > 0 ? NS : 1]) {
+__device__ __forceinline__ void split4(const float4 v, float scale, bf16x4 (&p)[split_planes(NS) > 0 ? split_planes(NS) : 1]) {
   float r[4] = {v.x, v.y, v.z, v.w};
+  if constexpr (NS == 4) {  // fp16 hi + scaled fp16 residual (the planes travel as 16-bit patterns in the bf16 types)
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = r[e] * scale;
+      const _Float16 h = (_Float16)x;  // round to nearest even
+      hi[e] = h;
+      lo[e] = (_Float16)((x - (float)h) * kF16LoScale);  // x - h is exact in fp32
+    }
+    p[0] = __builtin_bit_cast(bf16x4, hi);
+    p[1] = __builtin_bit_cast(bf16x4, lo);
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
 #pragma unroll
@@ -107,6 +135,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
                 "split mode: both operands row-major, or both k-major on the 128x128 tile");
   constexpr int kSplitRowBytes = split_row_bytes(A_KM);
   constexpr bool KM_SPLIT = SPLIT > 0 && A_KM;
+  constexpr int NP = split_planes(SPLIT);  // LDS plane images per operand tile
+  const float a_scale = (SPLIT == 4 && a.a_scale > 0.f) ? a.a_scale : 1.0f;
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   constexpr int kKmRowBytes = 2 * BM + 64;  // k-major split tiles: one k row of BM bf16 features + 64 bytes
   static_assert(!KM_SPLIT || 2 * BK * kKmRowBytes == (BM + BN) * kSplitRowBytes, "plane size of the k-major image");
@@ -224,7 +254,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   };
   // split mode: plane s of buffer `buf`, A rows then B rows
   auto plane = [&](int buf, int s) {
-    return reinterpret_cast<unsigned char*>(smem) + (size_t)((buf * (SPLIT > 0 ? SPLIT : 1) + s) * (BM + BN)) * kSplitRowBytes;
+    return reinterpret_cast<unsigned char*>(smem) + (size_t)((buf * (NP > 0 ? NP : 1) + s) * (BM + BN)) * kSplitRowBytes;
   };
   // `masked` (std::true_type / std::false_type, split paths only): false skips the zero-fill selects.  Zeros are only
   // owed past k_end (both operands: garbage there would reach every output) and, in the grouped form, in the rows of
@@ -266,10 +296,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
             v.z = lim > 2 ? v.z : 0.f;
             v.w = lim > 3 ? v.w : 0.f;
           }
-          bf16x4 pl[SPLIT > 0 ? SPLIT : 1];
-          split4<SPLIT>(v, pl);
+          bf16x4 pl[NP > 0 ? NP : 1];
+          split4<SPLIT>(v, op == 0 ? a_scale : 1.0f, pl);
 #pragma unroll
-          for (int s = 0; s < SPLIT; ++s)
+          for (int s = 0; s < NP; ++s)
             *reinterpret_cast<bf16x4*>(plane(buf, s) + (size_t)(op * BK + kr + 8 * p) * kKmRowBytes + fq * 8) = pl[s];
         }
       }
@@ -291,13 +321,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
             v.z = lim > 2 ? v.z : 0.f;
             v.w = lim > 3 ? v.w : 0.f;
           }
-          bf16x4 pl[SPLIT > 0 ? SPLIT : 1];
-          split4<SPLIT>(v, pl);
+          bf16x4 pl[NP > 0 ? NP : 1];
+          split4<SPLIT>(v, isA ? a_scale : 1.0f, pl);
           // the 16-byte halves of a row swap places in every second group of 8 rows: the 16 lanes one ds_read_b128
           // cycle serves (rows 0-3, 12-15, 20-27 / 4-11, 16-19, 28-31) then cover all 64 banks
           const int kbyte = (((kq >> 1) ^ ((row >> 3) & 1)) << 4) | ((kq & 1) << 3);
 #pragma unroll
-          for (int s = 0; s < SPLIT; ++s)
+          for (int s = 0; s < NP; ++s)
             *reinterpret_cast<bf16x4*>(plane(buf, s) + (size_t)((isA ? 0 : BM) + row) * kSplitRowBytes + kbyte) = pl[s];
         }
       }
@@ -350,12 +380,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   };
 
   f32x16 acc[2][2];
+  f32x16 accx[SPLIT == 4 ? 2 : 1][SPLIT == 4 ? 2 : 1];  // mode 4: the two cross products (weight 2^-11)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if constexpr (SPLIT == 4) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[i][j][r] = 0.f;
+  }
 
   // A wave whose 64x64 tile lies entirely outside the matrix skips the MFMAs (wave-uniform); partly
   // outside sub-tiles multiply the zero rows the LDS store wrote (one straight-line MFMA stream).
@@ -372,12 +411,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
     if constexpr (SPLIT > 0) {
       {  // (no `act` test here: a wave outside the matrix multiplies tiles nobody stores; its block waits at the
          // barrier for the other waves anyway, and the K step stays one basic block the scheduler can interleave)
-        bf16x8 fa[SPLIT > 0 ? SPLIT : 1][2], fb[SPLIT > 0 ? SPLIT : 1][2];
+        bf16x8 fa[NP > 0 ? NP : 1][2], fb[NP > 0 ? NP : 1][2];
         // fragments are fetched plane by plane and the plane products run in the order hi*hi, hi*mid, mid*hi,
         // mid*mid, hi*lo, lo*hi: the first MFMAs wait for four ds_read_b128 only, the rest of the fetch lands
         // behind them
 #pragma unroll
-        for (int s = 0; s < SPLIT; ++s)
+        for (int s = 0; s < NP; ++s)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             if constexpr (KM_SPLIT) {
@@ -399,7 +438,25 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
               fb[s][i] = *reinterpret_cast<const bf16x8*>(pb);
             }
           }
-        constexpr int kPairs = SPLIT == 3 ? 6 : 3;
+        if constexpr (SPLIT == 4) {
+          auto h8 = [](const bf16x8& v) { return __builtin_bit_cast(f16x8, v); };
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(fa[0][i]), h8(fb[0][j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(fa[0][i]), h8(fb[1][j]), accx[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(fa[1][i]), h8(fb[0][j]), accx[i][j], 0, 0, 0);
+        }
+        constexpr int kPairs = SPLIT == 4 ? 0 : SPLIT == 3 ? 6 : 3;
         constexpr int pa_[6] = {0, 0, 1, 1, 0, 2}, pb_[6] = {0, 1, 0, 1, 2, 0};
         constexpr int qa_[3] = {0, 0, 1}, qb_[3] = {0, 1, 0};
 #pragma unroll
@@ -417,11 +474,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
         if (bias_blk && tid < 128) {
           const int fq = tid & 31, kg = tid >> 5;
 #pragma unroll
-          for (int s = 0; s < SPLIT; ++s)
+          for (int s = 0; s < NP; ++s)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const bf16x4 v = *reinterpret_cast<const bf16x4*>(plane(buf, s) + (size_t)(kg * 4 + r) * kKmRowBytes + fq * 8);
-              kbias4.x += (float)v[0]; kbias4.y += (float)v[1]; kbias4.z += (float)v[2]; kbias4.w += (float)v[3];
+              if constexpr (SPLIT == 4) {
+                const f16x4 h = __builtin_bit_cast(f16x4, v);
+                const float wgt = s == 0 ? 1.0f : kF16LoInv;
+                kbias4.x += (float)h[0] * wgt; kbias4.y += (float)h[1] * wgt; kbias4.z += (float)h[2] * wgt; kbias4.w += (float)h[3] * wgt;
+              } else {
+                kbias4.x += (float)v[0]; kbias4.y += (float)v[1]; kbias4.z += (float)v[2]; kbias4.w += (float)v[3];
+              }
             }
         }
       }
@@ -514,6 +577,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
     __syncthreads();
   }
   if (t < nk) compute(0);
+  }
+
+  if constexpr (SPLIT == 4) {  // main + cross * 2^-11, and the A operand's pre-scale taken out again (powers of two: exact)
+    const float inv_scale = 1.0f / a_scale;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] + accx[i][j][r] * kF16LoInv) * inv_scale;
+    kbias4.x *= inv_scale; kbias4.y *= inv_scale; kbias4.z *= inv_scale; kbias4.w *= inv_scale;
   }
 
   // ---- epilogue -------------------------------------------------------------
@@ -671,7 +745,7 @@ __device__ __forceinline__ void xcd_split_order(int lin, int T, int S, int* tile
 }
 
 template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int GRP, int EPI, int SPLIT = 0>
-__global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, SPLIT == 4 ? 2 : SPLIT > 0 ? 3 : 1) void gemm_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<WAVES_M, WAVES_N, SPLIT, A_KM>()];
   __shared__ int perm_s[GRP == 2 ? kGroupRows : 1];
   int tile = blockIdx.x, split = blockIdx.z;
@@ -703,7 +777,7 @@ __global__ __launch_bounds__(256, (D_SPLIT > 0 || WG_SPLIT > 0) ? 2 : 1) void ge
 // All wide categorical columns in one launch: a block looks up its column in the tile prefix table and runs
 // the ordinary tile body on that column's operands.
 template <int MODE, int SPLIT = 0>
-__global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_wide_kernel(WideGemmArgs w) {
+__global__ __launch_bounds__(256, SPLIT == 4 ? 2 : SPLIT > 0 ? 3 : 1) void gemm_wide_kernel(WideGemmArgs w) {
   __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<2, 2, SPLIT, MODE == 2>()];
   __shared__ int perm_s[1];
   const int tiles_m = MODE == 2 ? 1 : (w.rows + 127) / 128;
@@ -720,6 +794,7 @@ __global__ __launch_bounds__(256, SPLIT > 0 ? 3 : 1) void gemm_wide_kernel(WideG
   g.bias = nullptr; g.H = nullptr; g.keep = nullptr; g.row_ids = nullptr; g.row_begin = 0;
   g.splits = 1; g.slab_stride = 0; g.ones_col = -1; g.drop_p = 0.f; g.seed = 0; g.step = 0; g.stream_id = 0;
   g.grouped = 0; g.perm = nullptr; g.chunk_comp = nullptr; g.hK = g.hD = g.hldK = g.hldD = g.q0 = 0;
+  g.row_vdiv = 0; g.a_scale = MODE == 0 ? 1.0f : w.grad_scale;
   float* slot = w.y + wc.y_off;
   float* logit = w.L + wc.l_off;
   const float* wt = w.params + wc.w_off;
@@ -759,11 +834,15 @@ int launch_gemm_wide(const WideGemmArgs& a, int mode, hipStream_t stream) {
   const int64_t blocks = (int64_t)a.cum_total * tiles_m;
   SUAVE_REQUIRE(blocks > 0 && blocks < (int64_t(1) << 31), "wide gemm: grid out of range");
   const dim3 grid((unsigned)blocks, 1, mode == 2 ? a.splits : 1), block(256);
-  if (mode == 0 && split_mode() == 3) hipLaunchKernelGGL((gemm_wide_kernel<0, 3>), grid, block, 0, stream, a);
+  const int sp = split_mode();
+  if (mode == 0 && sp == 4) hipLaunchKernelGGL((gemm_wide_kernel<0, 4>), grid, block, 0, stream, a);
+  else if (mode == 0 && sp == 3) hipLaunchKernelGGL((gemm_wide_kernel<0, 3>), grid, block, 0, stream, a);
   else if (mode == 0) hipLaunchKernelGGL(gemm_wide_kernel<0>, grid, block, 0, stream, a);
-  else if (mode == 1 && split_mode() == 3 && a.wT != nullptr) hipLaunchKernelGGL((gemm_wide_kernel<1, 3>), grid, block, 0, stream, a);
+  else if (mode == 1 && sp == 4 && a.wT != nullptr) hipLaunchKernelGGL((gemm_wide_kernel<1, 4>), grid, block, 0, stream, a);
+  else if (mode == 1 && sp == 3 && a.wT != nullptr) hipLaunchKernelGGL((gemm_wide_kernel<1, 3>), grid, block, 0, stream, a);
   else if (mode == 1) hipLaunchKernelGGL(gemm_wide_kernel<1>, grid, block, 0, stream, a);
-  else if (split_mode() == 3) hipLaunchKernelGGL((gemm_wide_kernel<2, 3>), grid, block, 0, stream, a);
+  else if (sp == 4) hipLaunchKernelGGL((gemm_wide_kernel<2, 4>), grid, block, 0, stream, a);
+  else if (sp == 3) hipLaunchKernelGGL((gemm_wide_kernel<2, 3>), grid, block, 0, stream, a);
   else hipLaunchKernelGGL(gemm_wide_kernel<2>, grid, block, 0, stream, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
@@ -791,14 +870,16 @@ int check_gemm(const GemmArgs& a) {
   return 0;
 }
 inline bool gemm_narrow(const GemmArgs& a) { return a.N <= 64; }
-// SUAVE_GEMM_SPLIT = 3 (default: fp32-accurate three-plane split on the bf16 MFMA) or 0 (exact-fp32 MFMA
-// everywhere).  Only the row-major forms have a split kernel.  A two-plane split (three products, 14 % faster on
-// the whole step) was measured and dropped: 5e-6 per GEMM on well-scaled data, but 5e-2 on the decoder weight
-// gradients of the std = 12 real columns, whose dY spans three decades within a row (scripts/split_accuracy.py).
+// SUAVE_GEMM_SPLIT = 4 (default: two fp16 planes, scaled residual, three products), 3 (three bf16 planes, six
+// products) or 0 (exact-fp32 MFMA everywhere).  Only the row-major forms and the 128x128 k-major form have split
+// kernels.  A two-plane BF16 split (three products) was measured in round 1 and dropped: 5e-6 per GEMM on
+// well-scaled data, but 5e-2 on the decoder weight gradients of the std = 12 real columns, whose dY spans three
+// decades within a row (16 significand bits); the fp16 pair keeps 22 bits and measures like mode 3
+// (scripts/split_accuracy.py on the GPU, scripts/split_emulate.py on the CPU).
 std::atomic<int>& split_mode_cell() {
   static std::atomic<int> mode{[] {
     const char* e = getenv("SUAVE_GEMM_SPLIT");
-    return (e && atoi(e) == 0) ? 0 : 3;
+    return (e && atoi(e) == 0) ? 0 : (e && atoi(e) == 3) ? 3 : 4;
   }()};
   return mode;
 }
@@ -810,7 +891,8 @@ inline int gemm_tiles(const GemmArgs& a) {
 
 int gemm_split_mode() { return split_mode(); }
 int gemm_split_mode_set(int mode) {
-  SUAVE_REQUIRE(mode == 0 || mode == 3, "gemm: the arithmetic mode is 0 (exact-fp32 MFMA) or 3 (three bf16 planes)");
+  SUAVE_REQUIRE(mode == 0 || mode == 3 || mode == 4,
+                "gemm: the arithmetic mode is 0 (exact-fp32 MFMA), 3 (three bf16 planes) or 4 (two fp16 planes)");
   split_mode_cell().store(mode, std::memory_order_relaxed);
   return 0;
 }
@@ -833,7 +915,10 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   } while (0)
 #define SUAVE_GEMM_LAUNCH_RM(GRP, EPI) /* row-major operands: exact fp32 or split bf16 */                       \
   do {                                                                                                          \
-    if (sp == 3) {                                                                                              \
+    if (sp == 4) {                                                                                              \
+      if (narrow) hipLaunchKernelGGL((gemm_kernel<4, 1, false, false, GRP, EPI, 4>), grid, block, 0, stream, args); \
+      else hipLaunchKernelGGL((gemm_kernel<2, 2, false, false, GRP, EPI, 4>), grid, block, 0, stream, args);    \
+    } else if (sp == 3) {                                                                                       \
       if (narrow) hipLaunchKernelGGL((gemm_kernel<4, 1, false, false, GRP, EPI, 3>), grid, block, 0, stream, args); \
       else hipLaunchKernelGGL((gemm_kernel<2, 2, false, false, GRP, EPI, 3>), grid, block, 0, stream, args);    \
     } else SUAVE_GEMM_LAUNCH(false, false, GRP, EPI);                                                           \
@@ -851,7 +936,8 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   else if (!a.a_kmajor && a.b_kmajor && e == kEpiBias) SUAVE_GEMM_LAUNCH(false, true, 0, kEpiBias);
   else if (!a.a_kmajor && a.b_kmajor && e == kEpiMaskBwd) SUAVE_GEMM_LAUNCH(false, true, 0, kEpiMaskBwd);
   else if (a.a_kmajor && a.b_kmajor && e == kEpiSlab) {
-    if (sp == 3 && !narrow) hipLaunchKernelGGL((gemm_kernel<2, 2, true, true, 0, kEpiSlab, 3>), grid, block, 0, stream, args);
+    if (sp == 4 && !narrow) hipLaunchKernelGGL((gemm_kernel<2, 2, true, true, 0, kEpiSlab, 4>), grid, block, 0, stream, args);
+    else if (sp == 3 && !narrow) hipLaunchKernelGGL((gemm_kernel<2, 2, true, true, 0, kEpiSlab, 3>), grid, block, 0, stream, args);
     else SUAVE_GEMM_LAUNCH(true, true, 0, kEpiSlab);
   } else SUAVE_REQUIRE(false, "gemm: unsupported operand layout / epilogue combination");
 #undef SUAVE_GEMM_LAUNCH_RM
@@ -893,14 +979,17 @@ int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t
     else SUAVE_PAIR(4, 1, DG, DE, 4, 1, WG, DS);            \
   } while (0)
   if (d.grouped == 1) {
-    if (split_mode() == 3) SUAVE_PAIR_SHAPES(1, kEpiMaskBwd, 2, 3);
+    if (split_mode() == 4) SUAVE_PAIR_SHAPES(1, kEpiMaskBwd, 2, 4);
+    else if (split_mode() == 3) SUAVE_PAIR_SHAPES(1, kEpiMaskBwd, 2, 3);
     else SUAVE_PAIR_SHAPES(1, kEpiMaskBwd, 2, 0);
   }
   else if (d.epi == kEpiMaskBwd) {
-    if (sp == 3) SUAVE_PAIR_SHAPES(0, kEpiMaskBwd, 0, 3);
+    if (sp == 4) SUAVE_PAIR_SHAPES(0, kEpiMaskBwd, 0, 4);
+    else if (sp == 3) SUAVE_PAIR_SHAPES(0, kEpiMaskBwd, 0, 3);
     else SUAVE_PAIR_SHAPES(0, kEpiMaskBwd, 0, 0);
   } else {
-    if (sp == 3) SUAVE_PAIR_SHAPES(0, kEpiBias, 0, 3);
+    if (sp == 4) SUAVE_PAIR_SHAPES(0, kEpiBias, 0, 4);
+    else if (sp == 3) SUAVE_PAIR_SHAPES(0, kEpiBias, 0, 3);
     else SUAVE_PAIR_SHAPES(0, kEpiBias, 0, 0);
   }
 #undef SUAVE_PAIR_SHAPES

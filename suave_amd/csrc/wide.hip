@@ -12,18 +12,20 @@
 namespace suave {
 
 // slot[r, yd .. yd+K) = s[r, :]: one-hot of the row's component (ELBO step, component-indexed decode) or the
-// dense assignment vector (soft imputation, model.py:3635-3644).
+// dense assignment vector (soft imputation, model.py:3635-3644).  Lane = (wide column, j) of one row, so a store
+// instruction writes runs of K consecutive floats (a thread per (row, column) wrote 64 scattered floats per
+// instruction); the slots' offsets come from an LDS table.
 __global__ __launch_bounds__(256) void k_wide_fill(WideRowArgs a) {
-  const int64_t total = (int64_t)a.n_rows * a.n_wide;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int r = (int)(e / a.n_wide), c = (int)(e % a.n_wide);
-    const WideCol wc = a.wide[c];
-    float* dst = a.y + (size_t)r * a.ldY + wc.y_off + wc.yd;
-    if (a.s_dense) {
-      for (int j = 0; j < a.K; ++j) dst[j] = a.s_dense[(size_t)r * a.K + j];
-    } else {
-      const int k = a.kidx ? a.kidx[r] : (r % a.vdiv);
-      for (int j = 0; j < a.K; ++j) dst[j] = j == k ? 1.f : 0.f;
+  extern __shared__ int soff_s[];  // [n_wide] offset of the assignment part of the column's slot
+  for (int i = threadIdx.x; i < a.n_wide; i += 256) soff_s[i] = a.wide[i].y_off + a.wide[i].yd;
+  __syncthreads();
+  const int per_row = a.n_wide * a.K;
+  for (int r = blockIdx.x; r < a.n_rows; r += gridDim.x) {
+    float* yrow = a.y + (size_t)r * a.ldY;
+    const int k = a.s_dense ? 0 : (a.kidx ? a.kidx[r] : (r % a.vdiv));
+    for (int i = threadIdx.x; i < per_row; i += 256) {
+      const int c = i / a.K, j = i - c * a.K;
+      yrow[soff_s[c] + j] = a.s_dense ? a.s_dense[(size_t)r * a.K + j] : (j == k ? 1.f : 0.f);
     }
   }
 }
@@ -195,19 +197,45 @@ __global__ __launch_bounds__(256) void k_wide_softmax_reg(WideRowArgs a) {
 
 // After the data-gradient GEMM the slots hold d loss / d [y_col ; s].  The assignment part is summed over
 // the wide columns into ds_out[r, 0..K) (the straight-through path needs the full K-vector, SURVEY.md
-// Appendix A) and cleared, so that the slots' pad rows of y_projection see a zero gradient.
+// Appendix A) and cleared, so that the slots' pad rows of y_projection see a zero gradient.  A block owns a row:
+// thread (column group g, j) adds its columns in order, eight loads in flight before the eight clearing stores
+// (one load -> store round trip per column was a 112-deep latency chain), and the groups are combined in a fixed
+// order.
 __global__ __launch_bounds__(256) void k_wide_ds(WideRowArgs a) {
-  const int64_t total = (int64_t)a.n_rows * a.K;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int r = (int)(e / a.K), j = (int)(e % a.K);
+  extern __shared__ int soff_s[];  // [n_wide] slot offsets | [G][K] partial sums (as floats)
+  float* part_s = reinterpret_cast<float*>(soff_s + a.n_wide);
+  for (int i = threadIdx.x; i < a.n_wide; i += 256) soff_s[i] = a.wide[i].y_off + a.wide[i].yd;
+  __syncthreads();
+  const int G = 256 / a.K;                       // column groups (K <= 32)
+  const int g = threadIdx.x / a.K, j = threadIdx.x - g * a.K;
+  for (int r = blockIdx.x; r < a.n_rows; r += gridDim.x) {
+    float* yrow = a.y + (size_t)r * a.ldY;
     float t = 0.f;
-    for (int c = 0; c < a.n_wide; ++c) {
-      const WideCol wc = a.wide[c];
-      float* p = a.y + (size_t)r * a.ldY + wc.y_off + wc.yd + j;
-      t += *p;
-      *p = 0.f;
+    if (g < G) {
+      for (int c0 = g; c0 < a.n_wide; c0 += 8 * G) {
+        float v[8];
+        int off[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int c = c0 + u * G;
+          off[u] = c < a.n_wide ? soff_s[c] + j : -1;
+          v[u] = off[u] >= 0 ? yrow[off[u]] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          t += v[u];
+          if (off[u] >= 0) yrow[off[u]] = 0.f;
+        }
+      }
+      part_s[g * a.K + j] = t;
     }
-    if (a.ds_out) a.ds_out[(size_t)j * a.n_rows + r] = t;  // plane-major [j][row], as the likelihood kernel's chunks
+    __syncthreads();
+    if (threadIdx.x < a.K && a.ds_out) {
+      float tot = 0.f;
+      for (int q = 0; q < G; ++q) tot += part_s[q * a.K + threadIdx.x];
+      a.ds_out[(size_t)threadIdx.x * a.n_rows + r] = tot;  // plane-major [j][row], as the likelihood kernel's chunks
+    }
+    __syncthreads();
   }
 }
 
@@ -232,7 +260,8 @@ static int wide_grid(int64_t work, int per_block, int cap) {
 int launch_wide_fill(const WideRowArgs& a, hipStream_t s) {
   if (a.n_rows <= 0 || a.n_wide <= 0) return 0;
   ProfScope prof_scope(kProfLoss, s);
-  hipLaunchKernelGGL(k_wide_fill, dim3(wide_grid((int64_t)a.n_rows * a.n_wide, 256, 4096)), dim3(256), 0, s, a);
+  SUAVE_REQUIRE(sizeof(int) * (size_t)a.n_wide <= 48 * 1024, "wide columns: offset table does not fit in LDS");
+  hipLaunchKernelGGL(k_wide_fill, dim3(std::min(a.n_rows, 8192)), dim3(256), sizeof(int) * a.n_wide, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -271,7 +300,9 @@ int launch_wide_transpose(const WideCol* cols, int n_wide, const float* params, 
 int launch_wide_ds(const WideRowArgs& a, hipStream_t s) {
   if (a.n_rows <= 0 || a.n_wide <= 0) return 0;
   ProfScope prof_scope(kProfLoss, s);
-  hipLaunchKernelGGL(k_wide_ds, dim3(wide_grid((int64_t)a.n_rows * a.K, 256, 4096)), dim3(256), 0, s, a);
+  const size_t lds = sizeof(int) * a.n_wide + sizeof(float) * (256 / a.K) * a.K;
+  SUAVE_REQUIRE(lds <= 48 * 1024, "wide columns: offset table does not fit in LDS");
+  hipLaunchKernelGGL(k_wide_ds, dim3(std::min(a.n_rows, 8192)), dim3(256), lds, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -381,10 +381,11 @@ def test_forward_only_matches_backward_outputs():
     assert rel_err(res["gaussian_kl"].cpu().numpy(), fx["out/gaussian_kl"]) < TOL
 
 
+@pytest.mark.parametrize("mode", [0, 3], ids=["exact", "bf16x3"])
 @pytest.mark.parametrize("case", ["s64", "golden_sup", "golden_unsup", "w1024_mini"])
-def test_exact_fp32_arithmetic_matches_oracle(case):
-    """Same parity checks with the matrix products on the exact-fp32 MFMA (suave_gemm_arithmetic_set(0));
-    every other test of this suite runs the default three-plane bf16 split (mode 3)."""
+def test_other_gemm_arithmetics_match_oracle(case, mode):
+    """Same parity checks with the matrix products on the exact-fp32 MFMA (suave_gemm_arithmetic_set(0)) and on the
+    three-plane bf16 split (3); every other test of this suite runs the default, two fp16 planes (mode 4)."""
 
     import ctypes as C
 
@@ -393,9 +394,9 @@ def test_exact_fp32_arithmetic_matches_oracle(case):
     L = slib.load()
     before = C.c_int(-1)
     slib.check(L.suave_gemm_arithmetic_get(C.byref(before)), "suave_gemm_arithmetic_get")
-    assert before.value == 3
-    assert L.suave_gemm_arithmetic_set(2) != 0  # only 0 and 3 exist
-    slib.check(L.suave_gemm_arithmetic_set(0), "suave_gemm_arithmetic_set")
+    assert before.value == 4
+    assert L.suave_gemm_arithmetic_set(2) != 0  # only 0, 3 and 4 exist
+    slib.check(L.suave_gemm_arithmetic_set(mode), "suave_gemm_arithmetic_set")
     try:
         if case == "s64":
             test_s64_step_matches_oracle(4096, 0.1)

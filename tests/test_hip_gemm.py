@@ -41,7 +41,7 @@ def _padded(rows, cols, ld, gen, dev, poison=True):
     return t
 
 
-@pytest.fixture(params=[3, 0], ids=["split3", "exact"])
+@pytest.fixture(params=[4, 3, 0], ids=["f16x2", "bf16x3", "exact"])
 def arithmetic(request):
     slib, L, _ = _debug_gemm()
     before = C.c_int(-1)
