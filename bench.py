@@ -33,7 +33,11 @@ if ROOT not in sys.path:
 K_COMP, LATENT, HIDDEN = 10, 32, (256, 128)
 PROF_CLASSES = ["gemm", "likelihood_kl", "latent", "expand", "reduce", "adam", "sample", "other"]
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 (same guide); an upper bound here: the grouped forms do not use this pipe
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 = dense fp16 (same guide); an upper bound here: the grouped forms do not use this pipe
+# plane products per fp32 product and the MFMA they run on, by GEMM arithmetic mode (include/suave_hip.h)
+ARITHMETIC = {4: (3, "two fp16 planes (hi + scaled residual), three plane products on v_mfma_f32_32x32x16_f16"),
+              3: (6, "three bf16 planes, six plane products on v_mfma_f32_32x32x16_bf16"),
+              0: (1, "exact fp32 on v_mfma_f32_32x32x2_f32")}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -448,24 +452,31 @@ def main():
             gemm_flops = gemm_flops_per_row(layout) * B * steps
             achieved = gemm_flops / (ms[0] * 1e-3) / 1e12
             executed = gemm_flops_executed_per_row(layout) * B * steps / (ms[0] * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel / gemm_pair_kernel, all %d launches/step.  fp32 GEMMs; every "
-                                "fp32 operand is cut into three bf16 planes in the kernel and six plane products accumulate in fp32 on "
-                                "v_mfma_f32_32x32x16_bf16 (fp32-grade error; the data gradient of the grouped per-component head and the "
-                                "narrow weight-gradient tiles stay on the exact-fp32 MFMA).  Priced as what it computes, fp32 matrix products, against the fp32 matrix peak; "
-                                "bf16_pipe_frac is the same time priced as 6 x executed flops against the dense bf16 peak"
-                                % (cnt[0] // steps),
-                                "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            import ctypes as _C
+            mode = _C.c_int(-1)
+            slib.check(slib.load().suave_gemm_arithmetic_get(_C.byref(mode)), "suave_gemm_arithmetic_get")
+            n_prod, how = ARITHMETIC[mode.value]
+            peak = PEAK_FP32_MFMA_TFLOPS if n_prod == 1 else PEAK_BF16_MFMA_TFLOPS / n_prod
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel / gemm_pair_kernel, all %d launches/step.  fp32 in, fp32 "
+                                "accumulate, fp32 out; arithmetic mode %d: %s (fp32-grade error; the data gradient of the grouped "
+                                "per-component head and the narrow weight-gradient tiles stay on the exact-fp32 MFMA).  achieved = "
+                                "algorithmic fp32 matrix FLOPs / GEMM time; peak = the dense MFMA peak of the instruction that runs "
+                                "them / plane products per fp32 product (%.0f / %d); vs_fp32_mfma_peak prices the same rate against "
+                                "the 157.3 TFLOP/s of the fp32 MFMA; matrix_pipe_frac = %d x executed FLOPs / dense 16-bit peak"
+                                % (cnt[0] // steps, mode.value, how, PEAK_BF16_MFMA_TFLOPS, n_prod, n_prod),
+                                "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                                "frac": achieved / peak, "traffic": None,
+                                "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                                "arithmetic_mode": mode.value,
                                 "avg_launch_us": 1e3 * ms[0] / cnt[0],
                                 "algorithmic_flops_per_launch": gemm_flops / cnt[0],
                                 "executed_tflops": executed,
-                                "bf16_pipe_frac": 6.0 * executed / PEAK_BF16_MFMA_TFLOPS}
-            # the same launches priced on what the matrix pipe executes: every fp32 product is six bf16 plane products,
-            # so the pipe's ceiling for this arithmetic is the dense bf16 peak / 6 -- the figure to read as "how much of
-            # the machine", next to the algorithmic fp32 line above (which counts skipped head FLOPs as done)
-            line["roofline_executed"] = {"bound": "mfma", "achieved": executed, "peak": PEAK_BF16_MFMA_TFLOPS / 6.0,
-                                         "unit": "TFLOP/s", "frac": executed / (PEAK_BF16_MFMA_TFLOPS / 6.0),
-                                         "kernel": "same GEMM launches; executed fp32 FLOPs against dense bf16 peak / 6"}
+                                "matrix_pipe_frac": n_prod * executed / (PEAK_FP32_MFMA_TFLOPS if n_prod == 1 else PEAK_BF16_MFMA_TFLOPS)}
+            # the same launches priced on the FLOPs actually executed (the algorithmic count above includes the dense
+            # encoder head, of which only the selected component's rows are computed)
+            line["roofline_executed"] = {"bound": "mfma", "achieved": executed, "peak": peak,
+                                         "unit": "TFLOP/s", "frac": executed / peak,
+                                         "kernel": "same GEMM launches; executed fp32 FLOPs against the same peak"}
             line["kernel_ms_per_step"] = {PROF_CLASSES[i]: ms[i] / steps for i in range(8) if cnt[i] > 0}
             line["kernel_timing"] = ("HIP events around every launch, on the launch stream, " +
                                      ("inside the timed region" if args.profile_timed else

@@ -635,11 +635,56 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
       }
     }
   }
+  // Every global load of a 32-row half (permuted output rows, dropout row ids, the activation / addend quads) is
+  // issued before the half's first store: vmcnt counts stores as well, so a load behind a store waits for that
+  // store's acknowledgement -- row by row that was a chain of sixteen round trips per wave (a third of the kernel
+  // on the K <= 256 layers).
+  const bool need_h = EPI == kEpiMaskBwd || (EPI == kEpiReluDrop && a.H != nullptr);
   if (act) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int row_tile = m0 + wm * 64 + mi * 32;
       if (row_tile >= a.M) continue;
+      int orow_[4][2];
+      uint32_t rid_[4][2];
+      float4 hq_[4][2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = row_tile + 8 * g + (lane >> 4) + 4 * h;
+          const bool ok = row < a.M && ncol > 0;
+          int orow = ok ? row : -1;
+          if (GRP == 1 && ok) orow = a.perm[row];
+          orow_[g][h] = orow;
+          rid_[g][h] = 0u;
+          if (hashed_drop && ok) {
+            if (a.row_vdiv > 1) {
+              const int drow = row / a.row_vdiv;
+              const uint32_t trow = a.row_ids ? static_cast<uint32_t>(a.row_ids[drow]) : static_cast<uint32_t>(a.row_begin + drow);
+              rid_[g][h] = trow * static_cast<uint32_t>(a.row_vdiv) + static_cast<uint32_t>(row - drow * a.row_vdiv);
+            } else {
+              rid_[g][h] = a.row_ids ? static_cast<uint32_t>(a.row_ids[row]) : static_cast<uint32_t>(a.row_begin + row);
+            }
+          }
+        }
+      if (need_h) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            hq_[g][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (orow_[g][h] >= 0) {
+              const float* hp = a.H + (size_t)orow_[g][h] * a.ldc + col;
+              if (ncol >= 4) hq_[g][h] = *reinterpret_cast<const float4*>(hp);
+              else {  // ragged right edge
+                hq_[g][h].x = hp[0];
+                if (ncol > 1) hq_[g][h].y = hp[1];
+                if (ncol > 2) hq_[g][h].z = hp[2];
+              }
+            }
+          }
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -651,42 +696,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
         for (int h = 0; h < 2; ++h) {
           const int lrow = (lane >> 4) + 4 * h;
           const float4 v4 = *reinterpret_cast<const float4*>(patch + lrow * LDP + c4);
-          const int row = row_tile + 8 * g + lrow;
-          if (row >= a.M || ncol <= 0) continue;
-          int orow = row;
-          if (GRP == 1) {
-            orow = a.perm[row];
-            if (orow < 0) continue;
-          }
+          const int orow = orow_[g][h];
+          if (orow < 0) continue;
           float v[4] = {v4.x, v4.y, v4.z, v4.w};
+          const float hv[4] = {hq_[g][h].x, hq_[g][h].y, hq_[g][h].z, hq_[g][h].w};
           const size_t off = (size_t)orow * a.ldc + col;
           if (EPI == kEpiBias) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += bias4[e];
           } else if (EPI == kEpiReluDrop) {
             if (a.H != nullptr) {  // first encoder layer of wide schemas: + the embedding rows (embed.hip)
-              if (ncol >= 4) {
-                const float4 hv = *reinterpret_cast<const float4*>(a.H + off);
-                v[0] += hv.x; v[1] += hv.y; v[2] += hv.z; v[3] += hv.w;
-              } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  if (e < ncol) v[e] += a.H[off + e];
-              }
+              for (int e = 0; e < 4; ++e) v[e] += hv[e];
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
             if (a.drop_p > 0.f) {
               if (hashed_drop) {
-                uint32_t rid;
-                if (a.row_vdiv > 1) {
-                  const int drow = row / a.row_vdiv;
-                  const uint32_t trow = a.row_ids ? static_cast<uint32_t>(a.row_ids[drow]) : static_cast<uint32_t>(a.row_begin + drow);
-                  rid = trow * static_cast<uint32_t>(a.row_vdiv) + static_cast<uint32_t>(row - drow * a.row_vdiv);
-                } else {
-                  rid = a.row_ids ? static_cast<uint32_t>(a.row_ids[row]) : static_cast<uint32_t>(a.row_begin + row);
-                }
-                const uint32_t hrow = drop_row_hash(key, rid);
+                const uint32_t hrow = drop_row_hash(key, rid_[g][h]);
                 const uint32_t h0 = hash32(hrow ^ (static_cast<uint32_t>(col >> 1) * 0x85EBCA77u));
                 const uint32_t h1 = hash32(hrow ^ (static_cast<uint32_t>((col >> 1) + 1) * 0x85EBCA77u));
                 v[0] = (h0 & 0xFFFFu) >= thr16 ? v[0] * inv_keep : 0.f;
@@ -694,23 +721,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
                 v[2] = (h1 & 0xFFFFu) >= thr16 ? v[2] * inv_keep : 0.f;
                 v[3] = (h1 >> 16) >= thr16 ? v[3] * inv_keep : 0.f;
               } else {
+                const int row = row_tile + 8 * g + lrow;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                   if (e < ncol) v[e] = a.keep[(size_t)row * a.N + col + e] != 0 ? v[e] * inv_keep : 0.f;
               }
             }
           } else if (EPI == kEpiMaskBwd) {
-            if (ncol >= 4) {
-              const float4 hv = *reinterpret_cast<const float4*>(a.H + off);
-              v[0] = hv.x > 0.f ? v[0] * inv_keep : 0.f;
-              v[1] = hv.y > 0.f ? v[1] * inv_keep : 0.f;
-              v[2] = hv.z > 0.f ? v[2] * inv_keep : 0.f;
-              v[3] = hv.w > 0.f ? v[3] * inv_keep : 0.f;
-            } else {
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (e < ncol) v[e] = a.H[off + e] > 0.f ? v[e] * inv_keep : 0.f;
-            }
+            for (int e = 0; e < 4; ++e) v[e] = hv[e] > 0.f ? v[e] * inv_keep : 0.f;
           }
           if (ncol >= 4) {
             *reinterpret_cast<float4*>(Cout + off) = make_float4(v[0], v[1], v[2], v[3]);
