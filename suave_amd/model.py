@@ -22,6 +22,7 @@ the library.
 from __future__ import annotations
 
 import math
+import warnings
 from typing import Dict, Iterable, Literal, Optional
 
 import numpy as np
@@ -368,12 +369,25 @@ class SUAVE:
                                noise=self._noise_for(nb))
                 self._record_step_gradient()
                 eng.adam_step(self.learning_rate)
-            s = self._all_reduce(eng.sums).cpu().numpy()  # ONE host sync per epoch (the reference syncs 4-5x per batch)
+            s = self._epoch_sums()  # ONE host sync per epoch (the reference syncs 4-5x per batch)
             cnt = max(s[3], 1.0)
             self._train_history.append({"reconstruction": s[0] / cnt, "categorical_kl": s[1] / cnt,
                                         "gaussian_kl": s[2] / cnt})
             if val is not None and val.n_rows:
                 self._warmup_val_history.append(self._elbo_on_table(val, bs, tau, seed=self.random_state + 1 + epoch))
+
+    def _epoch_sums(self) -> np.ndarray:
+        """The epoch's (sum reconstruction, sum categorical KL, sum Gaussian KL, rows) over all ranks: one host sync.
+        A non-finite sum is reported once (the reference keeps training on NaNs silently): with the default GEMM
+        arithmetic an activation or scaled gradient beyond fp16's range (65504) is the first thing to rule out."""
+
+        s = self._all_reduce(self._engine.sums).cpu().numpy()
+        if not np.all(np.isfinite(s)) and not getattr(self, "_warned_nonfinite", False):
+            self._warned_nonfinite = True
+            warnings.warn("non-finite ELBO sums during fit; if the data or the activations exceed fp16's range, rerun "
+                          "with SUAVE_GEMM_SPLIT=3 (three bf16 planes: fp32's exponent range, slower matrix products)",
+                          RuntimeWarning, stacklevel=3)
+        return s
 
     def _posterior_mean(self, table: PackedTable) -> torch.Tensor:
         """posterior["mean"] of _collect_posterior_statistics (model.py:1669-1741), kept on the device."""
@@ -501,7 +515,7 @@ class SUAVE:
                 eng.adam_step(lrs)
                 clf_opt.step()
                 ce_tot += class_loss.detach().double() * nb
-            s = self._all_reduce(eng.sums).cpu().numpy()
+            s = self._epoch_sums()
             cnt = max(s[3], 1.0)
             elbo_loss = -(s[0] - self.beta * (s[1] + s[2])) / cnt
             ce = float(self._all_reduce(ce_tot).item()) / cnt
@@ -621,7 +635,7 @@ class SUAVE:
                 self._record_step_gradient()
                 eng.adam_step(lrs)
             done += 1
-            s = self._all_reduce(eng.sums).cpu().numpy()
+            s = self._epoch_sums()
             cnt = max(s[3], 1.0)
             m = decorate(val_elbo())
             self._refine_history.append({"train_elbo_loss": -(s[0] - self.beta * (s[1] + s[2])) / cnt, "val": m})
@@ -645,7 +659,7 @@ class SUAVE:
             b, e = self._span(nb)  # noise is keyed by (seed, step, table row): the sums do not depend on the sharding
             eng.elbo(table, start + b, e - b, beta_scale=self.beta, tau=tau, grad=False, training=False, seed=seed,
                      step=i, accumulate_sums=True, noise=self._noise_for(nb))
-        s = self._all_reduce(eng.sums).cpu().numpy()
+        s = self._epoch_sums()
         n = max(s[3], 1.0)
         return {"nll": float(((s[1] + s[2]) * self.beta - s[0]) / n), "reconstruction": float(s[0] / n),
                 "categorical_kl": float(s[1] / n), "gaussian_kl": float(s[2] / n)}

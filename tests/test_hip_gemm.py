@@ -90,6 +90,47 @@ def test_row_major_forms(arithmetic, M, N, K, epi):
     assert bool((out[:, N:] == 7.5).all())  # nothing written past the N real columns
 
 
+def test_fp16_plane_range_is_loud_and_small_operands_keep_their_precision():
+    """Mode 4 cuts operands into fp16 planes: an element beyond fp16's range must give a non-finite result (never a
+    silently clipped one) while mode 3 handles it; operands far below fp16's normal range (1e-7: subnormal hi plane)
+    still come out with an ABSOLUTE error of ~1e-11 per element thanks to the scaled residual plane."""
+
+    import torch
+
+    slib, L, f = _debug_gemm()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(5)
+    M, N, K = 256, 128, 64
+    lda, ldb, ldc = _ru(K), _ru(K), _ru(N + 1)
+    bias = torch.zeros(N, device=dev)
+    before = C.c_int(-1)
+    slib.check(L.suave_gemm_arithmetic_get(C.byref(before)), "suave_gemm_arithmetic_get")
+
+    def run(A, W, mode):
+        slib.check(L.suave_gemm_arithmetic_set(mode), "suave_gemm_arithmetic_set")
+        out = torch.zeros(M, ldc, device=dev)
+        rc = f(A.data_ptr(), W.data_ptr(), out.data_ptr(), bias.data_ptr(), None, M, N, K, lda, ldb, ldc, 0, 0, EPI_BIAS, 1,
+               0.0, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, L.suave_last_error()
+        torch.cuda.synchronize()
+        return out[:, :N].double()
+
+    try:
+        A, W = _padded(M, K, lda, gen, dev, poison=False), _padded(N, K, ldb, gen, dev, poison=False)
+        A[3, 5] = 1.0e5
+        ref = A[:, :K].double() @ W[:, :K].double().t()
+        assert not torch.isfinite(run(A, W, 4)[3]).all()          # loud
+        assert torch.isfinite(run(A, W, 4)[4:]).all()             # and confined to the rows that hold the element
+        got3 = run(A, W, 3)
+        assert float((got3 - ref).abs().max()) <= TOL * float(ref.abs().max())
+        A2 = _padded(M, K, lda, gen, dev, poison=False) * 1.0e-7
+        ref2 = A2[:, :K].double() @ W[:, :K].double().t()
+        got4 = run(A2, W, 4)
+        assert float((got4 - ref2).abs().max()) <= 1e-4 * float(ref2.abs().max())
+    finally:
+        slib.check(L.suave_gemm_arithmetic_set(before.value), "suave_gemm_arithmetic_set")
+
+
 @pytest.mark.parametrize("M,N,K", [(129, 127, 17), (1000, 141, 128), (300, 650, 260), (513, 40, 96)])
 def test_k_major_weight_operand(arithmetic, M, N, K):
     """C = A @ B with B stored [K, N] (the data-gradient form on the untransposed weight)."""
