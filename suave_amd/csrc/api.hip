@@ -102,6 +102,8 @@ struct Workspace {
   float* hd[SUAVE_MAX_HIDDEN];
   float* dhe[SUAVE_MAX_HIDDEN];
   float* dhd[SUAVE_MAX_HIDDEN];
+  uint64_t* mask_e[SUAVE_MAX_HIDDEN];  // sign bits of he[i] / hd[i] (GemmArgs::mask_out), read by the data gradients
+  uint64_t* mask_d[SUAVE_MAX_HIDDEN];
   int32_t* kidx;
   float *recon_part, *ds_part, *catkl, *gausskl, *gkl_logit, *gkl_mu, *gkl_lv, *prior_terms, *recon;
   float* onehot;
@@ -235,6 +237,8 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
     w->hd[i] = c.take<float>(R * p->ldH[i]);
     w->dhe[i] = c.take<float>(R * p->ldH[i]);
     w->dhd[i] = c.take<float>(R * p->ldH[i]);
+    w->mask_e[i] = c.take<uint64_t>((size_t)gemm_mask_words((int64_t)R, m.enc[i].n_out));
+    w->mask_d[i] = c.take<uint64_t>((size_t)gemm_mask_words((int64_t)R, m.dec[i].n_out));
   }
   w->kidx = c.take<int32_t>(R);
   const size_t nch = p->chunks_host.size();
@@ -327,8 +331,9 @@ float grad_scale_for(int64_t global_rows) {
 // forward layer: C = epi(A * W^T + b)
 int fwd_layer(const suave_plan* p, const float* params, const suave_layer_t& l, const float* A, int lda, float* C,
               int ldc, int rows, bool relu_drop, float drop_p, const uint8_t* keep, const suave_batch_t* b,
-              const suave_noise_t* nz, uint32_t stream_id, int vdiv, hipStream_t s) {
+              const suave_noise_t* nz, uint32_t stream_id, int vdiv, hipStream_t s, uint64_t* mask_out = nullptr) {
   GemmArgs g = gemm_base();
+  g.mask_out = relu_drop ? mask_out : nullptr;
   g.A = A; g.B = params + l.w_off; g.C = C; g.bias = params + l.b_off;
   g.M = rows; g.N = l.n_out; g.K = l.n_in;
   g.lda = lda; g.ldb = l.ld; g.ldc = ldc;
@@ -398,8 +403,9 @@ int encoder_chain_forward(const suave_plan* p, const float* params, const float*
 
 // data gradient: dA = (dC * W) [* relu/dropout mask of H]
 GemmArgs bwd_data_args(const float* params, const suave_layer_t& l, const float* dC, int lddc, float* dA, int ldda, int rows,
-                       const float* H, float drop_p, const float* wT = nullptr) {
+                       const float* H, float drop_p, const float* wT = nullptr, const uint64_t* mask_in = nullptr) {
   GemmArgs g = gemm_base();
+  g.mask_in = H ? mask_in : nullptr;
   g.A = dC; g.B = params + l.w_off; g.C = dA;
   g.M = rows; g.N = l.n_in; g.K = l.n_out;
   g.lda = lddc; g.ldb = l.ld; g.ldc = ldda;
@@ -484,10 +490,10 @@ int bwd_weight(const suave_plan* p, const suave_layer_t& l, const float* dC, int
 int bwd_layer(const suave_plan* p, const float* params, const suave_layer_t& l, const float* dC, int lddc,
               const float* A_in, int lda_in, float* dA_in, int ldda, int rows, const float* H_in, float drop_p,
               float* slab_base, size_t* slab_off, ReduceArgs* red, int* max_elems, hipStream_t s,
-              const float* wT = nullptr) {
+              const float* wT = nullptr, const uint64_t* mask_in = nullptr) {
   GemmArgs w;
   if (int rc = bwd_weight_args(p, l, dC, lddc, A_in, lda_in, rows, slab_base, slab_off, red, max_elems, &w)) return rc;
-  return launch_gemm_pair(bwd_data_args(params, l, dC, lddc, dA_in, ldda, rows, H_in, drop_p, wT), w, p->n_cu, s);
+  return launch_gemm_pair(bwd_data_args(params, l, dC, lddc, dA_in, ldda, rows, H_in, drop_p, wT, mask_in), w, p->n_cu, s);
 }
 
 WideRowArgs wide_row_args(const suave_plan* p, const Workspace& w, int rows) {
@@ -598,6 +604,7 @@ int encoder_trunk_forward(const suave_plan* p, const float* params, const suave_
     g.seed = nz ? nz->seed : 0;
     g.step = nz ? nz->step : 0;
     g.stream_id = kStreamEncDrop + i;
+    g.mask_out = w.mask_e[i];
     if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
     act = w.he[i];
     ld_act = p->ldH[i];
@@ -930,7 +937,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     ld_act = p->ldD;
     for (int i = 0; i < nh; ++i) {
       if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], B, true, drop_p, nz->dec_keep[i], batch,
-                             nz, kStreamDecDrop + i, 1, s))
+                             nz, kStreamDecDrop + i, 1, s, grad ? w.mask_d[i] : nullptr))
         return rc;
       act = w.hd[i];
       ld_act = p->ldH[i];
@@ -938,6 +945,8 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, batch, nz, 0, 1, s))
       return rc;
   }
+  // the per-layer launches leave sign bits of the hidden activations for the data gradients; the fused chains do not
+  const bool dec_masks = !decoder_chain_ok(p), enc_masks = !encoder_chain_ok(p);
   // ---- fused likelihood (+ gradients) ----
   {
     LossArgs a{};
@@ -997,7 +1006,8 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
         const int ldain = i >= 0 ? p->ldH[i] : p->ldD;
         float* dain = i >= 0 ? w.dhd[i] : w.dz;
         if (int rc = bwd_layer(p, params, *lcur, dcur, lddcur, ain, ldain, dain, ldain, B, i >= 0 ? w.hd[i] : nullptr,
-                               i >= 0 ? drop_p : 0.f, w.slab, &slab_off, &red, &max_elems, s, w.wT[layer_index(p, lcur)]))
+                               i >= 0 ? drop_p : 0.f, w.slab, &slab_off, &red, &max_elems, s, w.wT[layer_index(p, lcur)],
+                               (i >= 0 && dec_masks) ? w.mask_d[i] : nullptr))
           return rc;
         dcur = dain;
         lddcur = ldain;
@@ -1091,7 +1101,8 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
       const int ldain = i > 0 ? p->ldH[i - 1] : p->ldI;
       if (i > 0) {
         if (int rc = bwd_layer(p, params, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, w.dhe[i - 1], ldain, B, w.he[i - 1],
-                               drop_p, w.slab, &slab_off, &red, &max_elems, s, w.wT[layer_index(p, &m.enc[i])]))
+                               drop_p, w.slab, &slab_off, &red, &max_elems, s, w.wT[layer_index(p, &m.enc[i])],
+                               enc_masks ? w.mask_e[i - 1] : nullptr))
           return rc;
       } else {
         if (int rc = bwd_weight(p, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, B, w.slab, &slab_off, &red, &max_elems, s))

@@ -228,6 +228,14 @@ struct GemmArgs {
   const int32_t* perm;        // sorted position -> batch row, -1 = padding
   const int32_t* chunk_comp;  // chunk of kGroupRows sorted positions -> component, -1 = unused chunk
   int hK, hD, hldK, hldD, q0;
+  // Activation sign bits instead of the activation itself (backward of a ReLU / dropout layer only needs h > 0): the
+  // forward epilogue (kEpiReluDrop) writes, per 64 x 64 wave tile, one 64-bit word per LANE -- bit
+  // ((mi*4 + g)*2 + h)*4 + e says that element e of the lane's quad in epilogue round (mi, g, h) is positive -- and the
+  // data-gradient epilogue (kEpiMaskBwd) of the SAME matrix shape (same tiles, same lane -> element map) reads its
+  // lane's word back: 1 bit instead of 4 bytes per activation, one coalesced 512-byte access per wave either way.
+  // Indexed by (tile_m, tile_n, wave, lane); gemm_mask_words() sizes the buffer.  Null: not written / H is read.
+  uint64_t* mask_out;
+  const uint64_t* mask_in;
   float a_scale;              // arithmetic mode 4 (fp16 planes): power of two the A operand is multiplied by before it is
                               // cut into planes (gradient operands are ~1 / batch rows: keeps them clear of the fp16
                               // subnormals); the product is scaled back in the epilogue.  <= 0 means 1.
@@ -270,6 +278,7 @@ struct WideGemmArgs {
   float grad_scale;     // modes 1 and 2: GemmArgs::a_scale of the logit gradients
 };
 int launch_gemm_wide(const WideGemmArgs& a, int mode, hipStream_t stream);
+int64_t gemm_mask_words(int64_t M, int N);  // 64-bit words of GemmArgs::mask_out for an M x N activation
 int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t stream);
 int gemm_split_mode_set(int mode);  // 0 on success (suave_gemm_arithmetic)
 int gemm_split_mode();  // 0 exact-fp32 MFMA, 3 bf16 planes per operand on the row-major forms (gemm.hip)

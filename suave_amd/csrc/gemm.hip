@@ -128,6 +128,33 @@ __device__ __forceinline__ void split4(const float4 v, float scale, bf16x4 (&p)[
   }
 }
 
+// kEpiReluDrop on one quad of a row: (+ addend) + bias, ReLU, dropout (hashed keep decision: 16 bits of a per-(row,
+// column pair) hash against round(p * 65536); or the injected mask)
+__device__ __forceinline__ void relu_drop_quad(const GemmArgs& a, float (&v)[4], const float4& addend, const float (&bias4)[4],
+                                               bool hashed_drop, uint32_t key, uint32_t rid, int col, int ncol,
+                                               uint32_t thr16, float inv_keep, int row) {
+  if (a.H != nullptr) {  // first encoder layer of wide schemas: + the embedding rows (embed.hip)
+    v[0] += addend.x; v[1] += addend.y; v[2] += addend.z; v[3] += addend.w;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
+  if (a.drop_p > 0.f) {
+    if (hashed_drop) {
+      const uint32_t hrow = drop_row_hash(key, rid);
+      const uint32_t h0 = hash32(hrow ^ (static_cast<uint32_t>(col >> 1) * 0x85EBCA77u));
+      const uint32_t h1 = hash32(hrow ^ (static_cast<uint32_t>((col >> 1) + 1) * 0x85EBCA77u));
+      v[0] = (h0 & 0xFFFFu) >= thr16 ? v[0] * inv_keep : 0.f;
+      v[1] = (h0 >> 16) >= thr16 ? v[1] * inv_keep : 0.f;
+      v[2] = (h1 & 0xFFFFu) >= thr16 ? v[2] * inv_keep : 0.f;
+      v[3] = (h1 >> 16) >= thr16 ? v[3] * inv_keep : 0.f;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < ncol) v[e] = a.keep[(size_t)row * a.N + col + e] != 0 ? v[e] * inv_keep : 0.f;
+    }
+  }
+}
+
 // One block's work: tile `bid` of split `bz`.
 template <int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int GRP, int EPI, int SPLIT = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, const int bz, float* smem, int* perm_s) {
@@ -639,7 +666,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   // issued before the half's first store: vmcnt counts stores as well, so a load behind a store waits for that
   // store's acknowledgement -- row by row that was a chain of sixteen round trips per wave (a third of the kernel
   // on the K <= 256 layers).
-  const bool need_h = EPI == kEpiMaskBwd || (EPI == kEpiReluDrop && a.H != nullptr);
+  const bool need_h = (EPI == kEpiMaskBwd && a.mask_in == nullptr) || (EPI == kEpiReluDrop && a.H != nullptr);
+  const size_t mbase = ((size_t)(tile_m * tiles_n + tile_n) * 4 + wave) * 64;  // this wave's 64 sign words
+  uint32_t sign_lo = 0u, sign_hi = 0u;  // this lane's word: bit ((mi*4 + g)*2 + h)*4 + e of its 16 quads
+  if (EPI == kEpiMaskBwd && a.mask_in != nullptr && act) {
+    const uint64_t wbits = a.mask_in[mbase + lane];
+    sign_lo = static_cast<uint32_t>(wbits);
+    sign_hi = static_cast<uint32_t>(wbits >> 32);
+  }
   if (act) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -705,31 +739,26 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += bias4[e];
           } else if (EPI == kEpiReluDrop) {
-            if (a.H != nullptr) {  // first encoder layer of wide schemas: + the embedding rows (embed.hip)
+            relu_drop_quad(a, v, hq_[g][h], bias4, hashed_drop, key, rid_[g][h], col, ncol, thr16, inv_keep,
+                           row_tile + 8 * g + lrow);
+            if (a.mask_out != nullptr) {  // v >= 0 here: positive <=> any bit set
+              const int wi = ((mi * 4 + g) * 2 + h) * 4;  // compile-time after unrolling
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += hv[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
-            if (a.drop_p > 0.f) {
-              if (hashed_drop) {
-                const uint32_t hrow = drop_row_hash(key, rid_[g][h]);
-                const uint32_t h0 = hash32(hrow ^ (static_cast<uint32_t>(col >> 1) * 0x85EBCA77u));
-                const uint32_t h1 = hash32(hrow ^ (static_cast<uint32_t>((col >> 1) + 1) * 0x85EBCA77u));
-                v[0] = (h0 & 0xFFFFu) >= thr16 ? v[0] * inv_keep : 0.f;
-                v[1] = (h0 >> 16) >= thr16 ? v[1] * inv_keep : 0.f;
-                v[2] = (h1 & 0xFFFFu) >= thr16 ? v[2] * inv_keep : 0.f;
-                v[3] = (h1 >> 16) >= thr16 ? v[3] * inv_keep : 0.f;
-              } else {
-                const int row = row_tile + 8 * g + lrow;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  if (e < ncol) v[e] = a.keep[(size_t)row * a.N + col + e] != 0 ? v[e] * inv_keep : 0.f;
+              for (int e = 0; e < 4; ++e) {
+                const uint32_t one = min(__float_as_uint(v[e]), 1u) << ((wi + e) & 31);
+                if (wi < 32) sign_lo |= one; else sign_hi |= one;
               }
             }
           } else if (EPI == kEpiMaskBwd) {
+            if (a.mask_in != nullptr) {  // the forward's sign bits of this lane's quads (compile-time bit index)
+              const int wi = ((mi * 4 + g) * 2 + h) * 4;  // compile-time after unrolling
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = hv[e] > 0.f ? v[e] * inv_keep : 0.f;
+              for (int e = 0; e < 4; ++e)
+                v[e] = (((wi < 32 ? sign_lo : sign_hi) >> ((wi + e) & 31)) & 1u) ? v[e] * inv_keep : 0.f;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = hv[e] > 0.f ? v[e] * inv_keep : 0.f;
+            }
           }
           if (ncol >= 4) {
             *reinterpret_cast<float4*>(Cout + off) = make_float4(v[0], v[1], v[2], v[3]);
@@ -741,6 +770,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
         }
       }
     }
+    if (EPI == kEpiReluDrop && a.mask_out != nullptr)
+      a.mask_out[mbase + lane] = (static_cast<uint64_t>(sign_hi) << 32) | sign_lo;  // quads never stored: bits 0
   }
 }
 
@@ -813,7 +844,7 @@ __global__ __launch_bounds__(256, SPLIT == 4 ? 2 : SPLIT > 0 ? 3 : 1) void gemm_
   g.bias = nullptr; g.H = nullptr; g.keep = nullptr; g.row_ids = nullptr; g.row_begin = 0;
   g.splits = 1; g.slab_stride = 0; g.ones_col = -1; g.drop_p = 0.f; g.seed = 0; g.step = 0; g.stream_id = 0;
   g.grouped = 0; g.perm = nullptr; g.chunk_comp = nullptr; g.hK = g.hD = g.hldK = g.hldD = g.q0 = 0;
-  g.row_vdiv = 0; g.a_scale = MODE == 0 ? 1.0f : w.grad_scale;
+  g.row_vdiv = 0; g.a_scale = MODE == 0 ? 1.0f : w.grad_scale; g.mask_out = nullptr; g.mask_in = nullptr;
   float* slot = w.y + wc.y_off;
   float* logit = w.L + wc.l_off;
   const float* wt = w.params + wc.w_off;
@@ -909,6 +940,10 @@ inline int gemm_tiles(const GemmArgs& a) {
 }  // namespace
 
 int gemm_split_mode() { return split_mode(); }
+int64_t gemm_mask_words(int64_t M, int N) {
+  const int64_t tiles = N <= 64 ? ((M + 255) / 256) * ((N + 63) / 64) : ((M + 127) / 128) * ((N + 127) / 128);
+  return tiles * 256;  // 4 waves x 64 words per tile
+}
 int gemm_split_mode_set(int mode) {
   SUAVE_REQUIRE(mode == 0 || mode == 3 || mode == 4,
                 "gemm: the arithmetic mode is 0 (exact-fp32 MFMA), 3 (three bf16 planes) or 4 (two fp16 planes)");
