@@ -946,7 +946,8 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
       return rc;
   }
   // the per-layer launches leave sign bits of the hidden activations for the data gradients; the fused chains do not
-  const bool dec_masks = !decoder_chain_ok(p), enc_masks = !encoder_chain_ok(p);
+  static const bool sign_bits = getenv("SUAVE_NO_SIGN_BITS") == nullptr;  // measurement knob: read the activations instead
+  const bool dec_masks = sign_bits && !decoder_chain_ok(p), enc_masks = sign_bits && !encoder_chain_ok(p);
   // ---- fused likelihood (+ gradients) ----
   {
     LossArgs a{};
