@@ -142,7 +142,11 @@ int tn_splits(const suave_plan* p, int n_out, int n_in1, int64_t rows) {
   const int tiles = narrow ? ((n_out + 255) / 256) * ((n_in1 + 63) / 64) : ((n_out + 127) / 128) * ((n_in1 + 127) / 128);
   static const int factor = [] { const char* e = getenv("SUAVE_TN_FACTOR"); return e ? std::max(1, atoi(e)) : 1; }();
   static const int divisor = [] { const char* e = getenv("SUAVE_TN_DIV"); return e ? std::max(1, atoi(e)) : 1; }();
-  int64_t s = (factor * (int64_t)p->n_cu / divisor + tiles - 1) / tiles;
+  // the first encoder layer's weight gradient has no data-gradient partner filling the CUs beside it
+  static const int first = [] { const char* e = getenv("SUAVE_TN_FIRST"); return e ? std::max(1, atoi(e)) : 2; }();  // (1: +0.8 % on the S64 step)
+  const suave_model_t& mm = p->model;
+  const bool unpaired = mm.n_hidden > 0 && n_out == mm.enc[0].n_out && n_in1 == mm.enc[0].n_in;
+  int64_t s = ((unpaired ? first : 1) * factor * (int64_t)p->n_cu / divisor + tiles - 1) / tiles;
   s = std::min<int64_t>(s, std::max<int64_t>(1, rows / 256));
   return (int)std::max<int64_t>(1, std::min<int64_t>(s, 512));
 }
