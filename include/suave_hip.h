@@ -306,6 +306,53 @@ int suave_decode_params(const suave_plan* plan, const float* params, const float
                         const int32_t* component, int64_t n, int32_t col_index, void* workspace,
                         size_t workspace_bytes, void* stream, float* out_params);
 
+/* ---- data formats either side of the path ----------------------------
+ *
+ * suave_pack_columns replaces the host tensorisation of the reference --
+ * SUAVE._prepare_training_tensors (suave/model.py:2784-2922, its per-row ordinal loop :2890-2891),
+ * _apply_training_normalization (:3116-3213) and data.standardize (suave/data.py:133-266): the raw columns of
+ * a table, one device array per column in whatever dtype the caller's frame holds them, become the packed table
+ * (float32 numerics, int16 codes, uint8 mask) with the normalisation fused in.  Arithmetic as the reference's
+ * numpy path: float64 (x - mean) / max(std, 1e-6), (log1p(x) - mean_log) / max(std_log, 1e-6), log(x + offset),
+ * rounded once to float32; a non-finite result is a missing cell (value 0, mask 0).  Categorical columns arrive
+ * as category codes (the mapping of labels to codes is pandas' and stays with the caller); ordinal columns as
+ * numeric levels, out-of-range levels become missing.  rejected[c] (device, zeroed by the caller) counts the
+ * values of column c that the reference rejects: pos < -1 and count < 0 (it raises ValueError), ordinal levels
+ * outside [0, n_classes) (it warns and treats them as missing).  cols: DEVICE array of the plan's n_cols
+ * descriptors in schema order. */
+#define SUAVE_RAW_F64 0
+#define SUAVE_RAW_F32 1
+#define SUAVE_RAW_I64 2
+#define SUAVE_RAW_I32 3
+#define SUAVE_RAW_I16 4
+#define SUAVE_RAW_I8 5
+typedef struct {
+  const void* src;    /* device array of n raw values of this column */
+  int32_t src_dtype;  /* SUAVE_RAW_* */
+  int32_t kind;       /* SUAVE_TYPE_* of the column */
+  int32_t n_classes;  /* cat / ordinal */
+  int32_t slot;       /* x_index of the column: its position in xnum (real / pos / count) or codes (cat / ordinal) */
+  double a, b;        /* real: mean, std;  pos: mean_log, std_log;  count: offset, unused */
+} suave_pack_col_t;
+int suave_pack_columns(const suave_plan* plan, const suave_pack_col_t* cols, int64_t n, float* xnum, int32_t ld_num,
+                       int16_t* codes, int32_t ld_disc, uint8_t* mask, int32_t ld_mask, uint64_t* rejected, void* stream);
+
+/* suave_unpack_columns replaces the per-column .cpu() / astype / concat of sampling.decoder_outputs_to_frame
+ * (suave/sampling.py:138-179, model.py:4420-4431): the row-major outputs of suave_decode_sample become columnar
+ * blocks [columns][ld_rows] that a DataFrame wraps without copying -- float32 (real, pos), int64 (count:
+ * max(rint(v), 0)), int16 / int8 category codes.  Descriptor i moves source column `src` (of out_num for blocks
+ * 0 and 1, of out_codes for 2 and 3) to row `dst` of its block.  cols: DEVICE array of n_out descriptors.  The
+ * blocks may be rows [r0, r0 + n) of larger arrays: ld_rows is the row stride of a block column. */
+typedef struct {
+  int32_t block;  /* 0 float32, 1 int64 (counts), 2 int16 codes, 3 int8 codes */
+  int32_t src;
+  int32_t dst;
+  int32_t reserved;
+} suave_unpack_col_t;
+int suave_unpack_columns(const suave_plan* plan, const suave_unpack_col_t* cols, int32_t n_out, int64_t n,
+                         const float* out_num, int32_t ld_num, const int16_t* out_codes, int32_t ld_disc, float* f32_block,
+                         int64_t* i64_block, int16_t* i16_block, int8_t* i8_block, int64_t ld_rows, void* stream);
+
 /* Arithmetic of the matrix products (no counterpart in the reference, which
  * multiplies in fp32 through torch: suave/modules/encoder.py:49-53,
  * decoder.py:300-318).  All modes take fp32 in, accumulate in fp32 and give

@@ -1667,6 +1667,33 @@ extern "C" int suave_decode_log_px(const suave_plan* p, const float* params, con
   return 0;
 }
 
+extern "C" int suave_pack_columns(const suave_plan* p, const suave_pack_col_t* cols, int64_t n, float* xnum, int32_t ld_num,
+                                  int16_t* codes, int32_t ld_disc, uint8_t* mask, int32_t ld_mask, uint64_t* rejected,
+                                  void* stream) {
+  drop_stale_hip_error();
+  SUAVE_REQUIRE(p != nullptr && cols != nullptr && rejected != nullptr, "pack_columns: plan / cols / rejected is null");
+  SUAVE_REQUIRE(n >= 0, "pack_columns: negative row count");
+  const suave_model_t& m = p->model;
+  SUAVE_REQUIRE(mask != nullptr && (m.n_num == 0 || xnum != nullptr) && (m.n_disc == 0 || codes != nullptr),
+                "pack_columns: output buffer is null");
+  SUAVE_REQUIRE(ld_num >= m.n_num && ld_disc >= m.n_disc && ld_mask >= m.n_cols,
+                "pack_columns: leading dimensions smaller than the schema");
+  return launch_pack_columns(cols, m.n_cols, m.n_num, m.n_disc, n, xnum, ld_num, codes, ld_disc, mask, ld_mask,
+                             reinterpret_cast<unsigned long long*>(rejected), static_cast<hipStream_t>(stream));
+}
+
+extern "C" int suave_unpack_columns(const suave_plan* p, const suave_unpack_col_t* cols, int32_t n_out, int64_t n,
+                                    const float* out_num, int32_t ld_num, const int16_t* out_codes, int32_t ld_disc,
+                                    float* f32_block, int64_t* i64_block, int16_t* i16_block, int8_t* i8_block,
+                                    int64_t ld_rows, void* stream) {
+  drop_stale_hip_error();
+  SUAVE_REQUIRE(p != nullptr && (cols != nullptr || n_out == 0), "unpack_columns: plan / cols is null");
+  SUAVE_REQUIRE(n >= 0 && n_out >= 0 && ld_rows >= n, "unpack_columns: bad sizes");
+  SUAVE_REQUIRE(ld_num >= p->model.n_num && ld_disc >= p->model.n_disc, "unpack_columns: leading dimensions smaller than the schema");
+  return launch_unpack_columns(cols, n_out, n, out_num, ld_num, out_codes, ld_disc, f32_block, i64_block, i16_block, i8_block,
+                               ld_rows, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int suave_gemm_arithmetic_set(int mode) { return gemm_split_mode_set(mode); }
 
 extern "C" int suave_gemm_arithmetic_get(int* mode) {

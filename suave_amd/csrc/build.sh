@@ -7,7 +7,7 @@ OBJ=../../build/obj
 mkdir -p "$OBJ"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $SUAVE_EXTRA_FLAGS"
 pids=()
-for f in gemm chain loss wide embed latent optim sample api; do
+for f in gemm chain loss wide embed latent optim sample frame api; do
   [ -f $f.hip ] || continue
   if [ ! -f $OBJ/$f.o ] || [ $f.hip -nt $OBJ/$f.o ] || [ common.h -nt $OBJ/$f.o ] || [ kernels.h -nt $OBJ/$f.o ] || [ detmath.h -nt $OBJ/$f.o ] || [ ../../include/suave_hip.h -nt $OBJ/$f.o ]; then
     extra=""
@@ -19,6 +19,6 @@ for f in gemm chain loss wide embed latent optim sample api; do
 done
 for p in "${pids[@]}"; do wait $p; done
 objs=""
-for f in gemm chain loss wide embed latent optim sample api; do [ -f $OBJ/$f.o ] && objs="$objs $OBJ/$f.o"; done
+for f in gemm chain loss wide embed latent optim sample frame api; do [ -f $OBJ/$f.o ] && objs="$objs $OBJ/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $OUT
 echo "built $(realpath $OUT)"

@@ -199,6 +199,13 @@ int launch_wide_ds(const WideRowArgs& a, hipStream_t s);
 // wT[t_off + n * round_up(C-1, 4) + k] = W[k][n] for every wide column (pad columns zero)
 int launch_wide_transpose(const WideCol* cols, int n_wide, const float* params, float* wT, hipStream_t s);
 
+int launch_pack_columns(const suave_pack_col_t* cols_dev, int n_cols, int n_num, int n_disc, int64_t n, float* xnum,
+                        int ld_num, int16_t* codes, int ld_disc, uint8_t* mask, int ld_mask, unsigned long long* rejected,
+                        hipStream_t s);
+int launch_unpack_columns(const suave_unpack_col_t* cols_dev, int n_cols, int64_t n, const float* out_num, int ld_num,
+                          const int16_t* out_codes, int ld_disc, float* f32_block, int64_t* i64_block, int16_t* i16_block,
+                          int8_t* i8_block, int64_t ld_rows, hipStream_t s);
+
 int launch_mix_fwd(const MixFwdArgs& a, hipStream_t s);
 int launch_mix_finalize(const MixFinArgs& a, bool grad, int grid, hipStream_t s);
 int launch_colsum(const float* src, int ld, int n_rows, int n_cols, float* slab, int n_blocks, hipStream_t s);

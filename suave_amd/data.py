@@ -1,4 +1,5 @@
-"""Host data layer: normalisation statistics and the packed-table writer.
+"""Data layer: normalisation statistics, the packed-table writer (host reference path and the device path that
+``SUAVE`` uses: ``pack_frame_device``) and the generation-side frame assembly (``FrameAssembler``).
 
 Semantics of the reference's ``suave/data.py:133-266`` (``standardize``) and
 ``suave/model.py:2784-2922`` (``_prepare_training_tensors``) /
@@ -11,7 +12,8 @@ the ordinal thermometer row by row, model.py:2890-2891).
 from __future__ import annotations
 
 import warnings
-from typing import Dict, Mapping, Tuple
+import ctypes as C
+from typing import Dict, List, Mapping, Optional, Tuple
 
 import numpy as np
 import pandas as pd
@@ -165,3 +167,178 @@ def frame_from_packed(out_num: np.ndarray, out_codes: np.ndarray, schema: Schema
                 cat_list.extend(range(len(cat_list), n_classes))
             data[column] = pd.Categorical.from_codes(c, categories=cat_list, ordered=(spec.type == "ordinal"))
     return pd.DataFrame(data)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Device path: the raw columns go to the GPU as they are and libsuave_hip.so
+# writes the packed table (suave_pack_columns) / hands generated columns back as DataFrame-ready blocks
+# (suave_unpack_columns).  The host keeps what is pandas' own: label -> category code maps and the frame object.
+# ---------------------------------------------------------------------------------------------------------------
+
+_KIND = {"real": 0, "pos": 1, "count": 2, "cat": 3, "ordinal": 4}
+_RAW = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.int64): 2, np.dtype(np.int32): 3,
+        np.dtype(np.int16): 4, np.dtype(np.int8): 5}
+_PACK_COL = np.dtype([("src", np.uint64), ("src_dtype", np.int32), ("kind", np.int32), ("n_classes", np.int32),
+                      ("slot", np.int32), ("a", np.float64), ("b", np.float64)], align=True)   # suave_pack_col_t
+_UNPACK_COL = np.dtype([("block", np.int32), ("src", np.int32), ("dst", np.int32), ("reserved", np.int32)])
+
+
+def _raw_array(series: pd.Series) -> Tuple[np.ndarray, int]:
+    """The column's values in a dtype the packer reads, without a copy when the frame already holds one; the second
+    value counts entries that are present but not numeric (coerced to NaN, as ``pd.to_numeric(errors="coerce")``)."""
+
+    dt = series.dtype
+    if isinstance(dt, np.dtype) and dt in _RAW:
+        return np.ascontiguousarray(series.to_numpy()), 0
+    if isinstance(dt, np.dtype) and dt.kind in "iub":
+        return np.ascontiguousarray(series.to_numpy(dtype=np.int64)), 0
+    if isinstance(dt, np.dtype) and dt.kind == "f":
+        return np.ascontiguousarray(series.to_numpy(dtype=np.float64)), 0
+    v = pd.to_numeric(series, errors="coerce").to_numpy(dtype=np.float64, na_value=np.nan)
+    return np.ascontiguousarray(v), int((series.notna().to_numpy() & np.isnan(v)).sum())
+
+
+def pack_frame_device(X: pd.DataFrame, schema: Schema, stats: Mapping[str, Mapping[str, object]], engine,
+                      chunk_rows: int = 1 << 22):
+    """``pack_frame`` on the GPU: returns ``(xnum, codes, mask)`` as device tensors, same values (the float64
+    normalisation arithmetic runs in the kernel; log1p / log may differ from numpy's in the last float32 bit)."""
+
+    import torch
+
+    names = list(schema.feature_names)
+    n = len(X)
+    n_num = sum(schema[c].type in ("real", "pos", "count") for c in names)
+    n_disc = len(names) - n_num
+    dev = engine.device
+    xnum = torch.empty((n, max(n_num, 1)), dtype=torch.float32, device=dev)
+    codes = torch.empty((n, max(n_disc, 1)), dtype=torch.int16, device=dev)
+    mask = torch.empty((n, len(names)), dtype=torch.uint8, device=dev)
+    rejected = torch.zeros(len(names), dtype=torch.int64, device=dev)
+    non_numeric = np.zeros(len(names), np.int64)
+    for start in range(0, n, chunk_rows):
+        stop = min(n, start + chunk_rows)
+        desc = np.zeros(len(names), _PACK_COL)
+        keep = []
+        i_num = i_disc = 0
+        for j, column in enumerate(names):
+            spec = schema[column]
+            st = stats.get(column, {})
+            series = X[column].iloc[start:stop]
+            d = desc[j]
+            d["kind"] = _KIND[spec.type]
+            if spec.type == "cat":
+                cats = st.get("categories")
+                cat = pd.Categorical(series, categories=cats) if cats is not None else series.astype("category").array
+                arr = np.ascontiguousarray(cat.codes)
+                d["n_classes"] = int(spec.n_classes)
+            else:
+                arr, bad = _raw_array(series)
+                if spec.type == "ordinal":
+                    non_numeric[j] += bad
+                    d["n_classes"] = int(st.get("n_classes", spec.n_classes or 0))
+                elif spec.type == "real":
+                    std = float(st.get("std", 1.0))
+                    d["a"], d["b"] = float(st.get("mean", 0.0)), (std if std > 0 else 1.0)
+                elif spec.type == "pos":
+                    d["a"], d["b"] = float(st.get("mean_log", 0.0)), float(st.get("std_log", 1.0))
+                else:
+                    d["a"] = float(st.get("offset", 0.0))
+            if spec.type in ("real", "pos", "count"):
+                d["slot"] = i_num
+                i_num += 1
+            else:
+                d["slot"] = i_disc
+                i_disc += 1
+            with warnings.catch_warnings():  # (frames hand out read-only views; the packer only reads)
+                warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
+                t = torch.from_numpy(arr).to(dev, non_blocking=True)
+            keep.append(t)
+            d["src"] = t.data_ptr()
+            d["src_dtype"] = _RAW[arr.dtype]
+        desc_t = torch.from_numpy(desc.view(np.uint8)).to(dev)
+        engine.pack_columns(desc_t, stop - start, xnum[start:], codes[start:], mask[start:], rejected)
+        torch.cuda.current_stream(dev).synchronize()  # the raw columns may go now
+        del keep
+    rej = rejected.cpu().numpy()
+    for j, column in enumerate(names):
+        t = schema[column].type
+        if t == "pos" and rej[j]:
+            raise ValueError(f"Column '{column}' of type 'pos' must be >= -1 to apply log1p")
+        if t == "count" and rej[j]:
+            raise ValueError(f"Column '{column}' of type 'count' must be non-negative")
+        if t == "ordinal" and (rej[j] or non_numeric[j]):
+            n_classes = int(stats.get(column, {}).get("n_classes", schema[column].n_classes or 0))
+            warnings.warn(
+                f"Column '{column}' contains ordinal values outside [0, {n_classes - 1}] or non-numeric entries; "
+                "they will be treated as missing.", UserWarning, stacklevel=2)
+    return xnum[:, :n_num], codes[:, :n_disc], mask
+
+
+class FrameAssembler:
+    """Generated rows -> DataFrame without per-column device copies, dtype conversions or ``pd.concat``: every chunk's
+    row-major decode outputs are regrouped on the device into columnar blocks (float32 | int64 counts | int16 / int8
+    codes: ``suave_unpack_columns``) and copied straight into their place in host blocks sized for the whole request
+    (pinned while they are small enough); the frame wraps rows of those blocks.  Values and dtypes are those of
+    ``frame_from_packed``."""
+
+    _PIN_LIMIT = 2 << 30
+
+    def __init__(self, schema: Schema, stats: Mapping[str, Mapping[str, object]], engine, n_rows: int, chunk_rows: int):
+        import torch
+
+        self.schema, self.stats, self.engine, self.n = schema, stats, engine, int(n_rows)
+        self.plan: List[Tuple[str, int, int]] = []  # (column, block, row in block)
+        counts = [0, 0, 0, 0]
+        desc = []
+        i_num = i_disc = 0
+        for column in schema.feature_names:
+            spec = schema[column]
+            if spec.type in ("real", "pos", "count"):
+                blk, src = (1 if spec.type == "count" else 0), i_num
+                i_num += 1
+            else:
+                blk, src = (3 if int(spec.n_classes or 0) <= 127 else 2), i_disc
+                i_disc += 1
+            self.plan.append((column, blk, counts[blk]))
+            desc.append((blk, src, counts[blk], 0))
+            counts[blk] += 1
+        dts = (torch.float32, torch.int64, torch.int16, torch.int8)
+        total = sum(c * self.n * torch.empty((), dtype=d).element_size() for c, d in zip(counts, dts))
+        pin = total <= self._PIN_LIMIT
+        self.host = [torch.empty((c, self.n), dtype=d, pin_memory=pin and c > 0) for c, d in zip(counts, dts)]
+        self.dev = [torch.empty((max(c, 1), chunk_rows), dtype=d, device=engine.device) for c, d in zip(counts, dts)]
+        self.desc = torch.from_numpy(np.array(desc, dtype=_UNPACK_COL).view(np.uint8)).to(engine.device)
+        self.n_out = len(desc)
+        self.chunk_rows = int(chunk_rows)
+
+    def add(self, start: int, out_num, out_codes) -> None:
+        """Rows [start, start + nb) of the request: the decode outputs of one chunk (device tensors)."""
+
+        nb = int(out_num.shape[0]) if out_num.numel() else int(out_codes.shape[0])
+        self.engine.unpack_columns(self.desc, self.n_out, nb, out_num, out_codes, self.dev, self.chunk_rows)
+        for h, d in zip(self.host, self.dev):
+            if h.shape[0]:
+                h[:, start:start + nb].copy_(d[: h.shape[0], :nb], non_blocking=True)
+
+    def frame(self) -> pd.DataFrame:
+        import torch
+
+        torch.cuda.current_stream(self.engine.device).synchronize()
+        blocks = [h.numpy() for h in self.host]
+        data: Dict[str, object] = {}
+        for column, blk, row in self.plan:
+            spec = self.schema[column]
+            if blk <= 1:
+                data[column] = blocks[blk][row]
+                continue
+            cats = self.stats.get(column, {}).get("categories")
+            n_classes = int(spec.n_classes or 0)
+            cat_list = list(cats) if cats is not None else list(range(n_classes))
+            if len(cat_list) < n_classes:
+                warnings.warn(
+                    "Column '%s' produced %d unseen categorical levels during sampling; extending the category list "
+                    "with numeric placeholders." % (column, n_classes - len(cat_list)), RuntimeWarning, stacklevel=2)
+                cat_list.extend(range(len(cat_list), n_classes))
+            data[column] = pd.Categorical.from_codes(blocks[blk][row], categories=cat_list,
+                                                     ordered=(spec.type == "ordinal"))
+        return pd.DataFrame(data, copy=False)

@@ -25,9 +25,14 @@ class PackedTable:
     """The mixed-type table resident in HBM in packed form (include/suave_hip.h)."""
 
     def __init__(self, xnum, codes, mask, device):
-        self.xnum = torch.as_tensor(np.ascontiguousarray(xnum, np.float32)).to(device)
-        self.codes = torch.as_tensor(np.ascontiguousarray(codes, np.int16)).to(device)
-        self.mask = torch.as_tensor(np.ascontiguousarray(mask, np.uint8)).to(device)
+        if isinstance(mask, torch.Tensor):  # already on the device (data.pack_frame_device)
+            self.xnum = xnum.to(device=device, dtype=torch.float32).contiguous()
+            self.codes = codes.to(device=device, dtype=torch.int16).contiguous()
+            self.mask = mask.to(device=device, dtype=torch.uint8).contiguous()
+        else:
+            self.xnum = torch.as_tensor(np.ascontiguousarray(xnum, np.float32)).to(device)
+            self.codes = torch.as_tensor(np.ascontiguousarray(codes, np.int16)).to(device)
+            self.mask = torch.as_tensor(np.ascontiguousarray(mask, np.uint8)).to(device)
         self.n_rows = int(self.mask.shape[0])
         if self.xnum.shape[0] != self.n_rows or self.codes.shape[0] != self.n_rows:
             raise ValueError("xnum / codes / mask must have the same number of rows")
@@ -101,6 +106,26 @@ class Engine:
             self._ws = torch.empty(int(nbytes.value) + 256, dtype=torch.uint8, device=self.device)
             self._ws_rows = rows
         return self._ws
+
+    # -- data formats either side of the path (f1 / f2) -----------------------------
+    def pack_columns(self, desc: torch.Tensor, n_rows: int, xnum: torch.Tensor, codes: torch.Tensor, mask: torch.Tensor,
+                     rejected: torch.Tensor) -> None:
+        """suave_pack_columns: ``desc`` is the device image of ``n_cols`` suave_pack_col_t records."""
+
+        _lib.check(self.lib.suave_pack_columns(self._plan, desc.data_ptr(), int(n_rows), _ptr(xnum), int(xnum.stride(0)),
+                                               _ptr(codes), int(codes.stride(0)), mask.data_ptr(), int(mask.stride(0)),
+                                               rejected.data_ptr(), self._stream()), "suave_pack_columns")
+
+    def unpack_columns(self, desc: torch.Tensor, n_out: int, n_rows: int, out_num: torch.Tensor, out_codes: torch.Tensor,
+                       blocks, ld_rows: int) -> None:
+        """suave_unpack_columns into the four columnar device blocks (float32, int64, int16, int8)."""
+
+        _lib.check(self.lib.suave_unpack_columns(self._plan, desc.data_ptr(), int(n_out), int(n_rows), _ptr(out_num),
+                                                 int(out_num.stride(0)) if out_num.numel() else self.layout.n_num,
+                                                 _ptr(out_codes),
+                                                 int(out_codes.stride(0)) if out_codes.numel() else self.layout.n_disc,
+                                                 blocks[0].data_ptr(), blocks[1].data_ptr(), blocks[2].data_ptr(),
+                                                 blocks[3].data_ptr(), int(ld_rows), self._stream()), "suave_unpack_columns")
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream

@@ -33,6 +33,8 @@ EXPORTS = (
     "suave_head_params_width",
     "suave_decode_params",
     "suave_decode_log_px",
+    "suave_pack_columns",
+    "suave_unpack_columns",
     "suave_gemm_arithmetic_set",
     "suave_gemm_arithmetic_get",
     "suave_profile_enable",
@@ -91,6 +93,8 @@ def load():
     lib.suave_head_params_width.argtypes = [vp, i32, C.POINTER(i32)]
     lib.suave_decode_params.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, sz, vp, vp]
     lib.suave_decode_log_px.argtypes = [vp, vp, vp, vp, C.POINTER(BatchT), vp, sz, vp, vp, vp]
+    lib.suave_pack_columns.argtypes = [vp, vp, i64, vp, i32, vp, i32, vp, i32, vp, vp]
+    lib.suave_unpack_columns.argtypes = [vp, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, vp, i64, vp]
     lib.suave_gemm_arithmetic_set.argtypes = [C.c_int]
     lib.suave_gemm_arithmetic_get.argtypes = [C.POINTER(C.c_int)]
     lib.suave_profile_enable.argtypes = [C.c_int]

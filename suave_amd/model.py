@@ -200,9 +200,23 @@ class SUAVE:
             return 1.0
         return max(self._tau_min, self._tau_start - self._tau_decay * float(epoch))
 
+    def _pack(self, X: pd.DataFrame):
+        """DataFrame -> packed table columns on the device (normalisation fused: ``suave_pack_columns``)."""
+
+        return data_utils.pack_frame_device(X, self.schema, self._norm_stats_per_col, self._engine)
+
     def _table(self, X: pd.DataFrame) -> PackedTable:
-        xnum, codes, mask = data_utils.pack_frame(X.reset_index(drop=True), self.schema, self._norm_stats_per_col)
+        xnum, codes, mask = self._pack(X.reset_index(drop=True))
         return PackedTable(xnum, codes, mask, self._engine.device)
+
+    def _frame(self, out_num: torch.Tensor, out_codes: torch.Tensor) -> pd.DataFrame:
+        """Decoded columns (device, row-major) -> DataFrame (``sampling.decoder_outputs_to_frame``)."""
+
+        n = int(out_num.shape[0]) if self._layout.n_num else int(out_codes.shape[0])
+        asm = data_utils.FrameAssembler(self.schema, self._norm_stats_per_col, self._engine, n, max(n, 1))
+        if n:
+            asm.add(0, out_num, out_codes)
+        return asm.frame()
 
     def _require_fitted(self, what: str) -> None:
         if not self._is_fitted or self._engine is None:
@@ -768,7 +782,7 @@ class SUAVE:
             class_off_t = torch.from_numpy(class_off).to(eng.device)
         else:
             cdf = self._prior_cdf()
-        frames = []
+        asm = data_utils.FrameAssembler(self.schema, self._norm_stats_per_col, eng, n_samples, min(chunk, max(n_samples, 1)))
         nz = _noise or {}
 
         def rows_of(key, start, nb):  # the chunk's rows of an injected draw tensor
@@ -790,9 +804,8 @@ class SUAVE:
                                              noise_normal=rows_of("normal", start, nb),
                                              noise_uniform=rows_of("uniform", start, nb),
                                              noise_exp=rows_of("exp", start, nb))
-            frames.append(data_utils.frame_from_packed(onum.cpu().numpy(), ocodes.cpu().numpy(), self.schema,
-                                                       self._norm_stats_per_col))
-        return pd.concat(frames, ignore_index=True) if len(frames) > 1 else frames[0]
+            asm.add(start, onum, ocodes)
+        return asm.frame()
 
     # ------------------------------------------------------------------
     def impute(self, X: pd.DataFrame, *, only_missing: bool = True,
@@ -816,7 +829,7 @@ class SUAVE:
         eng = self._engine
         seed = self.random_state if seed is None else int(seed)
         aligned = X.loc[:, list(self.schema.feature_names)].reset_index(drop=True)
-        xnum, codes, mask = data_utils.pack_frame(aligned, self.schema, self._norm_stats_per_col)
+        xnum, codes, mask = self._pack(aligned)
         table = PackedTable(xnum, codes, mask, eng.device)
         K, D = self.n_components, self.latent_dim
         tau = self._inference_tau if self.behaviour == "unsupervised" else None
@@ -853,16 +866,16 @@ class SUAVE:
             onum, ocodes = eng.decode_sample(z, component=comp, assignments=assign, seed=seed + 1, row_offset=s0,
                                              noise_normal=rows_of("normal", s0, nb), noise_uniform=rows_of("uniform", s0, nb),
                                              noise_exp=rows_of("exp", s0, nb))
-            nums.append(onum.cpu().numpy())
-            cods.append(ocodes.cpu().numpy())
+            nums.append(onum)
+            cods.append(ocodes)
         if _routing is not None:
             _routing["latent"] = torch.cat(lat) if lat else torch.empty((0, D), device=eng.device)
             _routing["assignments"] = torch.cat(asg) if asg else torch.empty((0, K), device=eng.device)
-        n_num = sum(1 for n in self.schema.feature_names if self.schema[n].type in ("real", "pos", "count"))
-        onum_all = np.concatenate(nums) if nums else np.empty((0, n_num), np.float32)
-        ocodes_all = np.concatenate(cods) if cods else np.empty((0, len(self.schema.feature_names) - n_num), np.int16)
-        recon = data_utils.frame_from_packed(onum_all, ocodes_all, self.schema, self._norm_stats_per_col)
-        return self._merge_observed(X, aligned, recon, mask, only_missing)
+        lay = self._layout
+        onum_all = torch.cat(nums) if nums else torch.empty((0, max(lay.n_num, 1)), device=eng.device)
+        ocodes_all = torch.cat(cods) if cods else torch.empty((0, max(lay.n_disc, 1)), dtype=torch.int16, device=eng.device)
+        recon = self._frame(onum_all, ocodes_all)
+        return self._merge_observed(X, aligned, recon, mask.cpu().numpy(), only_missing)
 
     # ------------------------------------------------------------------
     def _ensure_classifier(self, what: str) -> None:
@@ -899,21 +912,18 @@ class SUAVE:
 
         names = list(self.schema.feature_names)
         aligned = X.loc[:, names].reset_index(drop=True)
-        xnum, codes, m = data_utils.pack_frame(aligned, self.schema, self._norm_stats_per_col)
+        xnum, codes, m = self._pack(aligned)
+        dev = self._engine.device
         if mask is not None:
             mm = np.asarray(mask.loc[:, names] if isinstance(mask, pd.DataFrame) else mask, dtype=bool)
-            m = (m.astype(bool) & ~mm).astype(np.uint8)
-        j = names.index(attr_name)
-        m[:, j] = 0
-        i_num = i_disc = 0
-        for jj, nme in enumerate(names):
-            if self.schema[nme].type in ("real", "pos", "count"):
-                xnum[m[:, jj] == 0, i_num] = 0.0
-                i_num += 1
-            else:
-                codes[m[:, jj] == 0, i_disc] = -1
-                i_disc += 1
-        return PackedTable(xnum, codes, m, self._engine.device)
+            m = m * (~torch.from_numpy(np.ascontiguousarray(mm)).to(dev)).to(torch.uint8)
+        m[:, names.index(attr_name)] = 0
+        is_num = [self.schema[nme].type in ("real", "pos", "count") for nme in names]
+        num_idx = torch.tensor([jj for jj, f in enumerate(is_num) if f], dtype=torch.long, device=dev)
+        disc_idx = torch.tensor([jj for jj, f in enumerate(is_num) if not f], dtype=torch.long, device=dev)
+        xnum = xnum.masked_fill(m[:, num_idx] == 0, 0.0)      # masked cells are zero-filled / coded -1 (Q7)
+        codes = codes.masked_fill(m[:, disc_idx] == 0, -1)
+        return PackedTable(xnum, codes, m, dev)
 
     def predict_proba(self, X: pd.DataFrame, attr=None, *, mask=None, L: int = 100, seed: Optional[int] = None):
         """attr=None: calibrated classifier probabilities (model.py:3797-3815).  Otherwise the Monte-Carlo posterior
@@ -1055,7 +1065,7 @@ class SUAVE:
         seed = self.random_state if seed is None else int(seed)
         names = list(self.schema.feature_names)
         aligned = X.loc[:, names].reset_index(drop=True)
-        xnum, codes, mask = data_utils.pack_frame(aligned, self.schema, self._norm_stats_per_col)
+        xnum, codes, mask = self._pack(aligned)
         table = PackedTable(xnum, codes, mask, eng.device)
         B, L = table.n_rows, int(L)
         lay = self._layout
@@ -1074,9 +1084,8 @@ class SUAVE:
                 onum_all[s0:s0 + nb, : lay.n_num] = v.mean(dim=0)
             if lay.n_disc:
                 ocode_all[s0:s0 + nb, : lay.n_disc] = torch.mode(ocodes.view(L, nb, -1), dim=0).values
-        recon = data_utils.frame_from_packed(onum_all[:, : lay.n_num].cpu().numpy(), ocode_all[:, : lay.n_disc].cpu().numpy(),
-                                             self.schema, self._norm_stats_per_col)
-        return self._merge_observed(X, aligned, recon, mask, only_missing)
+        recon = self._frame(onum_all, ocode_all)
+        return self._merge_observed(X, aligned, recon, mask.cpu().numpy(), only_missing)
 
     def _merge_observed(self, X, aligned, recon, mask, only_missing):
         if only_missing:
