@@ -130,25 +130,18 @@ __device__ __forceinline__ void split4(const float4 v, float scale, bf16x4 (&p)[
   }
 }
 
-// kEpiReluDrop on one quad of a row: (+ addend) + bias, ReLU, dropout (hashed keep decision: 16 bits of a per-(row,
-// column pair) hash against round(p * 65536); or the injected mask)
+// kEpiReluDrop on one quad of a row: (+ addend) + bias, ReLU, dropout (hashed keep decisions or the injected mask)
 __device__ __forceinline__ void relu_drop_quad(const GemmArgs& a, float (&v)[4], const float4& addend, const float (&bias4)[4],
-                                               bool hashed_drop, uint32_t key, uint32_t rid, int col, int ncol,
-                                               uint32_t thr16, float inv_keep, int row) {
+                                               bool hashed_drop, uint32_t keep4, int col, int ncol, float inv_keep, int row) {
   if (a.H != nullptr) {  // first encoder layer of wide schemas: + the embedding rows (embed.hip)
     v[0] += addend.x; v[1] += addend.y; v[2] += addend.z; v[3] += addend.w;
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
   if (a.drop_p > 0.f) {
-    if (hashed_drop) {
-      const uint32_t hrow = drop_row_hash(key, rid);
-      const uint32_t h0 = hash32(hrow ^ (static_cast<uint32_t>(col >> 1) * 0x85EBCA77u));
-      const uint32_t h1 = hash32(hrow ^ (static_cast<uint32_t>((col >> 1) + 1) * 0x85EBCA77u));
-      v[0] = (h0 & 0xFFFFu) >= thr16 ? v[0] * inv_keep : 0.f;
-      v[1] = (h0 >> 16) >= thr16 ? v[1] * inv_keep : 0.f;
-      v[2] = (h1 & 0xFFFFu) >= thr16 ? v[2] * inv_keep : 0.f;
-      v[3] = (h1 >> 16) >= thr16 ? v[3] * inv_keep : 0.f;
+    if (hashed_drop) {  // keep4: the quad's four keep decisions, hashed before the K loop (gemm_body)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ((keep4 >> e) & 1u) ? v[e] * inv_keep : 0.f;
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -551,6 +544,58 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   // Two register sets: while tile t is multiplied out of LDS, the global loads of tiles t+1 and t+2
   // are in flight (the chip needs ~2 us of loads in flight per CU; one K step is < 1 us of MFMA).
   // Tiles past the end load nothing real and store zeros into a buffer nobody multiplies.
+  // Dropout keep decisions of this lane's 16 output quads (16 bits of a per-(row, column pair) hash against
+  // round(p * 65536)), packed as 64 bits.  They depend on nothing the K loop computes, so the row ids are fetched first
+  // and the hashes run while the first operand tiles are in flight -- issue slots the wave would spend waiting --
+  // instead of in the epilogue.
+  const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const uint32_t thr16 = a.drop_p > 0.f ? min(65535u, static_cast<uint32_t>(a.drop_p * 65536.0f + 0.5f)) : 0u;
+  const bool hashed_drop = EPI == kEpiReluDrop && a.drop_p > 0.f && a.keep == nullptr;
+  uint32_t keep_lo = 0xFFFFFFFFu, keep_hi = 0xFFFFFFFFu;
+  uint32_t drop_rid[2][4][2];
+  if (EPI == kEpiReluDrop && hashed_drop && act) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = m0 + wm * 64 + mi * 32 + 8 * g + (lane >> 4) + 4 * h;
+          uint32_t rid = 0u;
+          if (row < a.M) {
+            if (a.row_vdiv > 1) {
+              const int drow = row / a.row_vdiv;
+              const uint32_t trow = a.row_ids ? static_cast<uint32_t>(a.row_ids[drow]) : static_cast<uint32_t>(a.row_begin + drow);
+              rid = trow * static_cast<uint32_t>(a.row_vdiv) + static_cast<uint32_t>(row - drow * a.row_vdiv);
+            } else {
+              rid = a.row_ids ? static_cast<uint32_t>(a.row_ids[row]) : static_cast<uint32_t>(a.row_begin + row);
+            }
+          }
+          drop_rid[mi][g][h] = rid;
+        }
+  }
+  auto drop_bits = [&]() {
+    if (!(EPI == kEpiReluDrop && hashed_drop && act)) return;
+    const uint32_t key = hash32(static_cast<uint32_t>(a.seed) ^ hash32(static_cast<uint32_t>(a.seed >> 32) + a.stream_id)) ^
+                         hash32(static_cast<uint32_t>(a.step) * 0x9E3779B1u + 0x632BE5ABu);
+    const int col = n0 + wn * 64 + (lane & 15) * 4;
+    const uint32_t c0 = static_cast<uint32_t>(col >> 1) * 0x85EBCA77u, c1 = static_cast<uint32_t>((col >> 1) + 1) * 0x85EBCA77u;
+    keep_lo = 0u;
+    keep_hi = 0u;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t hrow = drop_row_hash(key, drop_rid[mi][g][h]);
+          const uint32_t h0 = hash32(hrow ^ c0), h1 = hash32(hrow ^ c1);
+          const uint32_t four = ((h0 & 0xFFFFu) >= thr16 ? 1u : 0u) | ((h0 >> 16) >= thr16 ? 2u : 0u) |
+                                ((h1 & 0xFFFFu) >= thr16 ? 4u : 0u) | ((h1 >> 16) >= thr16 ? 8u : 0u);
+          const int wi = ((mi * 4 + g) * 2 + h) * 4;  // compile-time after unrolling
+          if (wi < 32) keep_lo |= four << wi; else keep_hi |= four << (wi - 32);
+        }
+  };
   float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
   uint32_t ok0 = 0, ok1 = 0;
   if constexpr (SPLIT > 0) {
@@ -562,6 +607,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
     constexpr std::false_type kNoMask{};
     const int nfull = GRP != 0 ? 0 : (k_end - k_begin) / BK;  // tiles 0 .. nfull-1 lie entirely inside [k_begin, k_end)
     load_tiles(k_begin, ra0, rb0, ok0);
+    drop_bits();
     store_tiles(k_begin, 0, ra0, rb0, ok0, kMask);
     load_tiles(k_begin + BK, ra0, rb0, ok0);
     load_tiles(k_begin + 2 * BK, ra1, rb1, ok1);
@@ -590,6 +636,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
     if (t < nk) compute(0);
   } else {
   load_tiles(k_begin, ra0, rb0, ok0);
+  drop_bits();
   store_tiles(k_begin, 0, ra0, rb0, ok0, std::true_type{});
   load_tiles(k_begin + BK, ra0, rb0, ok0);
   load_tiles(k_begin + 2 * BK, ra1, rb1, ok1);
@@ -642,12 +689,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   } else {
     if (do_bias && m0 + tid < a.M) Cout[(size_t)(m0 + tid) * a.ldc + a.ones_col] = bias_acc;
   }
-  const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-  // keep decision: 16 bits of a per-(row, column pair) hash against round(p * 65536)
-  const uint32_t thr16 = a.drop_p > 0.f ? min(65535u, static_cast<uint32_t>(a.drop_p * 65536.0f + 0.5f)) : 0u;
-  const uint32_t key = hash32(static_cast<uint32_t>(a.seed) ^ hash32(static_cast<uint32_t>(a.seed >> 32) + a.stream_id)) ^
-                       hash32(static_cast<uint32_t>(a.step) * 0x9E3779B1u + 0x632BE5ABu);
-  const bool hashed_drop = EPI == kEpiReluDrop && a.drop_p > 0.f && a.keep == nullptr;
   constexpr int LDP = 68;
   __syncthreads();  // every wave is done with the operand tiles
   float* patch = smem + wave * (8 * LDP);
@@ -682,7 +723,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
       const int row_tile = m0 + wm * 64 + mi * 32;
       if (row_tile >= a.M) continue;
       int orow_[4][2];
-      uint32_t rid_[4][2];
       float4 hq_[4][2];
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -693,16 +733,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
           int orow = ok ? row : -1;
           if (GRP == 1 && ok) orow = a.perm[row];
           orow_[g][h] = orow;
-          rid_[g][h] = 0u;
-          if (hashed_drop && ok) {
-            if (a.row_vdiv > 1) {
-              const int drow = row / a.row_vdiv;
-              const uint32_t trow = a.row_ids ? static_cast<uint32_t>(a.row_ids[drow]) : static_cast<uint32_t>(a.row_begin + drow);
-              rid_[g][h] = trow * static_cast<uint32_t>(a.row_vdiv) + static_cast<uint32_t>(row - drow * a.row_vdiv);
-            } else {
-              rid_[g][h] = a.row_ids ? static_cast<uint32_t>(a.row_ids[row]) : static_cast<uint32_t>(a.row_begin + row);
-            }
-          }
         }
       if (need_h) {
 #pragma unroll
@@ -741,8 +771,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += bias4[e];
           } else if (EPI == kEpiReluDrop) {
-            relu_drop_quad(a, v, hq_[g][h], bias4, hashed_drop, key, rid_[g][h], col, ncol, thr16, inv_keep,
-                           row_tile + 8 * g + lrow);
+            {
+              const int wi = ((mi * 4 + g) * 2 + h) * 4;  // compile-time after unrolling
+              relu_drop_quad(a, v, hq_[g][h], bias4, hashed_drop, ((wi < 32 ? keep_lo : keep_hi) >> (wi & 31)) & 15u, col, ncol,
+                             inv_keep, row_tile + 8 * g + lrow);
+            }
             if (a.mask_out != nullptr) {  // v >= 0 here: positive <=> any bit set
               const int wi = ((mi * 4 + g) * 2 + h) * 4;  // compile-time after unrolling
 #pragma unroll
