@@ -219,7 +219,7 @@ struct GemmArgs {
   float drop_p;
   uint64_t seed, step;
   uint32_t stream_id;
-  // Selected-component encoder head (rows sorted by component, see latent.hip k_assign / k_group_scan):
+  // Selected-component encoder head (rows sorted by component, see latent.hip k_assign / k_group_scatter):
   //   grouped == 1: rows of A and C are sorted positions, read / written through perm; row r of B is
   //                 weight row head_row(q0 + r, component of the tile)        (forward and data gradient)
   //   grouped == 2: the k rows of A and B are sorted positions read through perm; split s is chunk s
