@@ -40,6 +40,6 @@ for B, dropout in ((4096, 0.1), (1000, 0.1), (256, 0.0)):
         if e > worst[1]:
             worst = (k, e)
     flips = int((res["component"].cpu().numpy().astype(np.int64) != ref["component_indices"]).sum())
-    print(f"SPLIT={os.environ.get('SUAVE_GEMM_SPLIT', '3')} B={B} dropout={dropout}: worst grad err/scale {worst[1]:.2e} ({worst[0]}), "
+    print(f"SPLIT={os.environ.get('SUAVE_GEMM_SPLIT', '4 (default)')} B={B} dropout={dropout}: worst grad err/scale {worst[1]:.2e} ({worst[0]}), "
           f"recon {rel_err(res['reconstruction'].cpu().numpy(), ref['reconstruction']):.2e}, "
           f"latent {rel_err(res['latent'].cpu().numpy(), ref['latent']):.2e}, component flips {flips}")

@@ -261,6 +261,30 @@ def test_wide_softmax_class_counts_match_oracle(classes):
     _grad_check(eng.grad_state(), ref["grads"])
 
 
+def test_gradients_of_a_small_shard_of_a_huge_global_batch_keep_their_precision():
+    """Data-parallel shards pass global_rows >> shard rows, so every gradient carries a factor 1 / global_rows: 2^-24
+    here.  The fp16-plane GEMMs pre-scale gradient operands by a power of two (GemmArgs::a_scale); the result must be
+    the small-batch gradient times rows / global_rows to fp32 accuracy, not to fp16's."""
+
+    import torch
+    from suave_amd.engine import PackedTable
+
+    cols = s64_columns(64, real_variant="scaled")
+    om = orc.OracleModel(cols, n_components=10, latent_dim=32, hidden=(256, 128), dropout=0.1)
+    P = om.init_params(seed=3)
+    B = 2048
+    xnum, codes, mask = synth_packed(cols, B, 0.1, seed=7)
+    eng = _engine(om, P)
+    table = PackedTable(xnum, codes, mask, eng.device)
+    eng.elbo(table, 0, B, beta_scale=1.0, tau=1.0, grad=True, seed=3, step=1, global_rows=B)
+    g_small = eng.grads.double().clone()
+    eng.elbo(table, 0, B, beta_scale=1.0, tau=1.0, grad=True, seed=3, step=1, global_rows=B << 13)
+    g_huge = eng.grads.double().clone() * float(1 << 13)
+    scale = g_small.abs().max().item()
+    assert torch.isfinite(g_huge).all() and scale > 0
+    assert (g_huge - g_small).abs().max().item() <= 2e-6 * scale
+
+
 def test_row_index_gather_and_determinism():
     """A permuted batch through row_index equals the contiguous batch of the permuted table, bit for bit,
     and two identical launches give bit-identical gradients (no float atomics anywhere)."""
