@@ -611,7 +611,7 @@ int encoder_trunk_forward(const suave_plan* p, const float* params, const suave_
     g.seed = nz ? nz->seed : 0;
     g.step = nz ? nz->step : 0;
     g.stream_id = kStreamEncDrop + i;
-    g.mask_out = w.mask_e[i];
+    g.mask_out = gemm_small_rows(batch->n_rows) ? nullptr : w.mask_e[i];
     if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
     act = w.he[i];
     ld_act = p->ldH[i];
@@ -828,6 +828,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   SUAVE_REQUIRE(dlatent == nullptr || m.behaviour == 0, "dlatent is only defined for the supervised branch (model.py:1987-1991)");
   SUAVE_REQUIRE(global_rows >= 1, "global_rows must be positive");
   t_grad_scale = grad_scale_for(global_rows);
+  GemmSmallScope small_scope;
   if (batch->n_rows == 0) {  // an empty shard still owes its gradient (zero) and its event to the all-reduce
     if (grads) SUAVE_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * m.n_params, s));
     if (ready_event) SUAVE_CHECK_HIP(hipEventRecord(ready_event, s));
@@ -944,7 +945,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     ld_act = p->ldD;
     for (int i = 0; i < nh; ++i) {
       if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], B, true, drop_p, nz->dec_keep[i], batch,
-                             nz, kStreamDecDrop + i, 1, s, grad ? w.mask_d[i] : nullptr))
+                             nz, kStreamDecDrop + i, 1, s, (grad && !gemm_small_rows(B)) ? w.mask_d[i] : nullptr))
         return rc;
       act = w.hd[i];
       ld_act = p->ldH[i];
@@ -954,7 +955,8 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   }
   // the per-layer launches leave sign bits of the hidden activations for the data gradients; the fused chains do not
   static const bool sign_bits = getenv("SUAVE_NO_SIGN_BITS") == nullptr;  // measurement knob: read the activations instead
-  const bool dec_masks = sign_bits && !decoder_chain_ok(p), enc_masks = sign_bits && !encoder_chain_ok(p);
+  const bool dec_masks = sign_bits && !decoder_chain_ok(p) && !gemm_small_rows(B);
+  const bool enc_masks = sign_bits && !encoder_chain_ok(p) && !gemm_small_rows(B);
   // ---- fused likelihood (+ gradients) ----
   {
     LossArgs a{};

@@ -278,6 +278,13 @@ struct WideGemmArgs {
   float grad_scale;     // modes 1 and 2: GemmArgs::a_scale of the logit gradients
 };
 int launch_gemm_wide(const WideGemmArgs& a, int mode, hipStream_t stream);
+struct GemmSmallScope {  // alive inside an ELBO step: small batches may take gemm_small_kernel (see gemm_small_rows)
+  GemmSmallScope();
+  ~GemmSmallScope();
+  GemmSmallScope(const GemmSmallScope&) = delete;
+  GemmSmallScope& operator=(const GemmSmallScope&) = delete;
+};
+bool gemm_small_rows(int64_t M);  // the forward forms of an M-row batch take the split-K small-batch kernel (no sign words)
 int64_t gemm_mask_words(int64_t M, int N);  // 64-bit words of GemmArgs::mask_out for an M x N activation
 int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t stream);
 int gemm_split_mode_set(int mode);  // 0 on success (suave_gemm_arithmetic)

@@ -810,6 +810,142 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
   }
 }
 
+// Small batches (the reference's own defaults are 128 - 256 rows, suave/defaults.py:116-130): a 128 x 128 block tile
+// leaves a handful of blocks on 256 CUs, each the latency chain of 13 - 16 K steps of ds_write -> barrier -> ds_read ->
+// 12 MFMAs.  Here a BLOCK owns a 32 x 64 output tile and its four waves split the K range (wave w takes K steps
+// w, w + 4, ...), so a layer of K <= 256 is one round: with row-major operands (forward layers: A [M, K], W [N, K])
+// the fragment of v_mfma_f32_32x32x16_f16 -- lane l: row l & 31, k = 8 (l >> 5) .. + 7 -- is eight contiguous floats
+// of the operand's row, so every lane loads its own fragments of up to four K steps straight from global memory in
+// one go (L2 resident at these sizes; no LDS staging, no barrier in the loop), cuts them into the two fp16 planes in
+// registers and issues the three plane products per 32 x 32 tile.  The four partial tiles meet in LDS; wave w then
+// finishes register groups 4 w .. 4 w + 3 of both 32-column halves: bias, ReLU, dropout (the same per-(row, column
+// pair) hash as gemm_body, or the injected mask).  The accumulator layout (lane = column, 4 consecutive rows per
+// register group) stores 128 contiguous bytes per half wave and row.  Arithmetic mode 4 only.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
+  __shared__ float part_s[4][32][64];  // [wave][j * 16 + r][lane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles_n = (a.N + 63) / 64;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int m0 = tile_m * 32, n0 = tile_n * 64;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int arow = min(m0 + l31, a.M - 1);  // out-of-range rows / columns read a valid row and are never stored
+  const int brow0 = min(n0 + l31, a.N - 1), brow1 = min(n0 + 32 + l31, a.N - 1);
+  const float* pa = a.A + (size_t)arow * a.lda + 8 * kh;
+  const float* pb0 = a.B + (size_t)brow0 * a.ldb + 8 * kh;
+  const float* pb1 = a.B + (size_t)brow1 * a.ldb + 8 * kh;
+  const bool two = n0 + 32 < a.N;  // block-uniform: the second 32 columns exist
+  f32x16 acc[2], accx[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; accx[j][r] = 0.f; }
+  auto load8 = [&](const float* p, int k0, float (&v)[8]) {
+    // lda / ldb are multiples of 4 floats: a quad that starts inside the K range lies inside the row's storage
+    const int k = k0 + 8 * kh;
+    const float4 q0 = k < a.K ? *reinterpret_cast<const float4*>(p + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 q1 = k + 4 < a.K ? *reinterpret_cast<const float4*>(p + k0 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (k + e >= a.K) v[e] = 0.f;  // ragged K inside a quad
+  };
+  auto planes = [&](const float (&v)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const _Float16 h = (_Float16)v[e];
+      hi[e] = h;
+      lo[e] = (_Float16)((v[e] - (float)h) * kF16LoScale);
+    }
+  };
+  constexpr int G = 4;  // K steps whose loads are in flight together
+  const int n_steps = (a.K + BK - 1) / BK;
+  for (int s0 = wave; s0 < n_steps; s0 += 4 * G) {
+    float va[G][8], vb0[G][8], vb1[G][8];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int k0 = (s0 + 4 * u) * BK;  // (past the end: load8 returns zeros without touching memory)
+      load8(pa, k0, va[u]);
+      load8(pb0, k0, vb0[u]);
+      if (two) load8(pb1, k0, vb1[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      if (s0 + 4 * u >= n_steps) break;  // wave-uniform
+      f16x8 ah, al, bh, bl;
+      planes(va[u], ah, al);
+      planes(vb0[u], bh, bl);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[0], 0, 0, 0);
+      accx[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[0], 0, 0, 0);
+      accx[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[0], 0, 0, 0);
+      if (two) {
+        planes(vb1[u], bh, bl);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[1], 0, 0, 0);
+        accx[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[1], 0, 0, 0);
+        accx[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[1], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part_s[wave][j * 16 + r][lane] = acc[j][r] + accx[j][r] * kF16LoInv;
+  // this wave's share of the epilogue: register groups 4 wave .. 4 wave + 3 of both halves (rows 8 wave + 4 kh + 0..3)
+  const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const bool hashed_drop = EPI == kEpiReluDrop && a.drop_p > 0.f && a.keep == nullptr;
+  uint32_t keep_bits = 0xFFu;
+  if (hashed_drop) {  // (before the barrier: the hashes fill the wait for the other waves)
+    const uint32_t thr16 = min(65535u, static_cast<uint32_t>(a.drop_p * 65536.0f + 0.5f));
+    const uint32_t key = hash32(static_cast<uint32_t>(a.seed) ^ hash32(static_cast<uint32_t>(a.seed >> 32) + a.stream_id)) ^
+                         hash32(static_cast<uint32_t>(a.step) * 0x9E3779B1u + 0x632BE5ABu);
+    keep_bits = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + 8 * wave + 4 * kh + i;
+      uint32_t rid = 0u;
+      if (row < a.M) {
+        if (a.row_vdiv > 1) {
+          const int drow = row / a.row_vdiv;
+          const uint32_t trow = a.row_ids ? static_cast<uint32_t>(a.row_ids[drow]) : static_cast<uint32_t>(a.row_begin + drow);
+          rid = trow * static_cast<uint32_t>(a.row_vdiv) + static_cast<uint32_t>(row - drow * a.row_vdiv);
+        } else {
+          rid = a.row_ids ? static_cast<uint32_t>(a.row_ids[row]) : static_cast<uint32_t>(a.row_begin + row);
+        }
+      }
+      const uint32_t hrow = drop_row_hash(key, rid);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + 32 * j + l31;
+        const uint32_t h = hash32(hrow ^ (static_cast<uint32_t>(col >> 1) * 0x85EBCA77u));
+        const uint32_t bits16 = (col & 1) ? (h >> 16) : (h & 0xFFFFu);
+        keep_bits |= (bits16 >= thr16 ? 1u : 0u) << (4 * j + i);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + 32 * j + l31;
+    if (col >= a.N) continue;
+    const float bias = a.bias != nullptr ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + 8 * wave + 4 * kh + i;
+      if (row >= a.M) continue;
+      const int slot = j * 16 + 4 * wave + i;
+      float v = ((part_s[0][slot][lane] + part_s[1][slot][lane]) + part_s[2][slot][lane]) + part_s[3][slot][lane] + bias;
+      if (EPI == kEpiReluDrop) {
+        v = fmaxf(v, 0.f);
+        if (a.drop_p > 0.f) {
+          const bool keep = hashed_drop ? ((keep_bits >> (4 * j + i)) & 1u) != 0u : a.keep[(size_t)row * a.N + col] != 0;
+          v = keep ? v * inv_keep : 0.f;
+        }
+      }
+      a.C[(size_t)row * a.ldc + col] = v;
+    }
+  }
+}
+
 // Weight-gradient launches are (tiles, K splits) grids of a few tiles: the tiles of ONE split read the same rows of
 // both operands (dC and the layer input), so they should meet in one L2.  Workgroups go to the XCDs round-robin by
 // dispatch order; this maps dispatch position `lin` of a (T tiles, S splits) launch to (tile, split) so that the T
@@ -975,6 +1111,16 @@ inline int gemm_tiles(const GemmArgs& a) {
 }  // namespace
 
 int gemm_split_mode() { return split_mode(); }
+// Rows up to which the row-major forward forms run on gemm_small_kernel (arithmetic mode 4 only), and only inside an
+// ELBO step (GemmSmallScope): the split-K summation order differs from gemm_body's in the last bits, and the
+// inference entry points promise results that do not depend on how the caller chunks the rows.
+namespace { thread_local int t_small_scope = 0; }
+GemmSmallScope::GemmSmallScope() { ++t_small_scope; }
+GemmSmallScope::~GemmSmallScope() { --t_small_scope; }
+bool gemm_small_rows(int64_t M) {
+  static const int small_m = [] { const char* e = getenv("SUAVE_GEMM_SMALL_M"); return e ? atoi(e) : 8192; }();  // tuning knob
+  return t_small_scope > 0 && M <= small_m && split_mode() == 4;
+}
 int64_t gemm_mask_words(int64_t M, int N) {
   const int64_t tiles = N <= 64 ? ((M + 255) / 256) * ((N + 63) / 64) : ((M + 127) / 128) * ((N + 127) / 128);
   return tiles * 256;  // 4 waves x 64 words per tile
@@ -994,6 +1140,15 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   GemmArgs args = a;
   args.splits = splits;
   ProfScope prof_scope(kProfGemm, stream);
+  // small batches: the LDS-free wave-tile kernel (row-major forward forms, arithmetic mode 4)
+  if (gemm_small_rows(a.M) && !a.a_kmajor && !a.b_kmajor && a.grouped == 0 && a.H == nullptr &&
+      a.mask_out == nullptr && (a.epi == kEpiBias || a.epi == kEpiReluDrop) && (a.a_scale <= 0.f || a.a_scale == 1.0f)) {
+    const dim3 sgrid(((a.M + 31) / 32) * ((a.N + 63) / 64)), sblock(256);
+    if (a.epi == kEpiBias) hipLaunchKernelGGL(gemm_small_kernel<kEpiBias>, sgrid, sblock, 0, stream, args);
+    else hipLaunchKernelGGL(gemm_small_kernel<kEpiReluDrop>, sgrid, sblock, 0, stream, args);
+    SUAVE_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   const bool narrow = gemm_narrow(a);
   const int tiles = gemm_tiles(a);
   const dim3 grid(tiles, 1, splits), block(256);
