@@ -822,11 +822,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
 // pair) hash as gemm_body, or the injected mask).  The accumulator layout (lane = column, 4 consecutive rows per
 // register group) stores 128 contiguous bytes per half wave and row.  Arithmetic mode 4 only.
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
-  __shared__ float part_s[4][32][64];  // [wave][j * 16 + r][lane]
+__device__ __forceinline__ void gemm_small_body(const GemmArgs& a, int block, float (&part_s)[4][32][64]) {  // part_s: [wave][j * 16 + r][lane]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tiles_n = (a.N + 63) / 64;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int tile_m = block / tiles_n, tile_n = block - tile_m * tiles_n;
   const int m0 = tile_m * 32, n0 = tile_n * 64;
   const int l31 = lane & 31, kh = lane >> 5;
   const int arow = min(m0 + l31, a.M - 1);  // out-of-range rows / columns read a valid row and are never stored
@@ -850,12 +849,14 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
     for (int e = 0; e < 8; ++e)
       if (k + e >= a.K) v[e] = 0.f;  // ragged K inside a quad
   };
-  auto planes = [&](const float (&v)[8], f16x8& hi, f16x8& lo) {
+  const float a_scale = a.a_scale > 0.f ? a.a_scale : 1.0f;  // gradient operands: pre-scaled into the fp16 range
+  auto planes = [&](const float (&v)[8], float scale, f16x8& hi, f16x8& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const _Float16 h = (_Float16)v[e];
+      const float x = v[e] * scale;
+      const _Float16 h = (_Float16)x;
       hi[e] = h;
-      lo[e] = (_Float16)((v[e] - (float)h) * kF16LoScale);
+      lo[e] = (_Float16)((x - (float)h) * kF16LoScale);
     }
   };
   constexpr int G = 4;  // K steps whose loads are in flight together
@@ -873,23 +874,24 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
     for (int u = 0; u < G; ++u) {
       if (s0 + 4 * u >= n_steps) break;  // wave-uniform
       f16x8 ah, al, bh, bl;
-      planes(va[u], ah, al);
-      planes(vb0[u], bh, bl);
+      planes(va[u], a_scale, ah, al);
+      planes(vb0[u], 1.0f, bh, bl);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[0], 0, 0, 0);
       accx[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[0], 0, 0, 0);
       accx[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[0], 0, 0, 0);
       if (two) {
-        planes(vb1[u], bh, bl);
+        planes(vb1[u], 1.0f, bh, bl);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[1], 0, 0, 0);
         accx[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[1], 0, 0, 0);
         accx[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[1], 0, 0, 0);
       }
     }
   }
+  const float inv_scale = 1.0f / a_scale;  // (a power of two: exact)
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part_s[wave][j * 16 + r][lane] = acc[j][r] + accx[j][r] * kF16LoInv;
+    for (int r = 0; r < 16; ++r) part_s[wave][j * 16 + r][lane] = (acc[j][r] + accx[j][r] * kF16LoInv) * inv_scale;
   // this wave's share of the epilogue: register groups 4 wave .. 4 wave + 3 of both halves (rows 8 wave + 4 kh + 0..3)
   const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const bool hashed_drop = EPI == kEpiReluDrop && a.drop_p > 0.f && a.keep == nullptr;
@@ -927,7 +929,15 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + 32 * j + l31;
     if (col >= a.N) continue;
-    const float bias = a.bias != nullptr ? a.bias[col] : 0.f;
+    const float bias = (EPI != kEpiMaskBwd && a.bias != nullptr) ? a.bias[col] : 0.f;
+    float hv[4] = {1.f, 1.f, 1.f, 1.f};
+    if (EPI == kEpiMaskBwd) {  // the layer's output activation (post ReLU / dropout): all four loads before the stores
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + 8 * wave + 4 * kh + i;
+        if (row < a.M) hv[i] = a.H[(size_t)row * a.ldc + col];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = m0 + 8 * wave + 4 * kh + i;
@@ -940,10 +950,131 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
           const bool keep = hashed_drop ? ((keep_bits >> (4 * j + i)) & 1u) != 0u : a.keep[(size_t)row * a.N + col] != 0;
           v = keep ? v * inv_keep : 0.f;
         }
+      } else if (EPI == kEpiMaskBwd) {
+        v = hv[i] > 0.f ? v * inv_keep : 0.f;
       }
       a.C[(size_t)row * a.ldc + col] = v;
     }
   }
+}
+
+// The weight gradient of a small batch: C[split][m][n] = sum over the split's batch rows r of A[r][m] * B[r][n]
+// (A = dC [rows, lda], B = the layer input [rows, ldb]; both "k-major": the reduction index is the row), + the bias
+// gradient (plain fp32 column sums of dC) in column ones_col.  Same shape as gemm_small_kernel: a block owns a 32 x 64
+// tile of one split, its four waves take the split's 16-row steps round-robin with the loads of four steps in flight
+// (a fragment is eight rows of one column: eight dword loads, coalesced across the lanes), partial tiles meet in LDS.
+__device__ __forceinline__ void gemm_small_wgrad_body(const GemmArgs& a, int rows_per_split, int tile, int split,
+                                                      float (&part_s)[4][32][64], float (&bias_s)[4][32]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles_n = (a.N + 63) / 64;
+  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  const int m0 = tile_m * 32, n0 = tile_n * 64;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int r_begin = split * rows_per_split, r_end = min(a.K, r_begin + rows_per_split);
+  const float* pa = a.A + min(m0 + l31, a.M - 1);  // out-of-range columns read a valid one and are never stored
+  const float* pb0 = a.B + min(n0 + l31, a.N - 1);
+  const float* pb1 = a.B + min(n0 + 32 + l31, a.N - 1);
+  const bool two = n0 + 32 < a.N;
+  const float a_scale = a.a_scale > 0.f ? a.a_scale : 1.0f;
+  f32x16 acc[2], accx[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; accx[j][r] = 0.f; }
+  auto load8 = [&](const float* p, int ld, int r0, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = r0 + 8 * kh + e;
+      v[e] = r < r_end ? p[(size_t)r * ld] : 0.f;
+    }
+  };
+  auto planes = [&](const float (&v)[8], float scale, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = v[e] * scale;
+      const _Float16 h = (_Float16)x;
+      hi[e] = h;
+      lo[e] = (_Float16)((x - (float)h) * kF16LoScale);
+    }
+  };
+  constexpr int G = 4;
+  const int n_steps = (max(r_end - r_begin, 0) + BK - 1) / BK;
+  float bsum = 0.f;
+  for (int s0 = wave; s0 < n_steps; s0 += 4 * G) {
+    float va[G][8], vb0[G][8], vb1[G][8];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int r0 = r_begin + (s0 + 4 * u) * BK;  // (past the split's end: zeros, no memory access)
+      load8(pa, a.lda, r0, va[u]);
+      load8(pb0, a.ldb, r0, vb0[u]);
+      if (two) load8(pb1, a.ldb, r0, vb1[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      if (s0 + 4 * u >= n_steps) break;  // wave-uniform
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bsum += va[u][e];
+      f16x8 ah, al, bh, bl;
+      planes(va[u], a_scale, ah, al);
+      planes(vb0[u], 1.0f, bh, bl);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[0], 0, 0, 0);
+      accx[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[0], 0, 0, 0);
+      accx[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[0], 0, 0, 0);
+      if (two) {
+        planes(vb1[u], 1.0f, bh, bl);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[1], 0, 0, 0);
+        accx[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[1], 0, 0, 0);
+        accx[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[1], 0, 0, 0);
+      }
+    }
+  }
+  const float inv_scale = 1.0f / a_scale;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part_s[wave][j * 16 + r][lane] = (acc[j][r] + accx[j][r] * kF16LoInv) * inv_scale;
+  bsum += __shfl_xor(bsum, 32);
+  if (lane < 32) bias_s[wave][lane] = bsum;
+  __syncthreads();
+  float* Cout = a.C + (size_t)split * a.slab_stride;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + 32 * j + l31;
+    if (col >= a.N) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + 8 * wave + 4 * kh + i;
+      if (row >= a.M) continue;
+      const int slot = j * 16 + 4 * wave + i;
+      Cout[(size_t)row * a.ldc + col] =
+          ((part_s[0][slot][lane] + part_s[1][slot][lane]) + part_s[2][slot][lane]) + part_s[3][slot][lane];
+    }
+  }
+  if (a.ones_col >= 0 && tile_n == 0 && wave == 0 && lane < 32 && m0 + lane < a.M)
+    Cout[(size_t)(m0 + lane) * a.ldc + a.ones_col] = ((bias_s[0][lane] + bias_s[1][lane]) + bias_s[2][lane]) + bias_s[3][lane];
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
+  __shared__ float part_s[4][32][64];
+  gemm_small_body<EPI>(a, blockIdx.x, part_s);
+}
+
+__global__ __launch_bounds__(256) void gemm_small_wgrad_kernel(GemmArgs a, int rows_per_split) {
+  __shared__ float part_s[4][32][64];
+  __shared__ float bias_s[4][32];
+  gemm_small_wgrad_body(a, rows_per_split, blockIdx.x, blockIdx.y, part_s, bias_s);
+}
+
+// Both backward GEMMs of a layer over a small batch in one launch (they are independent and neither fills the chip):
+// blocks [0, w_blocks) are the weight gradient's (tile, split) pairs, the rest the data gradient's tiles.
+template <int DEPI>
+__global__ __launch_bounds__(256) void gemm_small_pair_kernel(GemmArgs d, GemmArgs w, int rows_per_split, int w_tiles, int w_blocks) {
+  __shared__ float part_s[4][32][64];
+  __shared__ float bias_s[4][32];
+  const int b = blockIdx.x;
+  if (b < w_blocks) gemm_small_wgrad_body(w, rows_per_split, b % w_tiles, b / w_tiles, part_s, bias_s);
+  else gemm_small_body<DEPI>(d, b - w_blocks, part_s);
 }
 
 // Weight-gradient launches are (tiles, K splits) grids of a few tiles: the tiles of ONE split read the same rows of
@@ -1132,6 +1263,21 @@ int gemm_split_mode_set(int mode) {
   return 0;
 }
 
+namespace {
+// forward layers and data gradients on row-major operands (the data gradient reads the transposed weight copy)
+bool small_rowmajor_ok(const GemmArgs& a) {
+  if (!gemm_small_rows(a.M) || a.a_kmajor || a.b_kmajor || a.grouped != 0 || a.mask_out != nullptr || a.mask_in != nullptr) return false;
+  if (a.epi == kEpiMaskBwd) return a.H != nullptr;
+  return (a.epi == kEpiBias || a.epi == kEpiReluDrop) && a.H == nullptr;
+}
+// weight gradients over a small batch (K = batch rows; at most 64 steps per block)
+bool small_wgrad_ok(const GemmArgs& a) {
+  static const bool off = getenv("SUAVE_NO_SMALL_WGRAD") != nullptr;  // tuning knob
+  return !off && gemm_small_rows(a.K) && a.a_kmajor && a.b_kmajor && a.grouped == 0 && a.epi == kEpiSlab && a.splits >= 1 &&
+         (a.K + a.splits - 1) / a.splits <= 1024;
+}
+}  // namespace
+
 int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   (void)n_cu;
   if (a.M <= 0 || a.N <= 0) return 0;
@@ -1140,12 +1286,19 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   GemmArgs args = a;
   args.splits = splits;
   ProfScope prof_scope(kProfGemm, stream);
-  // small batches: the LDS-free wave-tile kernel (row-major forward forms, arithmetic mode 4)
-  if (gemm_small_rows(a.M) && !a.a_kmajor && !a.b_kmajor && a.grouped == 0 && a.H == nullptr &&
-      a.mask_out == nullptr && (a.epi == kEpiBias || a.epi == kEpiReluDrop) && (a.a_scale <= 0.f || a.a_scale == 1.0f)) {
+  // small batches (inside an ELBO step, arithmetic mode 4): the split-K kernels
+  if (small_rowmajor_ok(a)) {
     const dim3 sgrid(((a.M + 31) / 32) * ((a.N + 63) / 64)), sblock(256);
     if (a.epi == kEpiBias) hipLaunchKernelGGL(gemm_small_kernel<kEpiBias>, sgrid, sblock, 0, stream, args);
-    else hipLaunchKernelGGL(gemm_small_kernel<kEpiReluDrop>, sgrid, sblock, 0, stream, args);
+    else if (a.epi == kEpiReluDrop) hipLaunchKernelGGL(gemm_small_kernel<kEpiReluDrop>, sgrid, sblock, 0, stream, args);
+    else hipLaunchKernelGGL(gemm_small_kernel<kEpiMaskBwd>, sgrid, sblock, 0, stream, args);
+    SUAVE_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  if (small_wgrad_ok(a)) {
+    const int per = ((a.K + splits - 1) / splits + BK - 1) / BK * BK;
+    const dim3 sgrid(((a.M + 31) / 32) * ((a.N + 63) / 64), splits), sblock(256);
+    hipLaunchKernelGGL(gemm_small_wgrad_kernel, sgrid, sblock, 0, stream, args, per);
     SUAVE_CHECK_HIP(hipGetLastError());
     return 0;
   }
@@ -1198,6 +1351,21 @@ int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t
                        w.epi == kEpiSlab && (d.epi == kEpiMaskBwd || d.epi == kEpiBias) &&
                        ((d.grouped == 0 && w.grouped == 0) || (d.grouped == 1 && w.grouped == 2 && d.epi == kEpiMaskBwd));
   static const bool no_pair = getenv("SUAVE_NO_PAIR") != nullptr;  // tuning knob: run the two GEMMs as two launches
+  static const bool no_small_pair = getenv("SUAVE_NO_SMALL_BWD") != nullptr;  // tuning knob
+  const bool small_pair = !no_small_pair && small_rowmajor_ok(d) && small_wgrad_ok(w);  // small batch: two split-K launches
+  if (small_pair && d.M > 0 && d.N > 0 && w.M > 0 && w.N > 0) {
+    if (int rc = check_gemm(d)) return rc;
+    if (int rc = check_gemm(w)) return rc;
+    ProfScope prof_scope(kProfGemm, stream);
+    const int per = ((w.K + w.splits - 1) / w.splits + BK - 1) / BK * BK;
+    const int w_tiles = ((w.M + 31) / 32) * ((w.N + 63) / 64), w_blocks = w_tiles * w.splits;
+    const int d_blocks = ((d.M + 31) / 32) * ((d.N + 63) / 64);
+    const dim3 sgrid(w_blocks + d_blocks), sblock(256);
+    if (d.epi == kEpiMaskBwd) hipLaunchKernelGGL(gemm_small_pair_kernel<kEpiMaskBwd>, sgrid, sblock, 0, stream, d, w, per, w_tiles, w_blocks);
+    else hipLaunchKernelGGL(gemm_small_pair_kernel<kEpiBias>, sgrid, sblock, 0, stream, d, w, per, w_tiles, w_blocks);
+    SUAVE_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (!fusable || (no_pair && d.grouped == 0)) {
     if (int rc = launch_gemm(w, n_cu, stream)) return rc;
     return launch_gemm(d, n_cu, stream);
