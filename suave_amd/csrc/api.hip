@@ -152,15 +152,25 @@ int tn_splits(const suave_plan* p, int n_out, int n_in1, int64_t rows) {
 }
 
 // blocks per column chunk of the likelihood kernel: about 28 independent wave workers per CU over all chunks
-int loss_grid(const suave_plan* p, int64_t rows) {
+int loss_grid(const suave_plan* p, int64_t rows, int n_chunks = -1) {
   const int64_t tiles = (rows + 63) / 64;
-  const int64_t nch = std::max<size_t>(1, p->chunks_host.size());
+  const int64_t nch = n_chunks > 0 ? n_chunks : std::max<size_t>(1, p->chunks_host.size());
   const int wpb = loss_workers_per_block();
   static const int wpc = [] { const char* e = getenv("SUAVE_LOSS_WPC"); return e ? std::max(1, atoi(e)) : 28; }();  // tuning knob (swept with SUAVE_LOSS_CHUNK_Y: scripts/sweep_loss.sh)
   const int64_t workers = std::min<int64_t>(tiles, (wpc * (int64_t)p->n_cu + nch - 1) / nch);
   return (int)std::max<int64_t>(1, (workers + wpb - 1) / wpb);
 }
-int loss_workers(const suave_plan* p, int64_t rows) { return loss_grid(p, rows) * loss_workers_per_block(); }
+int loss_workers(const suave_plan* p, int64_t rows, int n_chunks = -1) { return loss_grid(p, rows, n_chunks) * loss_workers_per_block(); }
+
+// Column chunks of the likelihood kernel for a step over `rows` (virtual) rows: the plan's chunks of ~24 y floats, or,
+// for a small batch inside an ELBO step (gemm_small_rows), the finer set of ~8 -- a chunk is one wave's serial chain
+// per 64 rows, and a few hundred rows leave the chip empty either way.
+struct LossChunks { const suave::ColChunk* dev; int n; };
+LossChunks loss_chunks(const suave_plan* p, int64_t rows) {
+  if (!p->chunks_small_host.empty() && gemm_small_rows(rows))
+    return LossChunks{p->chunks_dev + p->chunks_host.size(), (int)p->chunks_small_host.size()};
+  return LossChunks{p->chunks_dev, (int)p->chunks_host.size()};
+}
 
 // split count of the grouped weight-gradient GEMM of the wide categorical columns
 int wide_splits(const suave_plan* p, int64_t rows) {
@@ -245,7 +255,9 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
     w->mask_d[i] = c.take<uint64_t>((size_t)gemm_mask_words((int64_t)R, m.dec[i].n_out));
   }
   w->kidx = c.take<int32_t>(R);
-  const size_t nch = p->chunks_host.size();
+  // (sized for either chunk set when the batch is small enough for the fine one: no dependence on the call's scope)
+  const bool fine_fits = rows <= gemm_small_rows_limit() && !p->chunks_small_host.empty();
+  const size_t nch = fine_fits ? std::max(p->chunks_host.size(), p->chunks_small_host.size()) : p->chunks_host.size();
   const bool any_wide = !p->wide_host.empty();
   w->recon_part = c.take<float>((nch + 1) * R);
   w->ds_part = c.take<float>((nch + 1) * R * p->ldK);
@@ -289,7 +301,7 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
     const int ldc = round_up(l->n_in + 1, 4);
     slab += (size_t)tn_splits(p, l->n_out, l->n_in, rows) * l->n_out * ldc;
   }
-  const int lg = loss_workers(p, rows);
+  const int lg = fine_fits ? std::max(loss_workers(p, rows), loss_workers(p, rows, (int)p->chunks_small_host.size())) : loss_workers(p, rows);
   slab += (size_t)lg * m.head_len + 4;
   {
     const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components;
@@ -693,16 +705,17 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, V, false, 0.f, nullptr, batch, nz, 0, K, s))
       return rc;
   }
-  const int n_chunks = (int)p->chunks_host.size();
-  const int lgrid = loss_grid(p, V);
-  const int lworkers = loss_workers(p, V);
+  const LossChunks lch = loss_chunks(p, V);
+  const int n_chunks = lch.n;
+  const int lgrid = loss_grid(p, V, n_chunks);
+  const int lworkers = loss_workers(p, V, n_chunks);
   const int ldT = round_up(K * D + D, 4);
   size_t slab_off = 0;
   float* head_slab = w.slab;
   slab_off += ((size_t)lworkers * m.head_len + 3) & ~size_t(3);  // GEMM slabs start 16-byte aligned
   {
     LossArgs a{};
-    a.cols = p->cols_dev; a.chunks = p->chunks_dev; a.params = params; a.y = w.y; a.batch = *batch;
+    a.cols = p->cols_dev; a.chunks = lch.dev; a.params = params; a.y = w.y; a.batch = *batch;
     a.n_rows = V; a.vdiv = K; a.kidx = nullptr; a.row_weight = wflat;
     a.c_up = -1.0f / (float)global_rows; a.bk = beta_scale / (float)global_rows;
     a.K = K; a.D = D; a.ldY = p->ldY; a.ldy = p->max_chunk_y | 1; a.ldK = p->ldK; a.ldD = p->ldD; a.ldE = p->ldE;
@@ -914,9 +927,10 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     head_geometry(g);
     if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
   }
-  const int n_chunks = (int)p->chunks_host.size();
-  const int lgrid = loss_grid(p, B);
-  const int lworkers = loss_workers(p, B);
+  const LossChunks lch = loss_chunks(p, B);
+  const int n_chunks = lch.n;
+  const int lgrid = loss_grid(p, B, n_chunks);
+  const int lworkers = loss_workers(p, B, n_chunks);
   const int ldT = round_up(2 * m.latent_dim + m.n_components, 4);
   la.params = params; la.prior_logits_off = m.prior_logits_off; la.prior_mu_off = m.prior_mu_off;
   la.prior_logvar_off = m.prior_logvar_off; la.bk = beta_scale / (float)global_rows; la.grad = grad ? 1 : 0; la.ldT = ldT;
@@ -960,7 +974,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   // ---- fused likelihood (+ gradients) ----
   {
     LossArgs a{};
-    a.cols = p->cols_dev; a.chunks = p->chunks_dev; a.params = params; a.y = w.y; a.batch = *batch;
+    a.cols = p->cols_dev; a.chunks = lch.dev; a.params = params; a.y = w.y; a.batch = *batch;
     a.n_rows = B; a.vdiv = 1; a.kidx = w.kidx; a.row_weight = nullptr;
     a.c_up = -1.0f / (float)global_rows;
     a.bk = beta_scale / (float)global_rows;
@@ -1289,10 +1303,15 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
     // chunks of about equal y width, ~24 floats of y per tile row (swept together with the workers per CU: S64
     // 20/16 -> 24/28 takes 5 % off the kernel, W1024 2 %); its y tile fits the float4 slots of the register prefetch
     static const int kChunkY = [] { const char* e = getenv("SUAVE_LOSS_CHUNK_Y"); return e ? std::max(4, atoi(e)) : 24; }();  // tuning knob
-    const int n_target = std::max(1, (y + kChunkY - 1) / kChunkY);
+    static const int kChunkYSmall = [] { const char* e = getenv("SUAVE_LOSS_CHUNK_Y_SMALL"); return e ? atoi(e) : 8; }();  // tuning knob (0: off)
+    int hw_max = 0, max_y = 0, max_cc = 1;
+    for (int pass = 0; pass < 2; ++pass) {
+    const int chunk_y = pass == 0 ? kChunkY : kChunkYSmall;
+    if (chunk_y <= 0 || (pass == 1 && chunk_y >= kChunkY)) continue;
+    std::vector<ColChunk>& chunk_out = pass == 0 ? p->chunks_host : p->chunks_small_host;
+    const int n_target = std::max(1, (y + chunk_y - 1) / chunk_y);
     const int y_target = (y + n_target - 1) / n_target;
     ColChunk cur{0, 0, 0, 0};
-    int hw_max = 0, max_y = 0, max_cc = 1;
     auto w_end = [&](int c) {
       for (int n = c + 1; n < m.n_cols; ++n)
         if (!col_is_wide(cols[n])) return cols[n].w_off;
@@ -1300,7 +1319,7 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
     };
     auto close = [&]() {
       if (cur.col_end <= cur.col_begin) return;
-      p->chunks_host.push_back(cur);
+      chunk_out.push_back(cur);
       hw_max = std::max(hw_max, w_end(cur.col_end - 1) - cols[cur.col_begin].w_off);
       max_y = std::max(max_y, cur.y_len);
       max_cc = std::max(max_cc, cur.col_end - cur.col_begin);
@@ -1320,6 +1339,8 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
       cur.y_len += cols[c].y_dim;
     }
     close();
+    }
+    if (p->chunks_small_host.size() <= p->chunks_host.size()) p->chunks_small_host.clear();
     p->max_chunk_y = std::max(max_y, 1);
     hw_max = round_up(std::max(hw_max, 4), 4);
     p->hw_max = hw_max;
@@ -1363,7 +1384,7 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
     return 2;
   };
   if (hipMalloc(&p->cols_dev, sizeof(suave_col_t) * m.n_cols) != hipSuccess) return dfail("plan_create: hipMalloc failed");
-  if (hipMalloc(&p->chunks_dev, sizeof(ColChunk) * std::max<size_t>(p->chunks_host.size(), 1)) != hipSuccess) return dfail("plan_create: hipMalloc failed");
+  if (hipMalloc(&p->chunks_dev, sizeof(ColChunk) * std::max<size_t>(p->chunks_host.size() + p->chunks_small_host.size(), 1)) != hipSuccess) return dfail("plan_create: hipMalloc failed");
   if (hipMalloc(&p->enc_map_dev, sizeof(int32_t) * p->ldI) != hipSuccess) return dfail("plan_create: hipMalloc failed");
   if (hipMalloc(&p->cls_off_dev, sizeof(int32_t) * m.n_cols) != hipSuccess) return dfail("plan_create: hipMalloc failed");
   if (hipMalloc(&p->xsrc_dev, sizeof(int32_t) * m.n_cols) != hipSuccess) return dfail("plan_create: hipMalloc failed");
@@ -1385,6 +1406,9 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
   }
   if (hipMemcpy(p->cols_dev, cols, sizeof(suave_col_t) * m.n_cols, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(p->chunks_dev, p->chunks_host.data(), sizeof(ColChunk) * p->chunks_host.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      (!p->chunks_small_host.empty() &&
+       hipMemcpy(p->chunks_dev + p->chunks_host.size(), p->chunks_small_host.data(), sizeof(ColChunk) * p->chunks_small_host.size(),
+                 hipMemcpyHostToDevice) != hipSuccess) ||
       hipMemcpy(p->enc_map_dev, enc_src.data(), sizeof(int32_t) * p->ldI, hipMemcpyHostToDevice) != hipSuccess)
     return dfail("plan_create: hipMemcpy failed");
   if (p->loss_lds_bytes > 48 * 1024)

@@ -86,6 +86,7 @@ struct suave_plan {
   suave_model_t model;
   std::vector<suave_col_t> cols_host;
   std::vector<suave::ColChunk> chunks_host;
+  std::vector<suave::ColChunk> chunks_small_host;  // finer set for small batches; on the device right behind chunks_host
   suave_col_t* cols_dev = nullptr;
   suave::ColChunk* chunks_dev = nullptr;
   int device = 0;
@@ -284,6 +285,7 @@ struct GemmSmallScope {  // alive inside an ELBO step: small batches may take ge
   GemmSmallScope(const GemmSmallScope&) = delete;
   GemmSmallScope& operator=(const GemmSmallScope&) = delete;
 };
+int64_t gemm_small_rows_limit();  // the row count up to which gemm_small_rows can hold (whatever the scope / mode)
 bool gemm_small_rows(int64_t M);  // the forward forms of an M-row batch take the split-K small-batch kernel (no sign words)
 int64_t gemm_mask_words(int64_t M, int N);  // 64-bit words of GemmArgs::mask_out for an M x N activation
 int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t stream);

@@ -1248,10 +1248,11 @@ int gemm_split_mode() { return split_mode(); }
 namespace { thread_local int t_small_scope = 0; }
 GemmSmallScope::GemmSmallScope() { ++t_small_scope; }
 GemmSmallScope::~GemmSmallScope() { --t_small_scope; }
-bool gemm_small_rows(int64_t M) {
+int64_t gemm_small_rows_limit() {
   static const int small_m = [] { const char* e = getenv("SUAVE_GEMM_SMALL_M"); return e ? atoi(e) : 8192; }();  // tuning knob
-  return t_small_scope > 0 && M <= small_m && split_mode() == 4;
+  return small_m;
 }
+bool gemm_small_rows(int64_t M) { return t_small_scope > 0 && M <= gemm_small_rows_limit() && split_mode() == 4; }
 int64_t gemm_mask_words(int64_t M, int N) {
   const int64_t tiles = N <= 64 ? ((M + 255) / 256) * ((N + 63) / 64) : ((M + 127) / 128) * ((N + 127) / 128);
   return tiles * 256;  // 4 waves x 64 words per tile
