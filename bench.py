@@ -312,6 +312,8 @@ def main():
     ap.add_argument("--profile-timed", action="store_true",
                     help="bracket the launches of the timed region itself with HIP events (default: a second pass of K steps)")
     ap.add_argument("--gen-rows", type=int, default=8_000_000, help="rows per GPU for the sample() measurement (0 = skip)")
+    ap.add_argument("--gen-chunk", type=int, default=0, help="rows per decode_sample call in the generation measurements (0 = default)")
+    ap.add_argument("--mc-chunk", type=int, default=0, help="table rows per call in the 32-draw imputation (0 = default)")
     args = ap.parse_args()
 
     import torch
@@ -424,7 +426,8 @@ def main():
         print(f"[bench] training: {1e3 * elapsed / max(args.steps, 1):.4f} ms/step", file=sys.stderr, flush=True)
     gen = None
     if args.gen_rows > 0 and not wide:
-        gen = generation_rates(eng, table, rows, args.gen_rows, device, rank, world, dist, fence, prof)
+        gen = generation_rates(eng, table, rows, args.gen_rows, device, rank, world, dist, fence, prof,
+                               chunk=args.gen_chunk or 1 << 18, mc_chunk=args.mc_chunk or 1 << 14)
     elif args.gen_rows > 0:  # W1024: y_full is 68 KB a row -- smaller chunks, 1M generated rows, the table's rows imputed
         gen = generation_rates(eng, table, rows, min(args.gen_rows, 1 << 20), device, rank, world, dist, fence, prof,
                                chunk=1 << 16, mc_chunk=1 << 11, n_imp_max=1 << 17)

@@ -368,6 +368,22 @@ int suave_unpack_columns(const suave_plan* plan, const suave_unpack_col_t* cols,
 int suave_gemm_arithmetic_set(int mode);
 int suave_gemm_arithmetic_get(int* mode);
 
+/* Small-batch path of the ELBO entry points, suave_elbo_forward / _backward /
+ * _backward_overlap (no counterpart in the reference, whose
+ * default batches are 128 - 256 rows: suave/defaults.py:116-130).  An ELBO step
+ * over at most `rows` (virtual) rows, in arithmetic mode 4, runs its layer GEMMs
+ * on split-K kernels (a block per 32 x 64 output tile, the K range divided
+ * among its four waves) and its likelihood kernel on a finer column chunk set;
+ * larger steps, every other arithmetic mode and every inference entry point
+ * (whose results must not depend on how the caller chunks the rows) take the
+ * 128 x 128 tile kernels.  Results agree to fp32 summation order.  rows = 0
+ * switches the path off; the default (and largest) value is 8192, or the
+ * environment variable SUAVE_GEMM_SMALL_M.  Process-wide; size workspaces
+ * (suave_workspace_bytes) after changing it, and do not switch while a call of
+ * this library is running on another thread. */
+int suave_small_batch_rows_set(int rows);
+int suave_small_batch_rows_get(int* rows);
+
 /* Measurement aid (no counterpart in the reference): when enabled, every kernel
  * launch of the library is bracketed by HIP events on its stream;
  * suave_profile_read synchronises and returns the summed device time (ms) and

@@ -1725,6 +1725,14 @@ extern "C" int suave_unpack_columns(const suave_plan* p, const suave_unpack_col_
 
 extern "C" int suave_gemm_arithmetic_set(int mode) { return gemm_split_mode_set(mode); }
 
+extern "C" int suave_small_batch_rows_set(int rows) { return gemm_small_rows_limit_set(rows); }
+
+extern "C" int suave_small_batch_rows_get(int* rows) {
+  SUAVE_REQUIRE(rows != nullptr, "small_batch_rows_get: null argument");
+  *rows = (int)gemm_small_rows_limit();
+  return 0;
+}
+
 extern "C" int suave_gemm_arithmetic_get(int* mode) {
   SUAVE_REQUIRE(mode != nullptr, "gemm_arithmetic_get: null argument");
   *mode = gemm_split_mode();

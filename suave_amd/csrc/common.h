@@ -285,6 +285,7 @@ struct GemmSmallScope {  // alive inside an ELBO step: small batches may take ge
   GemmSmallScope(const GemmSmallScope&) = delete;
   GemmSmallScope& operator=(const GemmSmallScope&) = delete;
 };
+int gemm_small_rows_limit_set(int rows);
 int64_t gemm_small_rows_limit();  // the row count up to which gemm_small_rows can hold (whatever the scope / mode)
 bool gemm_small_rows(int64_t M);  // the forward forms of an M-row batch take the split-K small-batch kernel (no sign words)
 int64_t gemm_mask_words(int64_t M, int N);  // 64-bit words of GemmArgs::mask_out for an M x N activation

@@ -1248,9 +1248,17 @@ int gemm_split_mode() { return split_mode(); }
 namespace { thread_local int t_small_scope = 0; }
 GemmSmallScope::GemmSmallScope() { ++t_small_scope; }
 GemmSmallScope::~GemmSmallScope() { --t_small_scope; }
-int64_t gemm_small_rows_limit() {
-  static const int small_m = [] { const char* e = getenv("SUAVE_GEMM_SMALL_M"); return e ? atoi(e) : 8192; }();  // tuning knob
-  return small_m;
+namespace {
+std::atomic<int>& small_rows_cell() {
+  static std::atomic<int> rows{[] { const char* e = getenv("SUAVE_GEMM_SMALL_M"); return e ? std::max(0, atoi(e)) : 8192; }()};
+  return rows;
+}
+}  // namespace
+int64_t gemm_small_rows_limit() { return small_rows_cell().load(std::memory_order_relaxed); }
+int gemm_small_rows_limit_set(int rows) {
+  SUAVE_REQUIRE(rows >= 0 && rows <= 8192, "gemm: the small-batch path takes ELBO steps of 0 (off) .. 8192 rows");
+  small_rows_cell().store(rows, std::memory_order_relaxed);
+  return 0;
 }
 bool gemm_small_rows(int64_t M) { return t_small_scope > 0 && M <= gemm_small_rows_limit() && split_mode() == 4; }
 int64_t gemm_mask_words(int64_t M, int N) {

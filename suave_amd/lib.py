@@ -37,6 +37,8 @@ EXPORTS = (
     "suave_unpack_columns",
     "suave_gemm_arithmetic_set",
     "suave_gemm_arithmetic_get",
+    "suave_small_batch_rows_set",
+    "suave_small_batch_rows_get",
     "suave_profile_enable",
     "suave_profile_read",
 )
@@ -97,6 +99,8 @@ def load():
     lib.suave_unpack_columns.argtypes = [vp, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, vp, i64, vp]
     lib.suave_gemm_arithmetic_set.argtypes = [C.c_int]
     lib.suave_gemm_arithmetic_get.argtypes = [C.POINTER(C.c_int)]
+    lib.suave_small_batch_rows_set.argtypes = [C.c_int]
+    lib.suave_small_batch_rows_get.argtypes = [C.POINTER(C.c_int)]
     lib.suave_profile_enable.argtypes = [C.c_int]
     lib.suave_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i64), i32]
     for name in EXPORTS:

@@ -432,3 +432,76 @@ def test_other_gemm_arithmetics_match_oracle(case, mode):
             test_w1024_miniature_step_matches_oracle("supervised")
     finally:
         slib.check(L.suave_gemm_arithmetic_set(before.value), "suave_gemm_arithmetic_set")
+
+
+@pytest.mark.parametrize("case", ["s64", "s64_ragged", "golden_sup", "golden_unsup", "w1024_mini"])
+def test_large_tile_kernels_match_oracle_on_small_batches(case):
+    """ELBO steps of at most 8192 rows take the split-K small-batch kernels and the fine likelihood chunks by default,
+    so most parity tests of this suite exercise those; here the same checks run with that path switched off
+    (suave_small_batch_rows_set(0)): the 128 x 128 tile kernels, the fused backward pairs, the sign-bit masks."""
+
+    import ctypes as C
+
+    from suave_amd import lib as slib
+
+    L = slib.load()
+    before = C.c_int(-1)
+    slib.check(L.suave_small_batch_rows_get(C.byref(before)), "suave_small_batch_rows_get")
+    assert before.value == 8192
+    assert L.suave_small_batch_rows_set(8193) != 0 and L.suave_small_batch_rows_set(-1) != 0
+    slib.check(L.suave_small_batch_rows_set(0), "suave_small_batch_rows_set")
+    try:
+        if case == "s64":
+            test_s64_step_matches_oracle(4096, 0.1)
+        elif case == "s64_ragged":
+            test_s64_step_matches_oracle(1000, 0.0)
+        elif case == "golden_sup":
+            test_golden_supervised_step("elbo_sup_mixed12_drop")
+        elif case == "golden_unsup":
+            test_golden_unsupervised_step(UNSUP[0])
+        else:
+            test_w1024_miniature_step_matches_oracle("supervised")
+    finally:
+        slib.check(L.suave_small_batch_rows_set(before.value), "suave_small_batch_rows_set")
+
+
+def test_small_batch_path_and_large_tile_path_agree_to_summation_order():
+    """One S64 step of 777 rows (ragged in every tile dimension), library-generated noise and dropout, through both
+    paths: same assignments, same loss terms and gradients within the parity tolerance (the per-(row, column pair)
+    dropout hash and the Philox streams do not depend on the tiling)."""
+
+    import ctypes as C
+
+    import torch
+    from suave_amd import lib as slib
+    from suave_amd.engine import PackedTable
+
+    L = slib.load()
+    cols = s64_columns(64, real_variant="scaled")
+    om = orc.OracleModel(cols, n_components=10, latent_dim=32, hidden=(256, 128), dropout=0.1)
+    P = om.init_params(seed=3)
+    B = 777
+    xnum, codes, mask = synth_packed(cols, B, 0.1, seed=5)
+    want = ("reconstruction", "categorical_kl", "gaussian_kl", "latent", "component")
+    outs = []
+    for rows in (8192, 0):
+        slib.check(L.suave_small_batch_rows_set(rows), "suave_small_batch_rows_set")
+        try:
+            eng = _engine(om, P)
+            table = PackedTable(xnum, codes, mask, eng.device)
+            res = eng.elbo(table, 0, B, beta_scale=1.0, tau=1.0, grad=True, seed=11, step=2, want=want)
+            torch.cuda.synchronize()
+            got = {k: v.cpu().numpy().copy() for k, v in res.items()}
+            got.update({"grad/" + k: np.asarray(v).copy() for k, v in eng.grad_state().items()})
+            outs.append(got)
+        finally:
+            slib.check(L.suave_small_batch_rows_set(8192), "suave_small_batch_rows_set")
+    a, b = outs
+    assert set(a) == set(b)
+    assert np.array_equal(a["component"], b["component"])
+    gmax = max(float(np.abs(v).max()) for k, v in b.items() if k.startswith("grad/") and v.size)
+    for k in a:
+        if k == "component" or not a[k].size:
+            continue
+        scale = max(float(np.abs(b[k]).max()), 1e-3 * gmax if k.startswith("grad/") else 0.0, 1e-6)
+        assert float(np.abs(a[k].astype(np.float64) - b[k]).max()) <= TOL * scale, k
