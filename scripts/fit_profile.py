@@ -24,7 +24,7 @@ X = pd.DataFrame(cols)
 y = pd.Series(rng.integers(0, 2, n))
 behaviour = os.environ.get("BEHAVIOUR", "unsupervised")
 model = SUAVE(Schema(spec), behaviour=behaviour, latent_dim=32, n_components=10, hidden_dims=(256, 128), dropout=0.1,
-              batch_size=65536, random_state=0)
+              batch_size=int(os.environ.get("BATCH", "65536")), random_state=0)
 kw = dict(warmup_epochs=epochs) if behaviour == "supervised" else dict(epochs=epochs)
 if behaviour == "supervised":
     kw.update(head_epochs=1, finetune_epochs=1)
