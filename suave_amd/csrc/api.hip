@@ -1109,6 +1109,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
         d.A = w.dsel; d.B = params + m.enc_head.w_off; d.C = w.dhe[nh - 1];
         d.M = Vg; d.N = m.enc_head.n_in; d.K = ldS; d.lda = ldS; d.ldb = m.enc_head.ld; d.ldc = p->ldH[nh - 1];
         d.b_kmajor = 1; d.epi = kEpiMaskBwd; d.H = w.he[nh - 1]; d.drop_p = drop_p; d.grouped = 1; d.q0 = 0;
+        d.a_scale = t_grad_scale;  // (read by the fp16-plane small-batch kernel; the exact-fp32 tile kernel ignores it)
         head_geometry(d);
         if (int rc = launch_gemm_pair(d, g, p->n_cu, s)) return rc;
       } else {

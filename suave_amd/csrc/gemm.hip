@@ -821,33 +821,60 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
 // finishes register groups 4 w .. 4 w + 3 of both 32-column halves: bias, ReLU, dropout (the same per-(row, column
 // pair) hash as gemm_body, or the injected mask).  The accumulator layout (lane = column, 4 consecutive rows per
 // register group) stores 128 contiguous bytes per half wave and row.  Arithmetic mode 4 only.
-template <int EPI>
+// GRP == 1: the selected-component encoder head (GemmArgs::grouped == 1) -- rows of A and C are sorted positions read /
+// written through perm (a 32-row tile lies in one component's chunk, its valid rows are a prefix), rows of B are
+// head_row(q0 + ., component).  B_KM (with GRP == 1, the head's data gradient): element (k, j) of B is
+// W[head_row(q0 + k, component)][j] -- eight dword loads per fragment, coalesced across the lanes' columns.
+template <int EPI, int GRP = 0, bool B_KM = false>
 __device__ __forceinline__ void gemm_small_body(const GemmArgs& a, int block, float (&part_s)[4][32][64]) {  // part_s: [wave][j * 16 + r][lane]
+  static_assert(GRP == 0 || EPI != kEpiReluDrop, "the grouped forms have no dropout epilogue");
+  static_assert(!B_KM || GRP == 1, "k-major B: only the grouped data gradient");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tiles_n = (a.N + 63) / 64;
   const int tile_m = block / tiles_n, tile_n = block - tile_m * tiles_n;
   const int m0 = tile_m * 32, n0 = tile_n * 64;
   const int l31 = lane & 31, kh = lane >> 5;
-  const int arow = min(m0 + l31, a.M - 1);  // out-of-range rows / columns read a valid row and are never stored
-  const int brow0 = min(n0 + l31, a.N - 1), brow1 = min(n0 + 32 + l31, a.N - 1);
-  const float* pa = a.A + (size_t)arow * a.lda + 8 * kh;
-  const float* pb0 = a.B + (size_t)brow0 * a.ldb + 8 * kh;
-  const float* pb1 = a.B + (size_t)brow1 * a.ldb + 8 * kh;
+  int comp = 0;
+  if (GRP == 1) {  // block-uniform exits, before any barrier
+    comp = a.chunk_comp[m0 / kGroupRows];
+    if (comp < 0 || a.perm[m0] < 0) return;  // unused chunk / a tile of padding positions only
+  }
+  // out-of-range rows / columns read a valid row and are never stored (GRP: absent rows read as zeros)
+  const int arow = GRP == 1 ? a.perm[m0 + l31] : min(m0 + l31, a.M - 1);
+  const bool a_ok = GRP == 1 ? arow >= 0 : true;
+  int brow0 = min(n0 + l31, a.N - 1), brow1 = min(n0 + 32 + l31, a.N - 1);
+  bool b_ok0 = true, b_ok1 = true;
+  if (GRP == 1 && !B_KM) {
+    brow0 = head_row(a.q0 + brow0, comp, a.hK, a.hD, a.hldK, a.hldD);
+    brow1 = head_row(a.q0 + brow1, comp, a.hK, a.hD, a.hldK, a.hldD);
+    b_ok0 = brow0 >= 0; b_ok1 = brow1 >= 0;
+  }
+  const float* pa = a.A + (size_t)max(arow, 0) * a.lda + 8 * kh;
+  const float* pb0 = B_KM ? a.B + brow0 : a.B + (size_t)max(brow0, 0) * a.ldb + 8 * kh;
+  const float* pb1 = B_KM ? a.B + brow1 : a.B + (size_t)max(brow1, 0) * a.ldb + 8 * kh;
   const bool two = n0 + 32 < a.N;  // block-uniform: the second 32 columns exist
   f32x16 acc[2], accx[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; accx[j][r] = 0.f; }
-  auto load8 = [&](const float* p, int k0, float (&v)[8]) {
+  auto load8 = [&](const float* p, bool ok, int k0, float (&v)[8]) {
     // lda / ldb are multiples of 4 floats: a quad that starts inside the K range lies inside the row's storage
     const int k = k0 + 8 * kh;
-    const float4 q0 = k < a.K ? *reinterpret_cast<const float4*>(p + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 q1 = k + 4 < a.K ? *reinterpret_cast<const float4*>(p + k0 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 q0 = (ok && k < a.K) ? *reinterpret_cast<const float4*>(p + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 q1 = (ok && k + 4 < a.K) ? *reinterpret_cast<const float4*>(p + k0 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       if (k + e >= a.K) v[e] = 0.f;  // ragged K inside a quad
+  };
+  auto load8_km = [&](const float* pcol, int k0, float (&v)[8]) {  // B_KM: rows head_row(q0 + k), this lane's column
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k0 + 8 * kh + e;
+      const int br = k < a.K ? head_row(a.q0 + k, comp, a.hK, a.hD, a.hldK, a.hldD) : -1;
+      v[e] = br >= 0 ? pcol[(size_t)br * a.ldb] : 0.f;
+    }
   };
   const float a_scale = a.a_scale > 0.f ? a.a_scale : 1.0f;  // gradient operands: pre-scaled into the fp16 range
   auto planes = [&](const float (&v)[8], float scale, f16x8& hi, f16x8& lo) {
@@ -866,9 +893,14 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& a, int block, fl
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const int k0 = (s0 + 4 * u) * BK;  // (past the end: load8 returns zeros without touching memory)
-      load8(pa, k0, va[u]);
-      load8(pb0, k0, vb0[u]);
-      if (two) load8(pb1, k0, vb1[u]);
+      load8(pa, a_ok, k0, va[u]);
+      if (B_KM) {
+        load8_km(pb0, k0, vb0[u]);
+        if (two) load8_km(pb1, k0, vb1[u]);
+      } else {
+        load8(pb0, b_ok0, k0, vb0[u]);
+        if (two) load8(pb1, b_ok1, k0, vb1[u]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < G; ++u) {
@@ -924,24 +956,32 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& a, int block, fl
       }
     }
   }
+  int orow[4];  // output rows of this lane (GRP: through perm; -1 = nothing to store)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + 8 * wave + 4 * kh + i;
+    orow[i] = row < a.M ? (GRP == 1 ? a.perm[row] : row) : -1;
+  }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + 32 * j + l31;
     if (col >= a.N) continue;
-    const float bias = (EPI != kEpiMaskBwd && a.bias != nullptr) ? a.bias[col] : 0.f;
+    float bias = 0.f;
+    if (EPI != kEpiMaskBwd && a.bias != nullptr) {
+      const int bi = GRP == 1 ? head_row(a.q0 + col, comp, a.hK, a.hD, a.hldK, a.hldD) : col;
+      if (bi >= 0) bias = a.bias[bi];
+    }
     float hv[4] = {1.f, 1.f, 1.f, 1.f};
     if (EPI == kEpiMaskBwd) {  // the layer's output activation (post ReLU / dropout): all four loads before the stores
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = m0 + 8 * wave + 4 * kh + i;
-        if (row < a.M) hv[i] = a.H[(size_t)row * a.ldc + col];
-      }
+      for (int i = 0; i < 4; ++i)
+        if (orow[i] >= 0) hv[i] = a.H[(size_t)orow[i] * a.ldc + col];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = m0 + 8 * wave + 4 * kh + i;
-      if (row >= a.M) continue;
+      const int row = orow[i];
+      if (row < 0) continue;
       const int slot = j * 16 + 4 * wave + i;
       float v = ((part_s[0][slot][lane] + part_s[1][slot][lane]) + part_s[2][slot][lane]) + part_s[3][slot][lane] + bias;
       if (EPI == kEpiReluDrop) {
@@ -963,8 +1003,12 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& a, int block, fl
 // gradient (plain fp32 column sums of dC) in column ones_col.  Same shape as gemm_small_kernel: a block owns a 32 x 64
 // tile of one split, its four waves take the split's 16-row steps round-robin with the loads of four steps in flight
 // (a fragment is eight rows of one column: eight dword loads, coalesced across the lanes), partial tiles meet in LDS.
+// GRP == 2 (the selected-component head, GemmArgs::grouped == 2): split = chunk of kGroupRows sorted positions, the
+// batch row of a position read through perm (-1: padding, contributes zeros).
+template <int GRP = 0>
 __device__ __forceinline__ void gemm_small_wgrad_body(const GemmArgs& a, int rows_per_split, int tile, int split,
                                                       float (&part_s)[4][32][64], float (&bias_s)[4][32]) {
+  if (GRP == 2 && a.chunk_comp[split] < 0) return;  // unused chunk (block-uniform, before any barrier)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tiles_n = (a.N + 63) / 64;
   const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
@@ -981,12 +1025,16 @@ __device__ __forceinline__ void gemm_small_wgrad_body(const GemmArgs& a, int row
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; accx[j][r] = 0.f; }
-  auto load8 = [&](const float* p, int ld, int r0, float (&v)[8]) {
+  auto rows8 = [&](int r0, int (&src)[8]) {  // source rows of a step's fragment (-1: none)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int r = r0 + 8 * kh + e;
-      v[e] = r < r_end ? p[(size_t)r * ld] : 0.f;
+      src[e] = r < r_end ? (GRP == 2 ? a.perm[r] : r) : -1;
     }
+  };
+  auto load8 = [&](const float* p, int ld, const int (&src)[8], float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[e] >= 0 ? p[(size_t)src[e] * ld] : 0.f;
   };
   auto planes = [&](const float (&v)[8], float scale, f16x8& hi, f16x8& lo) {
 #pragma unroll
@@ -1002,12 +1050,14 @@ __device__ __forceinline__ void gemm_small_wgrad_body(const GemmArgs& a, int row
   float bsum = 0.f;
   for (int s0 = wave; s0 < n_steps; s0 += 4 * G) {
     float va[G][8], vb0[G][8], vb1[G][8];
+    int src[G][8];
+#pragma unroll
+    for (int u = 0; u < G; ++u) rows8(r_begin + (s0 + 4 * u) * BK, src[u]);  // (past the split's end: -1, no memory access)
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-      const int r0 = r_begin + (s0 + 4 * u) * BK;  // (past the split's end: zeros, no memory access)
-      load8(pa, a.lda, r0, va[u]);
-      load8(pb0, a.ldb, r0, vb0[u]);
-      if (two) load8(pb1, a.ldb, r0, vb1[u]);
+      load8(pa, a.lda, src[u], va[u]);
+      load8(pb0, a.ldb, src[u], vb0[u]);
+      if (two) load8(pb1, a.ldb, src[u], vb1[u]);
     }
 #pragma unroll
     for (int u = 0; u < G; ++u) {
@@ -1054,10 +1104,10 @@ __device__ __forceinline__ void gemm_small_wgrad_body(const GemmArgs& a, int row
     Cout[(size_t)(m0 + lane) * a.ldc + a.ones_col] = ((bias_s[0][lane] + bias_s[1][lane]) + bias_s[2][lane]) + bias_s[3][lane];
 }
 
-template <int EPI>
+template <int EPI, int GRP = 0>
 __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
   __shared__ float part_s[4][32][64];
-  gemm_small_body<EPI>(a, blockIdx.x, part_s);
+  gemm_small_body<EPI, GRP, false>(a, blockIdx.x, part_s);
 }
 
 __global__ __launch_bounds__(256) void gemm_small_wgrad_kernel(GemmArgs a, int rows_per_split) {
@@ -1068,13 +1118,13 @@ __global__ __launch_bounds__(256) void gemm_small_wgrad_kernel(GemmArgs a, int r
 
 // Both backward GEMMs of a layer over a small batch in one launch (they are independent and neither fills the chip):
 // blocks [0, w_blocks) are the weight gradient's (tile, split) pairs, the rest the data gradient's tiles.
-template <int DEPI>
+template <int DEPI, int GRP = 0>
 __global__ __launch_bounds__(256) void gemm_small_pair_kernel(GemmArgs d, GemmArgs w, int rows_per_split, int w_tiles, int w_blocks) {
   __shared__ float part_s[4][32][64];
   __shared__ float bias_s[4][32];
   const int b = blockIdx.x;
-  if (b < w_blocks) gemm_small_wgrad_body(w, rows_per_split, b % w_tiles, b / w_tiles, part_s, bias_s);
-  else gemm_small_body<DEPI>(d, b - w_blocks, part_s);
+  if (b < w_blocks) gemm_small_wgrad_body<GRP == 1 ? 2 : 0>(w, rows_per_split, b % w_tiles, b / w_tiles, part_s, bias_s);
+  else gemm_small_body<DEPI, GRP, GRP == 1>(d, b - w_blocks, part_s);
 }
 
 // Weight-gradient launches are (tiles, K splits) grids of a few tiles: the tiles of ONE split read the same rows of
@@ -1279,6 +1329,25 @@ bool small_rowmajor_ok(const GemmArgs& a) {
   if (a.epi == kEpiMaskBwd) return a.H != nullptr;
   return (a.epi == kEpiBias || a.epi == kEpiReluDrop) && a.H == nullptr;
 }
+// the selected-component head over a small batch: forward (grouped == 1, row-major W) / data gradient (k-major W) /
+// weight gradient (grouped == 2).  The grouped extent is ceil(rows / kGroupRows) + K chunks of kGroupRows positions.
+bool small_grouped_rows(const GemmArgs& a) {
+  static const bool off = getenv("SUAVE_NO_SMALL_GROUPED") != nullptr;  // tuning knob
+  const int64_t ext = a.grouped == 1 ? a.M : a.K;
+  return !off && a.perm != nullptr && a.chunk_comp != nullptr && gemm_small_rows(ext - (int64_t)a.hK * kGroupRows);
+}
+bool small_grouped_fwd_ok(const GemmArgs& a) {
+  static const bool off = getenv("SUAVE_NO_SMALL_GFWD") != nullptr;  // tuning knob
+  return !off && a.grouped == 1 && small_grouped_rows(a) && !a.a_kmajor && !a.b_kmajor && a.epi == kEpiBias && a.H == nullptr;
+}
+bool small_grouped_dgrad_ok(const GemmArgs& a) {
+  return a.grouped == 1 && small_grouped_rows(a) && !a.a_kmajor && a.b_kmajor && a.epi == kEpiMaskBwd && a.H != nullptr &&
+         a.mask_in == nullptr;
+}
+bool small_grouped_wgrad_ok(const GemmArgs& a) {
+  return a.grouped == 2 && small_grouped_rows(a) && a.a_kmajor && a.b_kmajor && a.epi == kEpiSlab &&
+         a.splits == a.K / kGroupRows;
+}
 // weight gradients over a small batch (K = batch rows; at most 64 steps per block)
 bool small_wgrad_ok(const GemmArgs& a) {
   static const bool off = getenv("SUAVE_NO_SMALL_WGRAD") != nullptr;  // tuning knob
@@ -1301,6 +1370,12 @@ int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
     if (a.epi == kEpiBias) hipLaunchKernelGGL(gemm_small_kernel<kEpiBias>, sgrid, sblock, 0, stream, args);
     else if (a.epi == kEpiReluDrop) hipLaunchKernelGGL(gemm_small_kernel<kEpiReluDrop>, sgrid, sblock, 0, stream, args);
     else hipLaunchKernelGGL(gemm_small_kernel<kEpiMaskBwd>, sgrid, sblock, 0, stream, args);
+    SUAVE_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  if (small_grouped_fwd_ok(a)) {
+    const dim3 sgrid(((a.M + 31) / 32) * ((a.N + 63) / 64)), sblock(256);
+    hipLaunchKernelGGL((gemm_small_kernel<kEpiBias, 1>), sgrid, sblock, 0, stream, args);
     SUAVE_CHECK_HIP(hipGetLastError());
     return 0;
   }
@@ -1362,6 +1437,17 @@ int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t
   static const bool no_pair = getenv("SUAVE_NO_PAIR") != nullptr;  // tuning knob: run the two GEMMs as two launches
   static const bool no_small_pair = getenv("SUAVE_NO_SMALL_BWD") != nullptr;  // tuning knob
   const bool small_pair = !no_small_pair && small_rowmajor_ok(d) && small_wgrad_ok(w);  // small batch: two split-K launches
+  if (!no_small_pair && small_grouped_dgrad_ok(d) && small_grouped_wgrad_ok(w)) {
+    if (int rc = check_gemm(d)) return rc;
+    if (int rc = check_gemm(w)) return rc;
+    ProfScope prof_scope(kProfGemm, stream);
+    const int w_tiles = ((w.M + 31) / 32) * ((w.N + 63) / 64), w_blocks = w_tiles * w.splits;
+    const int d_blocks = ((d.M + 31) / 32) * ((d.N + 63) / 64);
+    hipLaunchKernelGGL((gemm_small_pair_kernel<kEpiMaskBwd, 1>), dim3(w_blocks + d_blocks), dim3(256), 0, stream, d, w,
+                       kGroupRows, w_tiles, w_blocks);
+    SUAVE_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (small_pair && d.M > 0 && d.N > 0 && w.M > 0 && w.N > 0) {
     if (int rc = check_gemm(d)) return rc;
     if (int rc = check_gemm(w)) return rc;

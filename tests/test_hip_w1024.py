@@ -132,21 +132,24 @@ def test_w1024_full_table_properties(w1024):
         assert bool(torch.isfinite(a[k]).all()), k
         assert float((a[k] - b[k]).abs().max() / a[k].abs().max().clamp_min(1e-6)) < 1e-6, k
     assert float(a["categorical_kl"].min()) > -1e-5 and float(a["gaussian_kl"].min()) > -1e-5
-    # gradient: linear in the rows (what data parallelism relies on), bit-identical run to run
-    B = 16384
-    idx = torch.randperm(ROWS, device=eng.device, generator=torch.Generator(eng.device).manual_seed(1))[:B].to(torch.int32)
-    kw = dict(beta_scale=0.8, tau=1.0, grad=True, seed=5, step=11, global_rows=B)
-    eng.elbo(table, 0, B, row_index=idx, **kw)
-    full = eng.grads.clone()
-    eng.elbo(table, 0, B, row_index=idx, **kw)
-    assert torch.equal(full, eng.grads)
-    eng.elbo(table, 0, B // 2, row_index=idx[: B // 2].contiguous(), **kw)
-    half = eng.grads.clone()
-    eng.elbo(table, 0, B - B // 2, row_index=idx[B // 2:].contiguous(), **kw)
-    both = half + eng.grads
-    for name, (lo, hi) in layout.group_ranges.items():
-        scale = float(full[lo:hi].abs().max().clamp_min(1e-12))
-        assert float((both[lo:hi] - full[lo:hi]).abs().max()) <= 1e-5 * scale + 1e-9, name
+    # gradient: linear in the rows (what data parallelism relies on), bit-identical run to run.  Whole and halves run
+    # on the same kernels (the tile kernels at 32 768 / 16 384 rows, the small-batch kernels at 8 192 / 4 096): across
+    # the two paths the last bit of a pre-activation may differ, and one ReLU that flips moves a weight row's
+    # gradient by a row's whole contribution (1 / B), which is not a rounding error.
+    for B in (32768, 8192):
+        idx = torch.randperm(ROWS, device=eng.device, generator=torch.Generator(eng.device).manual_seed(1))[:B].to(torch.int32)
+        kw = dict(beta_scale=0.8, tau=1.0, grad=True, seed=5, step=11, global_rows=B)
+        eng.elbo(table, 0, B, row_index=idx, **kw)
+        full = eng.grads.clone()
+        eng.elbo(table, 0, B, row_index=idx, **kw)
+        assert torch.equal(full, eng.grads)
+        eng.elbo(table, 0, B // 2, row_index=idx[: B // 2].contiguous(), **kw)
+        half = eng.grads.clone()
+        eng.elbo(table, 0, B - B // 2, row_index=idx[B // 2:].contiguous(), **kw)
+        both = half + eng.grads
+        for name, (lo, hi) in layout.group_ranges.items():
+            scale = float(full[lo:hi].abs().max().clamp_min(1e-12))
+            assert float((both[lo:hi] - full[lo:hi]).abs().max()) <= 1e-5 * scale + 1e-9, (B, name)
 
 
 def test_w1024_generation_does_not_depend_on_the_sharding(w1024):
