@@ -55,34 +55,6 @@ __global__ void k_onehot(const int32_t* kidx, int n_rows, int K, int ld, float* 
   }
 }
 
-// Row-major copies W^T [n_in, ldT] of the layer weights W [n_out, ld]: with them the data-gradient GEMM
-// dA = dC * W reads both operands k-contiguous, i.e. it is a forward-type product the split kernels handle.
-struct TransArgs {
-  const float* src[2 * SUAVE_MAX_HIDDEN + 2];
-  float* dst[2 * SUAVE_MAX_HIDDEN + 2];
-  int n_out[2 * SUAVE_MAX_HIDDEN + 2], n_in[2 * SUAVE_MAX_HIDDEN + 2], ld[2 * SUAVE_MAX_HIDDEN + 2], ldT[2 * SUAVE_MAX_HIDDEN + 2];
-};
-__global__ __launch_bounds__(256) void k_transpose(TransArgs a) {
-  __shared__ float tile[32][33];
-  const int m = blockIdx.y;
-  const int n_out = a.n_out[m], n_in = a.n_in[m], ld = a.ld[m], ldT = a.ldT[m];
-  const int tiles_i = (n_in + 31) / 32, tiles_o = (n_out + 31) / 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int t = blockIdx.x; t < tiles_i * tiles_o; t += gridDim.x) {
-    const int o0 = (t / tiles_i) * 32, i0 = (t % tiles_i) * 32;
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-      const int o = o0 + r, i = i0 + tx;
-      tile[r][tx] = (o < n_out && i < n_in) ? a.src[m][(size_t)o * ld + i] : 0.f;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-      const int i = i0 + r, o = o0 + tx;
-      if (i < n_in && o < ldT) a.dst[m][(size_t)i * ldT + o] = tile[tx][r];  // pad columns o >= n_out get zeros
-    }
-  }
-}
-
 int launch_onehot(const int32_t* kidx, int n_rows, int K, int ld, float* out, hipStream_t s) {
   const int64_t n = (int64_t)n_rows * K;
   hipLaunchKernelGGL(k_onehot, dim3((int)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, kidx, n_rows, K, ld, out);
@@ -482,9 +454,9 @@ int layer_index(const suave_plan* p, const suave_layer_t* l) {
   return -1;
 }
 
-int transpose_weights(const suave_plan* p, const float* params, const Workspace& w, hipStream_t s) {
-  if (gemm_split_mode() == 0) return 0;
+TransArgs transpose_args(const suave_plan* p, const float* params, const Workspace& w) {
   TransArgs t{};
+  if (gemm_split_mode() == 0) return t;
   int n = 0, max_tiles = 1;
   for (const suave_layer_t* l : all_layers(p)) {
     t.src[n] = params + l->w_off; t.dst[n] = w.wT[n];
@@ -492,10 +464,9 @@ int transpose_weights(const suave_plan* p, const float* params, const Workspace&
     max_tiles = std::max(max_tiles, ((l->n_in + 31) / 32) * ((l->n_out + 31) / 32));
     ++n;
   }
-  ProfScope prof_scope(kProfOther, s);
-  hipLaunchKernelGGL(k_transpose, dim3(std::min(max_tiles, 1024), n), dim3(256), 0, s, t);
-  SUAVE_CHECK_HIP(hipGetLastError());
-  return 0;
+  t.n_mats = n;
+  t.blocks_per_mat = std::min(max_tiles, 512);  // (a 256 x 256 layer is 64 tiles; blocks beyond a matrix's tiles exit at once)
+  return t;
 }
 
 int bwd_weight(const suave_plan* p, const suave_layer_t& l, const float* dC, int lddc, const float* A, int lda,
@@ -674,7 +645,10 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
   const suave_noise_t* nz = noise ? noise : &nz_default;
   const float tau_c = tau > 0.f ? std::max(tau, 1e-6f) : 0.f;
 
-  if (int rc = launch_expand(p, *batch, w.x, w.cells, s)) return rc;
+  {  // (+ the transposed weight copies of the backward, in the same launch)
+    const TransArgs trans = grad ? transpose_args(p, params, w) : TransArgs{};
+    if (int rc = launch_expand(p, *batch, w.x, w.cells, s, grad ? &trans : nullptr)) return rc;
+  }
   const float* act = w.x;
   int ld_act = p->ldI;
   if (int rc = encoder_trunk_forward(p, params, batch, nz, drop_p, w, grad, &act, &ld_act, s)) return rc;
@@ -736,7 +710,6 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
   red.n_segs = 0; red.slab = w.slab; red.dst = grads;
   int max_elems = 256;
   if (grad) {
-    if (int rc = transpose_weights(p, params, w, s)) return rc;
     if (n_wide)
       if (int rc = wide_backward(p, params, w, V, nullptr, &slab_off, &red, &max_elems, s)) return rc;
     const float* hlast = nh ? w.hd[nh - 1] : w.z;
@@ -875,7 +848,10 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   const suave_noise_t* nz = noise ? noise : &nz_default;
 
   // ---- encoder ----
-  if (int rc = launch_expand(p, *batch, w.x, w.cells, s)) return rc;
+  {  // (+ the transposed weight copies of the backward, in the same launch)
+    const TransArgs trans = grad ? transpose_args(p, params, w) : TransArgs{};
+    if (int rc = launch_expand(p, *batch, w.x, w.cells, s, grad ? &trans : nullptr)) return rc;
+  }
   const float* act = w.x;
   int ld_act = p->ldI;
   const bool enc_chain = encoder_chain_ok(p) && nh + 1 <= kChainMaxLayers;
@@ -903,6 +879,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   la.latent_out = out ? out->latent : nullptr;
   la.comp_out = out ? out->component : nullptr;
   la.lrank = w.lrank; la.blk_cnt = w.blk_cnt;
+  la.perm_fill = w.perm; la.perm_fill_n = w.n_chunks_max * kGroupRows;
   GroupArgs ga{};
   ga.K = K; ga.n_rows = B; ga.n_blocks = w.n_blocks; ga.n_chunks_max = w.n_chunks_max; ga.kidx = w.kidx;
   ga.lrank = w.lrank; ga.blk_cnt = w.blk_cnt; ga.chunk_comp = w.chunk_comp;
@@ -1016,7 +993,6 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   int max_elems = 256;
 
   if (grad) {
-    if (int rc = transpose_weights(p, params, w, s)) return rc;
     if (n_wide)
       if (int rc = wide_backward(p, params, w, B, w.ds_part + (size_t)n_chunks * B * p->ldK, &slab_off, &red, &max_elems, s))
         return rc;

@@ -62,6 +62,8 @@ struct LatentFwdArgs {
   // rows sorted by component (stable): rank of the row inside its 256-row block, per-block counts
   int32_t* lrank;       // [B]
   int32_t* blk_cnt;     // [ceil(B/256), K]
+  int32_t* perm_fill;   // k_assign pre-fills the sorted-position table of k_group_scatter with -1 (null: no fill)
+  int perm_fill_n;
   // KL terms (k_reparam): losses.py:51-57, :87-97 with the prior of the selected component (model.py:1607-1613)
   const float* params;
   int prior_logits_off, prior_mu_off, prior_logvar_off;
@@ -219,7 +221,18 @@ size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes, int ldx, int 
 int loss_set_lds_limit(size_t lds_bytes);
 int loss_workers_per_block();
 int launch_loss(const LossArgs& a, bool grad, int kmax, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s);
-int launch_expand(const suave_plan* p, const suave_batch_t& b, float* x, int32_t* cells, hipStream_t s);
+// Row-major copies W^T [n_in, ldT] of the layer weights W [n_out, ld]: with them the data-gradient GEMM
+// dA = dC * W reads both operands k-contiguous, i.e. it is a forward-type product the split kernels handle.
+// The copies are written by extra blocks of the step's first launch (k_expand): as a launch of its own the
+// transposition sat on the step's dependency chain for 5 us.
+struct TransArgs {
+  const float* src[2 * SUAVE_MAX_HIDDEN + 2];
+  float* dst[2 * SUAVE_MAX_HIDDEN + 2];
+  int n_out[2 * SUAVE_MAX_HIDDEN + 2], n_in[2 * SUAVE_MAX_HIDDEN + 2], ld[2 * SUAVE_MAX_HIDDEN + 2], ldT[2 * SUAVE_MAX_HIDDEN + 2];
+  int n_mats, blocks_per_mat;  // n_mats == 0: nothing to transpose
+};
+int launch_expand(const suave_plan* p, const suave_batch_t& b, float* x, int32_t* cells, hipStream_t s,
+                  const TransArgs* trans = nullptr);
 int launch_assign(const LatentFwdArgs& a, hipStream_t s);
 int launch_group(const GroupArgs& a, hipStream_t s);
 int reparam_grid(int n_rows);

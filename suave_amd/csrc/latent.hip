@@ -19,10 +19,39 @@ namespace suave {
 //   x     [B, ldI]    the encoder input (model.py:2784-2922 layout, quirks Q6/Q7), and
 //   cells [ceil(B/64), n_cols, 64] one int per cell for the likelihood kernel (tile-transposed): float bits /
 //         class code, kCellMissing when masked.
+// 32 x 32 tiles `first`, `first + stride`, ... of matrix m of a TransArgs
+__device__ __forceinline__ void transpose_tiles(const TransArgs& a, int m, int first, int stride, float (&tile)[32][33]) {
+  const int n_out = a.n_out[m], n_in = a.n_in[m], ld = a.ld[m], ldT = a.ldT[m];
+  const int tiles_i = (n_in + 31) / 32, tiles_o = (n_out + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int t = first; t < tiles_i * tiles_o; t += stride) {
+    const int o0 = (t / tiles_i) * 32, i0 = (t % tiles_i) * 32;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int o = o0 + r, i = i0 + tx;
+      tile[r][tx] = (o < n_out && i < n_in) ? a.src[m][(size_t)o * ld + i] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int i = i0 + r, o = o0 + tx;
+      if (i < n_in && o < ldT) a.dst[m][(size_t)i * ldT + o] = tile[tx][r];  // pad columns o >= n_out get zeros
+    }
+  }
+}
+
+// Blocks [0, n_expand) expand the batch; blocks behind them write the transposed weight copies of `trans`
+// (independent work riding in the step's first launch).
 __global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_map, const int32_t* __restrict__ xsrc,
                                                 suave_batch_t b, int n_num, int n_disc, int n_cols, int ldI,
-                                                int rows_per_block, float* __restrict__ x, int32_t* __restrict__ cells) {
+                                                int rows_per_block, float* __restrict__ x, int32_t* __restrict__ cells,
+                                                int n_expand, TransArgs trans) {
   extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
+  __shared__ float trans_tile[32][33];
+  if ((int)blockIdx.x >= n_expand) {  // block-uniform
+    const int idx = blockIdx.x - n_expand;
+    transpose_tiles(trans, idx / trans.blocks_per_mat, idx % trans.blocks_per_mat, trans.blocks_per_mat, trans_tile);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // row strides: odd word counts for the lane = row reads of the cell phase (a 64-byte mask row put all 64 lanes on
   // two banks)
@@ -30,7 +59,7 @@ __global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_
   float* xn_s = reinterpret_cast<float*>(stage);                                   // [R][ldn]
   int16_t* cd_s = reinterpret_cast<int16_t*>(xn_s + (size_t)rows_per_block * ldn);  // [R][ldd]
   uint8_t* mk_s = reinterpret_cast<uint8_t*>(cd_s + (size_t)rows_per_block * ldd);  // [R][ldm]
-  for (int r0 = blockIdx.x * rows_per_block; r0 < b.n_rows; r0 += gridDim.x * rows_per_block) {
+  for (int r0 = blockIdx.x * rows_per_block; r0 < b.n_rows; r0 += n_expand * rows_per_block) {
     const int nrows = min(rows_per_block, b.n_rows - r0);
     __syncthreads();
     // each wave stages a contiguous quarter of the block's rows: one load of their table row ids, then
@@ -148,6 +177,9 @@ __global__ __launch_bounds__(256) void k_assign(LatentFwdArgs a) {
   const Philox rng(a.seed);
   const int r = blockIdx.x * 256 + tid;
   const bool valid = r < a.n_rows;
+  // (the -1 fill of the sorted-position table rides along: as a memset of its own it was a 4.6 us dispatch on the chain)
+  if (a.perm_fill != nullptr)
+    for (int i = r; i < a.perm_fill_n; i += gridDim.x * 256) a.perm_fill[i] = -1;
   int kb = -1;
   if (valid) {
     const uint32_t rid = a.row_index ? (uint32_t)a.row_index[r] : (uint32_t)(a.row_begin + r);
@@ -1018,7 +1050,7 @@ int launch_colsum(const float* src, int ld, int n_rows, int n_cols, float* slab,
   return 0;
 }
 
-int launch_expand(const suave_plan* p, const suave_batch_t& b, float* x, int32_t* cells, hipStream_t s) {
+int launch_expand(const suave_plan* p, const suave_batch_t& b, float* x, int32_t* cells, hipStream_t s, const TransArgs* trans) {
   if (b.n_rows <= 0) return 0;
   ProfScope prof_scope(kProfExpand, s);
   const suave_model_t& m = p->model;
@@ -1027,8 +1059,11 @@ int launch_expand(const suave_plan* p, const suave_batch_t& b, float* x, int32_t
   int rows_per_block = std::max(4, std::min(rows_cap, (48 * 1024) / std::max(row_bytes, 1)) & ~3);
   SUAVE_REQUIRE((size_t)rows_per_block * row_bytes <= 48 * 1024, "expand: schema too wide for the staging buffer");
   const int grid = std::min((b.n_rows + rows_per_block - 1) / rows_per_block, 4096);
-  hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), (size_t)rows_per_block * row_bytes, s, p->enc_map_dev, p->xsrc_dev, b,
-                     m.n_num, m.n_disc, m.n_cols, p->ldI, rows_per_block, x, cells);
+  TransArgs t{};
+  if (trans != nullptr) t = *trans;
+  const int t_blocks = t.n_mats * t.blocks_per_mat;
+  hipLaunchKernelGGL(k_expand, dim3(grid + t_blocks), dim3(256), (size_t)rows_per_block * row_bytes, s, p->enc_map_dev, p->xsrc_dev, b,
+                     m.n_num, m.n_disc, m.n_cols, p->ldI, rows_per_block, x, cells, grid, t);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1044,7 +1079,7 @@ int launch_assign(const LatentFwdArgs& a, hipStream_t s) {
 int launch_group(const GroupArgs& a, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
   ProfScope prof_scope(kProfLatent, s);
-  SUAVE_CHECK_HIP(hipMemsetAsync(a.perm, 0xFF, sizeof(int32_t) * (size_t)a.n_chunks_max * kGroupRows, s));
+  // (a.perm was filled with -1 by k_assign: LatentFwdArgs::perm_fill)
   hipLaunchKernelGGL(k_group_scatter, dim3(a.n_blocks), dim3(256), 0, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
