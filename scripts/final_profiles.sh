@@ -34,7 +34,7 @@ python scripts/pmc_traffic.py $O/${R}_fetch_t $O/${R}_write_t 7 > $O/${R}_out/${
 python scripts/pmc_traffic.py $O/${R}_fetch $O/${R}_write > $O/${R}_out/${R}_pmc_traffic_gen.json
 python scripts/step_timeline.py $(find $O/${R}_tl_s64 -name '*kernel_trace.csv' | tail -1) > $O/${R}_out/${R}_step_timeline.txt
 python scripts/step_timeline.py $(find $O/${R}_tl_w -name '*kernel_trace.csv' | tail -1) > $O/${R}_out/${R}_w1024_step_timeline.txt
-tail -1 $O/${R}_bench_stats.log > $O/${R}_out/${R}_bench_default_under_rocprof.json || true
+grep -h "^{\"metric\"" $O/${R}_bench_stats.log | tail -1 > $O/${R}_out/${R}_bench_default_under_rocprof.json || true
 rm -rf $O/${R}_stats $O/${R}_stats_train $O/${R}_fetch $O/${R}_write $O/${R}_fetch_t $O/${R}_write_t $O/${R}_tl_s64 $O/${R}_tl_w
 echo "[8b] PMC FETCH_SIZE / WRITE_SIZE, W1024 training only"
 rm -rf $O/${R}_fetch_w $O/${R}_write_w
