@@ -171,6 +171,9 @@ __global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_
 // supervised, step 1: y_soft = softmax((logits + g)/tau), k = argmax; one row per thread.  Also the first
 // pass of the stable counting sort by component: the row's rank among the rows of its 256-row block that
 // chose the same component, and the block's per-component counts.
+// KMAX >= K, compile-time: the K scores stay in registers (indexed dynamically they lived in scratch memory) and the
+// K deterministic log / divide chains are independent instruction streams the scheduler interleaves.
+template <int KMAX>
 __global__ __launch_bounds__(256) void k_assign(LatentFwdArgs a) {
   __shared__ int wcnt[4][SUAVE_MAX_COMPONENTS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -184,31 +187,42 @@ __global__ __launch_bounds__(256) void k_assign(LatentFwdArgs a) {
   if (valid) {
     const uint32_t rid = a.row_index ? (uint32_t)a.row_index[r] : (uint32_t)(a.row_begin + r);
     const float* lg = a.sel + (size_t)r * a.ldS;
-    float t[SUAVE_MAX_COMPONENTS];
+    float t[KMAX], lgv[KMAX], ev[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {  // every load first
+      lgv[j] = j < a.K ? lg[j] : 0.f;
+      ev[j] = (a.exp_noise && j < a.K) ? a.exp_noise[(size_t)r * a.K + j] : 1.0f;
+    }
+    if (!a.exp_noise) {
+#pragma unroll
+      for (int j4 = 0; j4 < (KMAX + 3) / 4; ++j4) {  // one Philox block = 4 draws
+        if (j4 * 4 >= a.K) break;
+        const uint4 w4 = rng(rid, (uint32_t)j4, kStreamGumbel, (uint32_t)a.step);
+        const uint32_t word[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j4 * 4 + u < KMAX) ev[j4 * 4 + u] = -__logf(u01(word[u]));
+      }
+    }
     float best = -INFINITY;
     kb = 0;
-    uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll 1
-    for (int j = 0; j < a.K; ++j) {
-      float e;
-      if (a.exp_noise) {
-        e = a.exp_noise[(size_t)r * a.K + j];
-      } else {
-        if ((j & 3) == 0) w4 = rng(rid, (uint32_t)(j >> 2), kStreamGumbel, (uint32_t)a.step);  // one block = 4 draws
-        const uint32_t word = (j & 3) == 0 ? w4.x : (j & 3) == 1 ? w4.y : (j & 3) == 2 ? w4.z : w4.w;
-        e = -__logf(u01(word));
-      }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
       // Gumbel noise g = -log(e); the assignment path is deterministic binary32
-      const float tj = detm::dvd(detm::sub(lg[j], detm::log(e)), a.tau);
+      const float tj = detm::dvd(detm::sub(lgv[j], detm::log(ev[j])), a.tau);
       t[j] = tj;
-      if (tj > best) { best = tj; kb = j; }
+      if (j < a.K && tj > best) { best = tj; kb = j; }
     }
     float sum = 0.f;
-#pragma unroll 1
-    for (int j = 0; j < a.K; ++j) { t[j] = __expf(t[j] - best); sum += t[j]; }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      t[j] = j < a.K ? __expf(t[j] - best) : 0.f;
+      sum += t[j];
+    }
     const float inv = 1.0f / sum;
-#pragma unroll 1
-    for (int j = 0; j < a.K; ++j) a.ysoft[(size_t)r * a.ldK + j] = t[j] * inv;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+      if (j < a.K) a.ysoft[(size_t)r * a.ldK + j] = t[j] * inv;
     a.kidx[r] = kb;
     if (a.comp_out) a.comp_out[r] = kb;
   }
@@ -1071,7 +1085,12 @@ int launch_expand(const suave_plan* p, const suave_batch_t& b, float* x, int32_t
 int launch_assign(const LatentFwdArgs& a, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
   ProfScope prof_scope(kProfLatent, s);
-  hipLaunchKernelGGL(k_assign, dim3((a.n_rows + 255) / 256), dim3(256), 0, s, a);
+  const dim3 grid((a.n_rows + 255) / 256), block(256);
+  if (a.K <= 4) hipLaunchKernelGGL(k_assign<4>, grid, block, 0, s, a);
+  else if (a.K <= 8) hipLaunchKernelGGL(k_assign<8>, grid, block, 0, s, a);
+  else if (a.K <= 12) hipLaunchKernelGGL(k_assign<12>, grid, block, 0, s, a);
+  else if (a.K <= 16) hipLaunchKernelGGL(k_assign<16>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(k_assign<SUAVE_MAX_COMPONENTS>, grid, block, 0, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }
