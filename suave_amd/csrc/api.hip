@@ -991,6 +991,8 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   red.sums_out = out ? out->sums : nullptr;
   red.n_rows = (double)B;
   int max_elems = 256;
+  HeadReduceArgs head_red{};  // the encoder head's chunk slabs: summed by extra blocks of the final reduction launch
+  bool have_head = false;
 
   if (grad) {
     if (n_wide)
@@ -1091,10 +1093,10 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
       } else {
         if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
       }
-      HeadReduceArgs h{};
+      HeadReduceArgs& h = head_red;  // (summed by extra blocks of the final reduction launch)
+      have_head = true;
       h.slab = w.gslab; h.chunk_begin = w.chunk_begin; h.K = K; h.D = D; h.ldK = p->ldK; h.ldD = p->ldD; h.ldS = ldS;
       h.n_in = l.n_in; h.ldc = ldc; h.grads = grads; h.w_off = l.w_off; h.b_off = l.b_off; h.ld = l.ld;
-      if (int rc = launch_head_reduce(h, s)) return rc;
     }
     // ---- encoder trunk backward ----
     for (int i = nh - 1; i >= 0; --i) {
@@ -1113,8 +1115,8 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     }
     SUAVE_REQUIRE(slab_off <= w.slab_floats, "internal: slab overflow");
   }
-  if ((grad && red.n_segs > 0) || red.sums_out) {
-    if (int rc = launch_reduce(red, max_elems, s)) return rc;
+  if ((grad && red.n_segs > 0) || red.sums_out || have_head) {
+    if (int rc = launch_reduce(red, max_elems, s, have_head ? &head_red : nullptr)) return rc;
   }
   if (!grad && ready_event) SUAVE_CHECK_HIP(hipEventRecord(ready_event, s));
   // ---- per-row outputs ----

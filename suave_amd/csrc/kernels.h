@@ -237,7 +237,6 @@ int launch_assign(const LatentFwdArgs& a, hipStream_t s);
 int launch_group(const GroupArgs& a, hipStream_t s);
 int reparam_grid(int n_rows);
 int launch_reparam(const LatentFwdArgs& a, hipStream_t s);
-int launch_head_reduce(const HeadReduceArgs& a, hipStream_t s);
 int launch_latent_bwd(const LatentBwdArgs& a, hipStream_t s);
 int launch_posterior_stats(const float* encout, int ldE, int K, int D, int n_rows, float inv_temp, float* enc_out_user,
                            float* post_mean, float* post_logvar, float* probs, hipStream_t s);
@@ -247,7 +246,7 @@ int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const f
                         int16_t* out_codes, int ld_disc, hipStream_t st, const float* wide_logits = nullptr);
 int launch_head_params(const suave_plan* p, int col_index, const float* params, const float* y, const float* s,
                        const int32_t* comp, int64_t n, float* out, int width, hipStream_t st);
-int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s);
+int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s, const HeadReduceArgs* head = nullptr);  // head: the encoder head's chunk slabs, summed by extra blocks of the same launch
 
 // ---- fused MLP chains (chain.hip) ---------------------------------------------------------------
 constexpr int kChainMaxWidth = 256;                    // widest layer (in or out) the register-chained kernel takes

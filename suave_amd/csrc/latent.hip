@@ -640,68 +640,6 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
   }
 }
 
-// dW_head[row(q, c)][j] = sum over the chunks of component c (all chunks for the logits rows), fixed order.
-// Both shapes are latency chains of strided loads, so they are cut short rather than wide:
-//   * blocks [0, logit_blocks): the K logits rows, whose sums run over EVERY chunk (266 at B = 65 536): 64 elements
-//     per block, the four waves take a quarter of the chunk range each, 16 loads in flight, quarters added in order;
-//   * the rest: the mu / logvar rows of component c sum only c's chunks (~27): one thread per element, 16 loads in
-//     flight, the tail of the range as a guarded batch instead of one load at a time.
-__global__ __launch_bounds__(256) void k_head_reduce(HeadReduceArgs a, int logit_blocks) {
-  const int n1 = a.n_in + 1;
-  const size_t stride = (size_t)a.ldS * a.ldc;
-  if ((int)blockIdx.x < logit_blocks) {
-    __shared__ float part[4][64];
-    const int sub = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int e = blockIdx.x * 64 + lane;
-    const bool valid = e < a.K * n1;
-    const int R = valid ? e / n1 : 0, j = valid ? e - R * n1 : 0;
-    const int S = a.chunk_begin[a.K];
-    const int per = (S + 3) / 4;
-    const int s0 = min(sub * per, S), s1 = min(S, s0 + per);
-    const float* src = a.slab + (size_t)R * a.ldc + j;
-    float t = 0.f;
-    if (valid) {
-      for (int s = s0; s < s1; s += 16) {
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = (s + u < s1) ? src[(size_t)(s + u) * stride] : 0.f;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) t += v[u];
-      }
-    }
-    part[sub][lane] = t;
-    __syncthreads();
-    if (sub == 0 && valid) {
-      const float r = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-      if (j < a.n_in) a.grads[a.w_off + (size_t)R * a.ld + j] = r;
-      else a.grads[a.b_off + R] = r;
-    }
-    return;
-  }
-  const int64_t total = (int64_t)2 * a.K * a.D * n1;
-  for (int64_t e = (int64_t)(blockIdx.x - logit_blocks) * 256 + threadIdx.x; e < total;
-       e += (int64_t)(gridDim.x - logit_blocks) * 256) {
-    const int t_row = (int)(e / n1), j = (int)(e % n1);
-    const int R = a.K + t_row;
-    const bool is_lv = t_row >= a.K * a.D;
-    const int u_row = is_lv ? t_row - a.K * a.D : t_row;
-    const int c = u_row / a.D, d = u_row % a.D;
-    const int q = a.ldK + (is_lv ? a.ldD : 0) + d;
-    const int s0 = a.chunk_begin[c], s1 = a.chunk_begin[c + 1];
-    const float* src = a.slab + (size_t)q * a.ldc + j;
-    float t = 0.f;
-    for (int s = s0; s < s1; s += 16) {
-      float v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = (s + u < s1) ? src[(size_t)(s + u) * stride] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) t += v[u];
-    }
-    if (j < a.n_in) a.grads[a.w_off + (size_t)R * a.ld + j] = t;
-    else a.grads[a.b_off + R] = t;
-  }
-}
-
 // encode: clamp logvar, softmax(logits * inv_temperature), mixture moment matching
 __global__ __launch_bounds__(256) void k_posterior_stats(const float* __restrict__ encout, int ldE, int K, int D, int n_rows,
                                                          float inv_temp, float* __restrict__ enc_out_user,
@@ -1123,16 +1061,6 @@ int launch_reparam(const LatentFwdArgs& a, hipStream_t s) {
     lds += sizeof(float) * reparam_colsum_floats(a.K, a.D);
   }
   hipLaunchKernelGGL(k_reparam, dim3(reparam_grid(a.n_rows)), dim3(256), lds, s, a);
-  SUAVE_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-int launch_head_reduce(const HeadReduceArgs& a, hipStream_t s) {
-  const int64_t total = (int64_t)2 * a.K * a.D * (a.n_in + 1);
-  const int logit_blocks = (a.K * (a.n_in + 1) + 63) / 64;
-  ProfScope prof_scope(kProfReduce, s);
-  hipLaunchKernelGGL(k_head_reduce, dim3(logit_blocks + (int)std::min<int64_t>(std::max<int64_t>((total + 255) / 256, 1), 2048)),
-                     dim3(256), 0, s, a, logit_blocks);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }

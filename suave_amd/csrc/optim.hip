@@ -27,8 +27,82 @@ __host__ __device__ inline bool reduce_seg_vec(const ReduceSeg& sg, const float*
   return ((sg.src_off | sg.src_ld | sg.slab_stride) & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0;
 }
 
-__global__ __launch_bounds__(kReduceWaves * 64) void k_reduce(ReduceArgs a, ReduceMap map) {
+// dW_head[row(q, c)][j] = sum over the chunks of component c (all chunks for the logits rows), fixed order.
+// Both shapes are latency chains of strided loads, so they are cut short rather than wide:
+//   * blocks [0, logit_blocks): the K logits rows, whose sums run over EVERY chunk (266 at B = 65 536): 64 elements
+//     per block, the four waves take a quarter of the chunk range each, 16 loads in flight, quarters added in order;
+//   * the rest: the mu / logvar rows of component c sum only c's chunks (~27): one thread per element, 16 loads in
+//     flight, the tail of the range as a guarded batch instead of one load at a time.
+// It rides in k_reduce's launch (as a launch of its own between the head's backward pair and the encoder trunk it
+// was 5 - 7 us on the step's chain): a k_reduce block of 16 waves runs four of its 256-thread blocks side by side.
+__device__ __forceinline__ void head_reduce_blocks(const HeadReduceArgs& a, int logit_blocks, int n_vblocks, int first_vb) {
+  __shared__ float part[4][4][64];  // [virtual block][quarter][element]
+  const int v = threadIdx.x >> 8, vtid = threadIdx.x & 255;
+  const int vb = first_vb + v;
+  const int n1 = a.n_in + 1;
+  const size_t stride = (size_t)a.ldS * a.ldc;
+  const bool logit_vb = vb < logit_blocks;
+  const int sub = vtid >> 6, lane = vtid & 63;
+  const int e_l = vb * 64 + lane;
+  const bool valid_l = logit_vb && e_l < a.K * n1;
+  const int R_l = valid_l ? e_l / n1 : 0, j_l = valid_l ? e_l - R_l * n1 : 0;
+  if (logit_vb) {
+    const int S = a.chunk_begin[a.K];
+    const int per = (S + 3) / 4;
+    const int s0 = min(sub * per, S), s1 = min(S, s0 + per);
+    const float* src = a.slab + (size_t)R_l * a.ldc + j_l;
+    float t = 0.f;
+    if (valid_l) {
+      for (int s = s0; s < s1; s += 16) {
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = (s + u < s1) ? src[(size_t)(s + u) * stride] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += x[u];
+      }
+    }
+    part[v][sub][lane] = t;
+  }
+  __syncthreads();  // (every thread of the block: the virtual blocks of one block may be of either kind)
+  if (logit_vb) {
+    if (sub == 0 && valid_l) {
+      const float r = ((part[v][0][lane] + part[v][1][lane]) + part[v][2][lane]) + part[v][3][lane];
+      if (j_l < a.n_in) a.grads[a.w_off + (size_t)R_l * a.ld + j_l] = r;
+      else a.grads[a.b_off + R_l] = r;
+    }
+    return;
+  }
+  if (vb >= n_vblocks) return;
+  const int64_t total = (int64_t)2 * a.K * a.D * n1;
+  for (int64_t e = (int64_t)(vb - logit_blocks) * 256 + vtid; e < total; e += (int64_t)(n_vblocks - logit_blocks) * 256) {
+    const int t_row = (int)(e / n1), j = (int)(e % n1);
+    const int R = a.K + t_row;
+    const bool is_lv = t_row >= a.K * a.D;
+    const int u_row = is_lv ? t_row - a.K * a.D : t_row;
+    const int c = u_row / a.D, d = u_row % a.D;
+    const int q = a.ldK + (is_lv ? a.ldD : 0) + d;
+    const int s0 = a.chunk_begin[c], s1 = a.chunk_begin[c + 1];
+    const float* src = a.slab + (size_t)q * a.ldc + j;
+    float t = 0.f;
+    for (int s = s0; s < s1; s += 16) {
+      float x[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) x[u] = (s + u < s1) ? src[(size_t)(s + u) * stride] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t += x[u];
+    }
+    if (j < a.n_in) a.grads[a.w_off + (size_t)R * a.ld + j] = t;
+    else a.grads[a.b_off + R] = t;
+  }
+}
+
+__global__ __launch_bounds__(kReduceWaves * 64) void k_reduce(ReduceArgs a, ReduceMap map, HeadReduceArgs head, int head_logit_blocks,
+                                                              int head_vblocks) {
   const int t = threadIdx.x;
+  if ((int)blockIdx.x > map.blk_begin[kMaxReduceSegs]) {  // behind the segment blocks: the encoder head's chunk slabs
+    head_reduce_blocks(head, head_logit_blocks, head_vblocks, ((int)blockIdx.x - 1 - map.blk_begin[kMaxReduceSegs]) * 4);
+    return;
+  }
   if (blockIdx.x == 0) {  // scalar sums (double), one block -- first in dispatch order: it is a latency chain
     if (a.sums_slab && a.sums_out) {
       __shared__ double part[3][kReduceWaves];
@@ -137,7 +211,7 @@ __global__ __launch_bounds__(kReduceWaves * 64) void k_reduce(ReduceArgs a, Redu
   }
 }
 
-int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s) {
+int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s, const HeadReduceArgs* head) {
   (void)max_elems;
   ReduceMap map;
   int blocks = 0;
@@ -151,7 +225,15 @@ int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s) {
   }
   for (int g = a.n_segs; g <= kMaxReduceSegs; ++g) map.blk_begin[g] = blocks;
   ProfScope prof_scope(kProfReduce, s);
-  hipLaunchKernelGGL(k_reduce, dim3(1 + blocks), dim3(kReduceWaves * 64), 0, s, a, map);
+  HeadReduceArgs h{};
+  int logit_blocks = 0, vblocks = 0;
+  if (head != nullptr) {
+    h = *head;
+    const int64_t total = (int64_t)2 * h.K * h.D * (h.n_in + 1);
+    logit_blocks = (h.K * (h.n_in + 1) + 63) / 64;
+    vblocks = logit_blocks + (int)std::min<int64_t>(std::max<int64_t>((total + 255) / 256, 1), 2048);
+  }
+  hipLaunchKernelGGL(k_reduce, dim3(1 + blocks + (vblocks + 3) / 4), dim3(kReduceWaves * 64), 0, s, a, map, h, logit_blocks, vblocks);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }
