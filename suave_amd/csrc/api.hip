@@ -880,6 +880,8 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   la.comp_out = out ? out->component : nullptr;
   la.lrank = w.lrank; la.blk_cnt = w.blk_cnt;
   la.perm_fill = w.perm; la.perm_fill_n = w.n_chunks_max * kGroupRows;
+  const bool one_block = w.n_blocks == 1;  // <= 256 rows: k_assign sorts as well
+  if (one_block) { la.one_chunk_comp = w.chunk_comp; la.one_chunk_begin = w.chunk_begin; la.one_chunks_max = w.n_chunks_max; }
   GroupArgs ga{};
   ga.K = K; ga.n_rows = B; ga.n_blocks = w.n_blocks; ga.n_chunks_max = w.n_chunks_max; ga.kidx = w.kidx;
   ga.lrank = w.lrank; ga.blk_cnt = w.blk_cnt; ga.chunk_comp = w.chunk_comp;
@@ -895,7 +897,8 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     if (int rc = launch_gemm(g, p->n_cu, s)) return rc;
   }
   if (int rc = launch_assign(la, s)) return rc;
-  if (int rc = launch_group(ga, s)) return rc;
+  if (!one_block)
+    if (int rc = launch_group(ga, s)) return rc;
   {
     GemmArgs g = gemm_base();  // [mu_k | logvar_k] of each row's own component -> sel[:, ldK:]
     g.A = hlast_e; g.B = params + m.enc_head.w_off; g.C = w.sel + p->ldK; g.bias = params + m.enc_head.b_off;

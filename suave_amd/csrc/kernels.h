@@ -64,6 +64,10 @@ struct LatentFwdArgs {
   int32_t* blk_cnt;     // [ceil(B/256), K]
   int32_t* perm_fill;   // k_assign pre-fills the sorted-position table of k_group_scatter with -1 (null: no fill)
   int perm_fill_n;
+  // batches of one 256-row block: k_assign also does k_group_scatter's work (one launch less on the step's chain)
+  int32_t* one_chunk_comp;   // [n_chunks_max] or null
+  int32_t* one_chunk_begin;  // [K + 1]
+  int one_chunks_max;
   // KL terms (k_reparam): losses.py:51-57, :87-97 with the prior of the selected component (model.py:1607-1613)
   const float* params;
   int prior_logits_off, prior_mu_off, prior_logvar_off;

@@ -239,6 +239,26 @@ __global__ __launch_bounds__(256) void k_assign(LatentFwdArgs a) {
     a.lrank[r] = rank;
   }
   if (tid < a.K) a.blk_cnt[(size_t)blockIdx.x * a.K + tid] = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+  if (a.one_chunk_comp != nullptr) {  // the whole batch is this block (launch_assign): the chunk table and the scatter
+    __shared__ int cb[SUAVE_MAX_COMPONENTS + 1];
+    if (tid == 0) {
+      int ch = 0;
+      for (int c = 0; c < a.K; ++c) {
+        cb[c] = ch;
+        ch = min(ch + (wcnt[0][c] + wcnt[1][c] + wcnt[2][c] + wcnt[3][c] + kGroupRows - 1) / kGroupRows, a.one_chunks_max);
+      }
+      cb[a.K] = ch;
+    }
+    __syncthreads();  // (also orders the -1 fill above before the scatter below: one block wrote both)
+    if (tid <= a.K) a.one_chunk_begin[tid] = cb[tid];
+    for (int ch = tid; ch < a.one_chunks_max; ch += 256) {
+      int comp = -1;
+      for (int c = 0; c < a.K; ++c)
+        if (ch >= cb[c] && ch < cb[c + 1]) comp = c;
+      a.one_chunk_comp[ch] = comp;
+    }
+    if (valid) a.perm_fill[cb[kb] * kGroupRows + rank] = r;
+  }
 }
 
 // Counting sort, passes 2 + 3 in one launch.  Every block works out for itself where its runs start: wave w takes
