@@ -168,70 +168,112 @@ __global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_
 }
 
 
-// supervised, step 1: y_soft = softmax((logits + g)/tau), k = argmax; one row per thread.  Also the first
-// pass of the stable counting sort by component: the row's rank among the rows of its 256-row block that
-// chose the same component, and the block's per-component counts.
-// KMAX >= K, compile-time: the K scores stay in registers (indexed dynamically they lived in scratch memory) and the
-// K deterministic log / divide chains are independent instruction streams the scheduler interleaves.
-template <int KMAX>
-__global__ __launch_bounds__(256) void k_assign(LatentFwdArgs a) {
+// supervised, step 1: y_soft = softmax((logits + g)/tau), k = argmax.  Also the first pass of the stable counting
+// sort by component: the row's rank among the rows of its 256-row block that chose the same component, and the
+// block's per-component counts.
+// A block is 256 rows x FOUR LANES PER ROW: the assignment path is deterministic binary32 (detmath log and divide,
+// ~300 dependent instructions per component), so one thread per row was a chain of K of them (12 us at one wave per
+// SIMD); lane q of a row takes the components of Philox blocks q, q + 4, ... (four components per block: one Philox
+// call per lane for K <= 16), the row's four lanes combine (best score, first index) and the exponential sums by
+// shuffles in a fixed order.  NB = Philox blocks per lane (compile-time: the scores stay in registers).
+template <int NB>
+__global__ __launch_bounds__(1024) void k_assign(LatentFwdArgs a) {
   __shared__ int wcnt[4][SUAVE_MAX_COMPONENTS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int kb_s[256];
+  const int t1024 = threadIdx.x;
   const Philox rng(a.seed);
-  const int r = blockIdx.x * 256 + tid;
-  const bool valid = r < a.n_rows;
   // (the -1 fill of the sorted-position table rides along: as a memset of its own it was a 4.6 us dispatch on the chain)
   if (a.perm_fill != nullptr)
-    for (int i = r; i < a.perm_fill_n; i += gridDim.x * 256) a.perm_fill[i] = -1;
-  int kb = -1;
-  if (valid) {
-    const uint32_t rid = a.row_index ? (uint32_t)a.row_index[r] : (uint32_t)(a.row_begin + r);
-    const float* lg = a.sel + (size_t)r * a.ldS;
-    float t[KMAX], lgv[KMAX], ev[KMAX];
+    for (int i = blockIdx.x * 1024 + t1024; i < a.perm_fill_n; i += gridDim.x * 1024) a.perm_fill[i] = -1;
+  {
+    const int q = t1024 & 3;
+    const int r = blockIdx.x * 256 + (t1024 >> 2);
+    const bool valid = r < a.n_rows;
+    const int rr = valid ? r : 0;  // (all four lanes of a row take part in the shuffles)
+    const uint32_t rid = a.row_index ? (uint32_t)a.row_index[rr] : (uint32_t)(a.row_begin + rr);
+    const float* lg = a.sel + (size_t)rr * a.ldS;
+    float lgv[NB][4], ev[NB][4], t[NB][4];
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) {  // every load first
-      lgv[j] = j < a.K ? lg[j] : 0.f;
-      ev[j] = (a.exp_noise && j < a.K) ? a.exp_noise[(size_t)r * a.K + j] : 1.0f;
-    }
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // every load first
+        const int j = 4 * (q + 4 * b) + u;
+        lgv[b][u] = j < a.K ? lg[j] : 0.f;
+        ev[b][u] = (a.exp_noise && j < a.K) ? a.exp_noise[(size_t)rr * a.K + j] : 1.0f;
+      }
     if (!a.exp_noise) {
 #pragma unroll
-      for (int j4 = 0; j4 < (KMAX + 3) / 4; ++j4) {  // one Philox block = 4 draws
-        if (j4 * 4 >= a.K) break;
-        const uint4 w4 = rng(rid, (uint32_t)j4, kStreamGumbel, (uint32_t)a.step);
-        const uint32_t word[4] = {w4.x, w4.y, w4.z, w4.w};
+      for (int b = 0; b < NB; ++b) {
+        const int j4 = q + 4 * b;
+        if (j4 * 4 < a.K) {
+          const uint4 w4 = rng(rid, (uint32_t)j4, kStreamGumbel, (uint32_t)a.step);  // one block = 4 draws
+          const uint32_t word[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (j4 * 4 + u < KMAX) ev[j4 * 4 + u] = -__logf(u01(word[u]));
+          for (int u = 0; u < 4; ++u) ev[b][u] = -__logf(u01(word[u]));
+        }
       }
     }
     float best = -INFINITY;
-    kb = 0;
+    int kb = 0x7FFFFFFF;
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-      // Gumbel noise g = -log(e); the assignment path is deterministic binary32
-      const float tj = detm::dvd(detm::sub(lgv[j], detm::log(ev[j])), a.tau);
-      t[j] = tj;
-      if (j < a.K && tj > best) { best = tj; kb = j; }
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = 4 * (q + 4 * b) + u;
+        // Gumbel noise g = -log(e); the assignment path is deterministic binary32
+        const float tj = detm::dvd(detm::sub(lgv[b][u], detm::log(ev[b][u])), a.tau);
+        t[b][u] = tj;
+        if (j < a.K && (tj > best || (tj == best && j < kb))) { best = tj; kb = j; }  // first maximum (ascending j within b; blocks interleave over lanes)
+      }
+#pragma unroll
+    for (int off = 1; off <= 2; off <<= 1) {  // the row's four lanes: greater score, on a tie the smaller index
+      const float bo = __shfl_xor(best, off, 64);
+      const int ko = __shfl_xor(kb, off, 64);
+      if (bo > best || (bo == best && ko < kb)) { best = bo; kb = ko; }
     }
+    if (kb == 0x7FFFFFFF) kb = 0;  // (every score NaN: component 0, as the sequential scan)
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-      t[j] = j < a.K ? __expf(t[j] - best) : 0.f;
-      sum += t[j];
-    }
-    const float inv = 1.0f / sum;
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j)
-      if (j < a.K) a.ysoft[(size_t)r * a.ldK + j] = t[j] * inv;
-    a.kidx[r] = kb;
-    if (a.comp_out) a.comp_out[r] = kb;
+      for (int u = 0; u < 4; ++u) {
+        const int j = 4 * (q + 4 * b) + u;
+        t[b][u] = j < a.K ? __expf(t[b][u] - best) : 0.f;
+        sum += t[b][u];
+      }
+    const int l0 = (t1024 & 63) & ~3;
+    const float s0 = __shfl(sum, l0, 64), s1 = __shfl(sum, l0 + 1, 64), s2 = __shfl(sum, l0 + 2, 64), s3 = __shfl(sum, l0 + 3, 64);
+    const float inv = 1.0f / (((s0 + s1) + s2) + s3);
+    if (valid) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = 4 * (q + 4 * b) + u;
+          if (j < a.K) a.ysoft[(size_t)r * a.ldK + j] = t[b][u] * inv;
+        }
+      if (q == 0) {
+        a.kidx[r] = kb;
+        if (a.comp_out) a.comp_out[r] = kb;
+      }
+    }
+    if (q == 0) kb_s[t1024 >> 2] = valid ? kb : -1;
   }
+  __syncthreads();
+  // the counting part: one thread per row (the first four waves)
+  const int tid = t1024, lane = tid & 63, wave = tid >> 6;
+  const bool counting = tid < 256;
+  const int r = blockIdx.x * 256 + tid;
+  const bool valid = counting && r < a.n_rows;
+  const int kb = counting ? kb_s[tid] : -1;
   int rank = 0;
+  if (counting) {
 #pragma unroll 1
-  for (int c = 0; c < a.K; ++c) {
-    const unsigned long long m = __ballot(kb == c);
-    if (kb == c) rank = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) wcnt[wave][c] = __popcll(m);
+    for (int c = 0; c < a.K; ++c) {
+      const unsigned long long m = __ballot(kb == c);
+      if (kb == c) rank = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wcnt[wave][c] = __popcll(m);
+    }
   }
   __syncthreads();
   if (valid) {
@@ -251,7 +293,7 @@ __global__ __launch_bounds__(256) void k_assign(LatentFwdArgs a) {
     }
     __syncthreads();  // (also orders the -1 fill above before the scatter below: one block wrote both)
     if (tid <= a.K) a.one_chunk_begin[tid] = cb[tid];
-    for (int ch = tid; ch < a.one_chunks_max; ch += 256) {
+    for (int ch = tid; ch < a.one_chunks_max; ch += 1024) {
       int comp = -1;
       for (int c = 0; c < a.K; ++c)
         if (ch >= cb[c] && ch < cb[c + 1]) comp = c;
@@ -1043,12 +1085,10 @@ int launch_expand(const suave_plan* p, const suave_batch_t& b, float* x, int32_t
 int launch_assign(const LatentFwdArgs& a, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
   ProfScope prof_scope(kProfLatent, s);
-  const dim3 grid((a.n_rows + 255) / 256), block(256);
-  if (a.K <= 4) hipLaunchKernelGGL(k_assign<4>, grid, block, 0, s, a);
-  else if (a.K <= 8) hipLaunchKernelGGL(k_assign<8>, grid, block, 0, s, a);
-  else if (a.K <= 12) hipLaunchKernelGGL(k_assign<12>, grid, block, 0, s, a);
-  else if (a.K <= 16) hipLaunchKernelGGL(k_assign<16>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(k_assign<SUAVE_MAX_COMPONENTS>, grid, block, 0, s, a);
+  const dim3 grid((a.n_rows + 255) / 256), block(1024);
+  static_assert(SUAVE_MAX_COMPONENTS <= 32, "k_assign: two Philox blocks per lane cover 32 components");
+  if (a.K <= 16) hipLaunchKernelGGL(k_assign<1>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(k_assign<2>, grid, block, 0, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }
