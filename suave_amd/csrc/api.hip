@@ -416,6 +416,18 @@ int bwd_weight_args(const suave_plan* p, const suave_layer_t& l, const float* dC
                     int rows, float* slab_base, size_t* slab_off, ReduceArgs* red, int* max_elems, GemmArgs* out) {
   const int ldc = round_up(l.n_in + 1, 4);
   const int splits = tn_splits(p, l.n_out, l.n_in, rows);
+  if (gemm_wgrad_direct_ok(rows, splits) && red->dst != nullptr && l.ld % 4 == 0 && l.w_off % 4 == 0) {
+    // a few hundred rows, one split: the small-batch kernel writes the layer's gradient itself (no slab, no segment)
+    GemmArgs g = gemm_base();
+    g.a_scale = t_grad_scale;
+    g.A = dC; g.B = A; g.C = red->dst + l.w_off; g.bias_out = red->dst + l.b_off;
+    g.M = l.n_out; g.N = l.n_in; g.K = rows;
+    g.lda = lddc; g.ldb = lda; g.ldc = l.ld;
+    g.a_kmajor = 1; g.b_kmajor = 1;
+    g.epi = kEpiSlab; g.splits = 1; g.slab_stride = 0; g.ones_col = l.n_in;
+    *out = g;
+    return 0;
+  }
   GemmArgs g = gemm_base();
   g.a_scale = t_grad_scale;
   g.A = dC; g.B = A; g.C = slab_base + *slab_off;

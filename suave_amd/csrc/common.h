@@ -237,6 +237,8 @@ struct GemmArgs {
   // Indexed by (tile_m, tile_n, wave, lane); gemm_mask_words() sizes the buffer.  Null: not written / H is read.
   uint64_t* mask_out;
   const uint64_t* mask_in;
+  float* bias_out;            // kEpiSlab on the small-batch kernel, one split: the ones column's sums go here (the bias
+                              // gradient) instead of column ones_col of C, and C is the weight gradient itself
   float a_scale;              // arithmetic mode 4 (fp16 planes): power of two the A operand is multiplied by before it is
                               // cut into planes (gradient operands are ~1 / batch rows: keeps them clear of the fp16
                               // subnormals); the product is scaled back in the epilogue.  <= 0 means 1.
@@ -285,6 +287,7 @@ struct GemmSmallScope {  // alive inside an ELBO step: small batches may take ge
   GemmSmallScope(const GemmSmallScope&) = delete;
   GemmSmallScope& operator=(const GemmSmallScope&) = delete;
 };
+bool gemm_wgrad_direct_ok(int64_t rows, int splits);  // see gemm.hip
 int gemm_small_rows_limit_set(int rows);
 int64_t gemm_small_rows_limit();  // the row count up to which gemm_small_rows can hold (whatever the scope / mode)
 bool gemm_small_rows(int64_t M);  // the forward forms of an M-row batch take the split-K small-batch kernel (no sign words)

@@ -1100,8 +1100,11 @@ __device__ __forceinline__ void gemm_small_wgrad_body(const GemmArgs& a, int row
           ((part_s[0][slot][lane] + part_s[1][slot][lane]) + part_s[2][slot][lane]) + part_s[3][slot][lane];
     }
   }
-  if (a.ones_col >= 0 && tile_n == 0 && wave == 0 && lane < 32 && m0 + lane < a.M)
-    Cout[(size_t)(m0 + lane) * a.ldc + a.ones_col] = ((bias_s[0][lane] + bias_s[1][lane]) + bias_s[2][lane]) + bias_s[3][lane];
+  if (a.ones_col >= 0 && tile_n == 0 && wave == 0 && lane < 32 && m0 + lane < a.M) {
+    const float bsum_all = ((bias_s[0][lane] + bias_s[1][lane]) + bias_s[2][lane]) + bias_s[3][lane];
+    if (a.bias_out != nullptr) a.bias_out[m0 + lane] = bsum_all;  // direct form (one split): straight into the gradient
+    else Cout[(size_t)(m0 + lane) * a.ldc + a.ones_col] = bsum_all;
+  }
 }
 
 template <int EPI, int GRP = 0>
@@ -1266,7 +1269,7 @@ int check_gemm(const GemmArgs& a) {
     SUAVE_REQUIRE(a.grouped == 1 ? !a.a_kmajor : (a.a_kmajor && a.b_kmajor && a.epi == kEpiSlab && a.splits == a.K / kGroupRows),
                   "gemm: unsupported grouped operand layout");
   }
-  SUAVE_REQUIRE(a.ldc >= a.N + (a.ones_col >= 0 ? 1 : 0), "gemm: ldc too small");
+  SUAVE_REQUIRE(a.ldc >= a.N + ((a.ones_col >= 0 && a.bias_out == nullptr) ? 1 : 0), "gemm: ldc too small");
   SUAVE_REQUIRE(a.ones_col < 0 || a.ones_col == a.N, "gemm: the bias column sits right after the N real columns");
   SUAVE_REQUIRE(a.epi != kEpiSlab || a.splits >= 1, "gemm: bad split count");
   return 0;
@@ -1356,10 +1359,19 @@ bool small_wgrad_ok(const GemmArgs& a) {
 }
 }  // namespace
 
+// A weight gradient over `rows` batch rows in ONE split on the small-batch kernel can write the gradient itself
+// (C = the layer's weight gradient, GemmArgs::bias_out = its bias gradient): no slab, no reduction segment.
+bool gemm_wgrad_direct_ok(int64_t rows, int splits) {
+  static const bool off = getenv("SUAVE_NO_SMALL_WGRAD") != nullptr || getenv("SUAVE_NO_SMALL_BWD") != nullptr ||
+                          getenv("SUAVE_NO_DIRECT_WGRAD") != nullptr;  // tuning knobs
+  return !off && splits == 1 && gemm_small_rows(rows) && rows <= 1024;
+}
+
 int launch_gemm(const GemmArgs& a, int n_cu, hipStream_t stream) {
   (void)n_cu;
   if (a.M <= 0 || a.N <= 0) return 0;
   if (int rc = check_gemm(a)) return rc;
+  SUAVE_REQUIRE(a.bias_out == nullptr || small_wgrad_ok(a), "gemm: the direct weight-gradient form needs the small-batch kernel");
   const int splits = a.epi == kEpiSlab ? a.splits : 1;
   GemmArgs args = a;
   args.splits = splits;
@@ -1461,7 +1473,7 @@ int launch_gemm_pair(const GemmArgs& d, const GemmArgs& w, int n_cu, hipStream_t
     SUAVE_CHECK_HIP(hipGetLastError());
     return 0;
   }
-  if (!fusable || (no_pair && d.grouped == 0)) {
+  if (!fusable || w.bias_out != nullptr || (no_pair && d.grouped == 0)) {  // (bias_out: only launch_gemm's small-batch kernel)
     if (int rc = launch_gemm(w, n_cu, stream)) return rc;
     return launch_gemm(d, n_cu, stream);
   }
