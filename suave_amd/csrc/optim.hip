@@ -19,7 +19,12 @@ constexpr int kReduceWaves = 16;  // waves of a block
 // Elements per block.  The slab range of an element is cut over the block's waves, and for segments with many
 // slabs and few elements (per-block column sums: 1024 slabs of 74 x 12 floats) also over lane groups of a wave, so
 // that a lane's whole share (<= 16 loads) is in flight at once: the kernel is a latency chain, not a stream.
-__host__ __device__ inline int reduce_epb(int n_slabs) { return n_slabs > 1024 ? 4 : n_slabs > 256 ? 16 : 64; }
+// With at most 16 slabs (small batches) a thread sums its element's whole range itself, 1024 elements per block:
+// sixteen waves cutting a range of four slabs left most of them idle and the launch was mostly block dispatch.
+constexpr int kReduceFewSlabs = 16;
+__host__ __device__ inline int reduce_epb(int n_slabs) {
+  return n_slabs > 1024 ? 4 : n_slabs > 256 ? 16 : n_slabs > kReduceFewSlabs ? 64 : kReduceWaves * 64;
+}
 
 __host__ __device__ inline bool reduce_seg_vec(const ReduceSeg& sg, const float* slab) {
   // Slabs whose rows are 16-byte aligned (every GEMM slab: ldc and the slab offsets are multiples of 4 floats) are
@@ -143,6 +148,40 @@ __global__ __launch_bounds__(kReduceWaves * 64) void k_reduce(ReduceArgs a, Redu
   for (int g = 1; g < kMaxReduceSegs; ++g)  // (uniform; the whole ascending table is fetched at once, entries past
     seg_id = blk >= map.blk_begin[g] ? g : seg_id;  //  the last segment hold the block count: never selected)
   const ReduceSeg sg = a.segs[seg_id];
+  if (sg.n_slabs <= kReduceFewSlabs) {  // (block-uniform) one thread per (vector) element, every slab load in flight at once
+    const int cols_f = sg.cols + (sg.bias_off1 ? 1 : 0);
+    const bool vec = reduce_seg_vec(sg, a.slab);
+    const int qpr = vec ? (cols_f + 3) >> 2 : cols_f;
+    const int64_t e = (int64_t)(blk - map.blk_begin[seg_id]) * (kReduceWaves * 64) + t;
+    if (e >= (int64_t)sg.rows * qpr) return;
+    const int i = (int)(e / qpr), j = (int)(e % qpr) * (vec ? 4 : 1);
+    const float* src = a.slab + sg.src_off + (int64_t)i * sg.src_ld + j;
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      float4 v[kReduceFewSlabs];
+#pragma unroll
+      for (int q = 0; q < kReduceFewSlabs; ++q)
+        v[q] = *reinterpret_cast<const float4*>(src + (int64_t)min(q, max(sg.n_slabs - 1, 0)) * sg.slab_stride);
+#pragma unroll
+      for (int q = 0; q < kReduceFewSlabs; ++q)
+        if (q < sg.n_slabs) { r[0] += v[q].x; r[1] += v[q].y; r[2] += v[q].z; r[3] += v[q].w; }
+    } else {
+      float v[kReduceFewSlabs];
+#pragma unroll
+      for (int q = 0; q < kReduceFewSlabs; ++q) v[q] = src[(int64_t)min(q, max(sg.n_slabs - 1, 0)) * sg.slab_stride];
+#pragma unroll
+      for (int q = 0; q < kReduceFewSlabs; ++q)
+        if (q < sg.n_slabs) r[0] += v[q];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (!vec && c > 0) break;
+      const int jj = j + c;
+      if (jj < sg.cols) a.dst[sg.dst_off + (int64_t)i * sg.dst_si + (int64_t)jj * sg.dst_sj] = r[c];
+      else if (jj < cols_f) a.dst[sg.bias_off1 - 1 + i] = r[c];
+    }
+    return;
+  }
   const int sub = t >> 6, lane = t & 63;
   const int epb = reduce_epb(sg.n_slabs), cpw = 64 / epb;  // elements per block, slab cuts per wave
   const int n_cuts = kReduceWaves * cpw;
