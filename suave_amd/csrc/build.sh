@@ -9,7 +9,11 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $SU
 pids=()
 for f in gemm chain loss wide embed latent optim sample frame api; do
   [ -f $f.hip ] || continue
-  if [ ! -f $OBJ/$f.o ] || [ $f.hip -nt $OBJ/$f.o ] || [ common.h -nt $OBJ/$f.o ] || [ kernels.h -nt $OBJ/$f.o ] || [ detmath.h -nt $OBJ/$f.o ] || [ ../../include/suave_hip.h -nt $OBJ/$f.o ]; then
+  stale=0  # an object is rebuilt when its source, ANY header here or under include/, or this script is newer
+  for dep in $f.hip *.h ../../include/*.h build.sh; do
+    if [ ! -f $OBJ/$f.o ] || [ $dep -nt $OBJ/$f.o ]; then stale=1; fi
+  done
+  if [ $stale = 1 ]; then
     extra=""
     # deterministic binary32 paths (detmath.h): no FMA contraction, correctly rounded sqrt / divide
     if [ $f = sample ] || [ $f = latent ]; then extra="-ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt"; fi
