@@ -21,6 +21,9 @@
 //           operand fetch (lane l: i = l&31, k = l>>5) is a conflict-free ds_read_b32.
 // Block tile 128x128 (2x2 waves) or 256x64 (4x1 waves, N <= 64), wave tile 64x64 = 2x2 MFMA tiles, K step 16,
 // double-buffered LDS with the next two tiles' global loads in flight during the MFMAs.
+// ELBO steps of at most 8192 rows (suave_small_batch_rows_set) take the split-K kernels instead (gemm_small_*,
+// mode 4 only): a block per 32 x 64 output tile, the K range divided among its four waves, fragments loaded
+// straight from global memory -- a short latency chain where the tile kernel leaves the chip empty.
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
