@@ -1110,16 +1110,25 @@ __device__ __forceinline__ void gemm_small_wgrad_body(const GemmArgs& a, int row
   }
 }
 
+// XCD-aware order of the small-batch launches: workgroups go to the eight XCDs round-robin, so dispatch positions
+// p, p + 8, ... share an L2; they get CONSECUTIVE work items (the column tiles of one row tile read the same A rows,
+// the tiles of one weight-gradient split the same batch rows).  0.2 - 0.7 % of a 1 024 - 8 192-row step.
+__device__ __forceinline__ int xcd_consecutive(int p, int n) {
+  const int per = n >> 3;
+  return p < per * 8 ? (p & 7) * per + (p >> 3) : p;
+}
+
 template <int EPI, int GRP = 0>
 __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
   __shared__ float part_s[4][32][64];
-  gemm_small_body<EPI, GRP, false>(a, blockIdx.x, part_s);
+  gemm_small_body<EPI, GRP, false>(a, xcd_consecutive(blockIdx.x, gridDim.x), part_s);
 }
 
 __global__ __launch_bounds__(256) void gemm_small_wgrad_kernel(GemmArgs a, int rows_per_split) {
   __shared__ float part_s[4][32][64];
   __shared__ float bias_s[4][32];
-  gemm_small_wgrad_body(a, rows_per_split, blockIdx.x, blockIdx.y, part_s, bias_s);
+  const int lin = xcd_consecutive(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);  // (tile fastest)
+  gemm_small_wgrad_body(a, rows_per_split, lin % (int)gridDim.x, lin / (int)gridDim.x, part_s, bias_s);
 }
 
 // Both backward GEMMs of a layer over a small batch in one launch (they are independent and neither fills the chip):
@@ -1129,8 +1138,12 @@ __global__ __launch_bounds__(256) void gemm_small_pair_kernel(GemmArgs d, GemmAr
   __shared__ float part_s[4][32][64];
   __shared__ float bias_s[4][32];
   const int b = blockIdx.x;
-  if (b < w_blocks) gemm_small_wgrad_body<GRP == 1 ? 2 : 0>(w, rows_per_split, b % w_tiles, b / w_tiles, part_s, bias_s);
-  else gemm_small_body<DEPI, GRP, GRP == 1>(d, b - w_blocks, part_s);
+  if (b < w_blocks) {
+    const int wb = xcd_consecutive(b, w_blocks);
+    gemm_small_wgrad_body<GRP == 1 ? 2 : 0>(w, rows_per_split, wb % w_tiles, wb / w_tiles, part_s, bias_s);
+  } else {
+    gemm_small_body<DEPI, GRP, GRP == 1>(d, xcd_consecutive(b - w_blocks, (int)gridDim.x - w_blocks), part_s);
+  }
 }
 
 // Weight-gradient launches are (tiles, K splits) grids of a few tiles: the tiles of ONE split read the same rows of
