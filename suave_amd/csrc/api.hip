@@ -89,7 +89,6 @@ struct Workspace {
   float* wideT;  // row-major transposed copies of the wide heads' weights (WideCol::t_off), rewritten every backward
   int16_t* ecodes;  // [n_embed, rows] codes of the embedded columns (first encoder layer)
   float* wT[2 * SUAVE_MAX_HIDDEN + 2];  // row-major transposes of the layer weights, in all_layers() order
-  unsigned char* chain_img;             // bf16 plane images of the fused chains' weights (chain.hip), rewritten every call
   float* slab;
   double* sums_slab;
   size_t slab_floats;
@@ -165,47 +164,6 @@ std::vector<const suave_layer_t*> all_layers(const suave_plan* p) {
   return v;
 }
 
-// ---- fused chains (chain.hip): which parts of this model they take -----------------------------------------
-// decoder: z -> hidden layers -> y_projection in one launch (all widths <= kChainMaxWidth)
-bool decoder_chain_ok(const suave_plan* p) {
-  const suave_model_t& m = p->model;
-  if (!chain_enabled()) return false;
-  int k = m.latent_dim;
-  for (int i = 0; i < m.n_hidden; ++i) {
-    if (!chain_layer_ok(m.dec[i].n_out, k)) return false;
-    k = m.dec[i].n_out;
-  }
-  return chain_layer_ok(m.y_proj.n_out, k);
-}
-// encoder: x -> hidden layers (-> the component_logits rows of the head) in one launch; embedded first layers
-// (wide categorical columns, embed.hip) keep the per-layer path
-bool encoder_chain_ok(const suave_plan* p) {
-  const suave_model_t& m = p->model;
-  if (!chain_enabled() || !p->embed_host.empty() || m.n_hidden == 0) return false;
-  int k = m.enc_in;
-  for (int i = 0; i < m.n_hidden; ++i) {
-    if (!chain_layer_ok(m.enc[i].n_out, k)) return false;
-    k = m.enc[i].n_out;
-  }
-  return true;
-}
-size_t chain_images_bytes(const suave_plan* p) {  // the larger of the two chains' images (they run one after the other)...
-  const suave_model_t& m = p->model;
-  size_t enc = 0, dec = 0;
-  int k = m.enc_in;
-  for (int i = 0; i < m.n_hidden; ++i) { enc += chain_image_bytes(m.enc[i].n_out, k); k = m.enc[i].n_out; }
-  enc += chain_image_bytes(m.n_components, k);
-  k = m.latent_dim;
-  for (int i = 0; i < m.n_hidden; ++i) { dec += chain_image_bytes(m.dec[i].n_out, k); k = m.dec[i].n_out; }
-  dec += chain_image_bytes(m.y_proj.n_out, k);
-  // ... but kept side by side (+ the decoder's data-gradient chain: the same shapes transposed)
-  size_t bwd = 0;
-  k = m.latent_dim;
-  for (int i = 0; i < m.n_hidden; ++i) { bwd += chain_image_bytes(k, m.dec[i].n_out); k = m.dec[i].n_out; }
-  bwd += chain_image_bytes(k, m.y_proj.n_out);
-  return enc + dec + bwd + 64;
-}
-
 void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
   const suave_model_t& m = p->model;
   Carver c{static_cast<char*>(base)};
@@ -240,7 +198,6 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
     int li = 0;
     for (const suave_layer_t* l : all_layers(p)) w->wT[li++] = c.take<float>((size_t)l->n_in * round_up(l->n_out, 4) + 4);
   }
-  w->chain_img = c.take<unsigned char>(chain_images_bytes(p) + 16);
   w->catkl = c.take<float>(R);
   w->gausskl = c.take<float>(R);
   w->recon = c.take<float>(R);
@@ -285,6 +242,8 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
   w->slab = c.take<float>(slab);
   w->sums_slab = c.take<double>(((size_t)lg * nch + 1024 + 4096) * 4);
   w->total_bytes = (c.off + 255) & ~size_t(255);
+  // (a decode call uses the head of the same workspace; its fused path needs the weight images whatever the row count)
+  if (m.n_hidden == 2) w->total_bytes = std::max(w->total_bytes, (decode_fused_image_bytes(p) + 511) & ~size_t(255));
 }
 
 int check_batch(const suave_plan* p, const suave_batch_t* b) {
@@ -336,60 +295,6 @@ int fwd_layer(const suave_plan* p, const float* params, const suave_layer_t& l, 
   g.step = nz ? nz->step : 0;
   g.stream_id = stream_id;
   return launch_gemm(g, p->n_cu, s);
-}
-
-// Decoder trunk + y_projection as one fused chain (decoder.py:286-300, :343-344).  hd == nullptr: the hidden
-// activations never leave the registers (validation, generation).
-int decoder_chain_forward(const suave_plan* p, const float* params, const float* z, int rows, float* const* hd, float* y,
-                          float drop_p, const suave_noise_t* nz, const suave_batch_t* b, int vdiv, unsigned char* images,
-                          hipStream_t s) {
-  const suave_model_t& m = p->model;
-  ChainArgs a;
-  std::memset(&a, 0, sizeof(a));
-  ChainWeights w[kChainMaxLayers];
-  int k = m.latent_dim, n = 0;
-  for (int i = 0; i < m.n_hidden; ++i, ++n) {
-    const suave_layer_t& l = m.dec[i];
-    w[n] = ChainWeights{params + l.w_off, l.n_out, k, l.ld, 0};
-    a.L[n].bias = params + l.b_off; a.L[n].out = hd ? hd[i] : nullptr; a.L[n].ldo = p->ldH[i];
-    a.L[n].epi = kChainReluDrop; a.L[n].keep = nz ? nz->dec_keep[i] : nullptr; a.L[n].stream_id = kStreamDecDrop + i;
-    k = l.n_out;
-  }
-  w[n] = ChainWeights{params + m.y_proj.w_off, m.y_proj.n_out, k, m.y_proj.ld, 0};
-  a.L[n].bias = params + m.y_proj.b_off; a.L[n].out = y; a.L[n].ldo = p->ldY; a.L[n].epi = kChainBias;
-  ++n;
-  a.n_layers = n; a.in = z; a.ld_in = p->ldD; a.in_width = m.latent_dim; a.rows = rows; a.drop_p = drop_p;
-  a.seed = nz ? nz->seed : 0; a.step = nz ? nz->step : 0;
-  a.row_ids = b ? b->row_index : nullptr; a.row_begin = b ? b->row_begin : 0; a.row_vdiv = vdiv;
-  return launch_chain(a, w, images, s);
-}
-
-// Encoder trunk (+ component_logits, written to `logits` with row stride ld_logits) as one fused chain
-// (encoder.py:46-58, :63-64).  he_all == false: only the last hidden activation is written.
-int encoder_chain_forward(const suave_plan* p, const float* params, const float* x, int rows, float* const* he, bool he_all,
-                          float* logits, int ld_logits, float drop_p, const suave_noise_t* nz, const suave_batch_t* b,
-                          unsigned char* images, hipStream_t s) {
-  const suave_model_t& m = p->model;
-  ChainArgs a;
-  std::memset(&a, 0, sizeof(a));
-  ChainWeights w[kChainMaxLayers];
-  int k = m.enc_in, n = 0;
-  for (int i = 0; i < m.n_hidden; ++i, ++n) {
-    const suave_layer_t& l = m.enc[i];
-    w[n] = ChainWeights{params + l.w_off, l.n_out, k, l.ld, 0};
-    a.L[n].bias = params + l.b_off; a.L[n].out = (he_all || i == m.n_hidden - 1) ? he[i] : nullptr; a.L[n].ldo = p->ldH[i];
-    a.L[n].epi = kChainReluDrop; a.L[n].keep = nz ? nz->enc_keep[i] : nullptr; a.L[n].stream_id = kStreamEncDrop + i;
-    k = l.n_out;
-  }
-  if (logits != nullptr && n < kChainMaxLayers) {
-    w[n] = ChainWeights{params + m.enc_head.w_off, m.n_components, k, m.enc_head.ld, 0};
-    a.L[n].bias = params + m.enc_head.b_off; a.L[n].out = logits; a.L[n].ldo = ld_logits; a.L[n].epi = kChainBias;
-    ++n;
-  }
-  a.n_layers = n; a.in = x; a.ld_in = p->ldI; a.in_width = m.enc_in; a.rows = rows; a.drop_p = drop_p;
-  a.seed = nz ? nz->seed : 0; a.step = nz ? nz->step : 0;
-  a.row_ids = b->row_index; a.row_begin = b->row_begin;
-  return launch_chain(a, w, images, s);
 }
 
 // data gradient: dA = (dC * W) [* relu/dropout mask of H]
@@ -575,14 +480,6 @@ int encoder_trunk_forward(const suave_plan* p, const float* params, const suave_
   const suave_model_t& m = p->model;
   const float* act = w.x;
   int ld_act = p->ldI;
-  if (encoder_chain_ok(p)) {
-    if (int rc = encoder_chain_forward(p, params, w.x, batch->n_rows, w.he, want_ecodes, nullptr, 0, drop_p, nz, batch,
-                                       w.chain_img, s))
-      return rc;
-    *act_out = w.he[m.n_hidden - 1];
-    *ld_out = p->ldH[m.n_hidden - 1];
-    return 0;
-  }
   for (int i = 0; i < m.n_hidden; ++i) {
     const bool embed = i == 0 && !p->embed_host.empty();
     if (embed) {
@@ -675,22 +572,17 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     a.eps_buf = w.eps; a.latent_out = out ? out->latent : nullptr;
     if (int rc = launch_mix_fwd(a, s)) return rc;
   }
-  if (decoder_chain_ok(p)) {
-    if (int rc = decoder_chain_forward(p, params, w.z, V, grad ? w.hd : nullptr, w.y, drop_p, nz, batch, K, w.chain_img, s))
+  act = w.z;
+  ld_act = p->ldD;
+  for (int i = 0; i < nh; ++i) {
+    if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], V, true, drop_p, nz->dec_keep[i], batch,
+                           nz, kStreamDecDrop + i, K, s))
       return rc;
-  } else {
-    act = w.z;
-    ld_act = p->ldD;
-    for (int i = 0; i < nh; ++i) {
-      if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], V, true, drop_p, nz->dec_keep[i], batch,
-                             nz, kStreamDecDrop + i, K, s))
-        return rc;
-      act = w.hd[i];
-      ld_act = p->ldH[i];
-    }
-    if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, V, false, 0.f, nullptr, batch, nz, 0, K, s))
-      return rc;
+    act = w.hd[i];
+    ld_act = p->ldH[i];
   }
+  if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, V, false, 0.f, nullptr, batch, nz, 0, K, s))
+    return rc;
   const LossChunks lch = loss_chunks(p, V);
   const int n_chunks = lch.n;
   const int lgrid = loss_grid(p, V, n_chunks);
@@ -866,14 +758,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   }
   const float* act = w.x;
   int ld_act = p->ldI;
-  const bool enc_chain = encoder_chain_ok(p) && nh + 1 <= kChainMaxLayers;
-  if (enc_chain) {  // trunk + component_logits in one launch; logits land in sel[:, 0:K]
-    if (int rc = encoder_chain_forward(p, params, w.x, B, w.he, grad, w.sel, p->ldK + 2 * p->ldD, drop_p, nz, batch,
-                                       w.chain_img, s))
-      return rc;
-    act = w.he[nh - 1];
-    ld_act = p->ldH[nh - 1];
-  } else if (int rc = encoder_trunk_forward(p, params, batch, nz, drop_p, w, grad, &act, &ld_act, s)) return rc;
+  if (int rc = encoder_trunk_forward(p, params, batch, nz, drop_p, w, grad, &act, &ld_act, s)) return rc;
   // ---- encoder head, selected component only ----
   // Only the logits and the selected component's mu / logvar enter the supervised loss (model.py:1587-1598,
   // losses.py:60-84), so the head is: logits GEMM -> assignment -> stable sort of the rows by component ->
@@ -901,7 +786,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   auto head_geometry = [&](GemmArgs& g) {
     g.perm = w.perm; g.chunk_comp = w.chunk_comp; g.hK = K; g.hD = D; g.hldK = p->ldK; g.hldD = p->ldD;
   };
-  if (!enc_chain) {
+  {
     GemmArgs g = gemm_base();  // logits = h * W[0:K]^T + b[0:K]  -> sel[:, 0:K]
     g.A = hlast_e; g.B = params + m.enc_head.w_off; g.C = w.sel; g.bias = params + m.enc_head.b_off;
     g.M = B; g.N = K; g.K = m.enc_head.n_in; g.lda = ldhe_last; g.ldb = m.enc_head.ld; g.ldc = ldS;
@@ -943,26 +828,21 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   }
   if (int rc = launch_reparam(la, s)) return rc;
   // ---- decoder trunk ----
-  if (decoder_chain_ok(p)) {
-    if (int rc = decoder_chain_forward(p, params, w.z, B, grad ? w.hd : nullptr, w.y, drop_p, nz, batch, 1, w.chain_img, s))
+  act = w.z;
+  ld_act = p->ldD;
+  for (int i = 0; i < nh; ++i) {
+    if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], B, true, drop_p, nz->dec_keep[i], batch,
+                           nz, kStreamDecDrop + i, 1, s, (grad && !gemm_small_rows(B)) ? w.mask_d[i] : nullptr))
       return rc;
-  } else {
-    act = w.z;
-    ld_act = p->ldD;
-    for (int i = 0; i < nh; ++i) {
-      if (int rc = fwd_layer(p, params, m.dec[i], act, ld_act, w.hd[i], p->ldH[i], B, true, drop_p, nz->dec_keep[i], batch,
-                             nz, kStreamDecDrop + i, 1, s, (grad && !gemm_small_rows(B)) ? w.mask_d[i] : nullptr))
-        return rc;
-      act = w.hd[i];
-      ld_act = p->ldH[i];
-    }
-    if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, batch, nz, 0, 1, s))
-      return rc;
+    act = w.hd[i];
+    ld_act = p->ldH[i];
   }
-  // the per-layer launches leave sign bits of the hidden activations for the data gradients; the fused chains do not
+  if (int rc = fwd_layer(p, params, m.y_proj, act, ld_act, w.y, p->ldY, B, false, 0.f, nullptr, batch, nz, 0, 1, s))
+    return rc;
+  // the forward launches leave sign bits of the hidden activations for the data gradients
   static const bool sign_bits = getenv("SUAVE_NO_SIGN_BITS") == nullptr;  // measurement knob: read the activations instead
-  const bool dec_masks = sign_bits && !decoder_chain_ok(p) && !gemm_small_rows(B);
-  const bool enc_masks = sign_bits && !encoder_chain_ok(p) && !gemm_small_rows(B);
+  const bool dec_masks = sign_bits && !gemm_small_rows(B);
+  const bool enc_masks = sign_bits && !gemm_small_rows(B);
   // ---- fused likelihood (+ gradients) ----
   {
     LossArgs a{};
@@ -1505,20 +1385,30 @@ struct DecodeScratch {
   float* hd[SUAVE_MAX_HIDDEN];
   float* y;
   float* wideL;              // [rows, ldL] logits of the wide categorical columns (null: the schema has none)
-  unsigned char* chain_img;  // weight images of the fused decoder chain (null: per-layer path)
+  unsigned char* fused_img;  // weight images of the fused decode kernel (decode.hip); null: the model is outside its shapes
 };
 
-size_t carve_decode(const suave_plan* p, int64_t rows, void* base, DecodeScratch* d) {
+// A decode call takes decode.hip's one-launch kernel when the rows come with component indices (hard assignments:
+// sample, impute's default strategy, the Monte-Carlo draws) and the model is inside the kernel's shapes; dense (soft)
+// assignments, wide categorical columns, other depths / widths and arithmetic modes 0 / 3 keep the per-layer path.
+bool decode_takes_fused(const suave_plan* p, const float* s_dense) {
+  static const bool off = getenv("SUAVE_NO_FUSED_DECODE") != nullptr;  // measurement knob: the per-layer path
+  return !off && s_dense == nullptr && decode_fused_ok(p);
+}
+
+// fused: the call takes decode.hip's one-launch path (decode_takes_fused) and needs the weight images only
+size_t carve_decode(const suave_plan* p, int64_t rows, void* base, DecodeScratch* d, bool fused) {
   Carver c{static_cast<char*>(base)};
   const size_t R = (size_t)std::max<int64_t>(rows, 1);
-  d->z = c.take<float>(R * p->ldD);
-  d->chain_img = nullptr;
-  if (decoder_chain_ok(p)) {  // the hidden activations stay in registers: only the weight images need room
+  d->fused_img = nullptr;
+  if (fused) {  // nothing but the weight images: activations and y_full stay on the chip
+    d->z = nullptr; d->y = nullptr; d->wideL = nullptr;
     for (int i = 0; i < p->model.n_hidden; ++i) d->hd[i] = nullptr;
-    d->chain_img = c.take<unsigned char>(chain_images_bytes(p));
-  } else {
-    for (int i = 0; i < p->model.n_hidden; ++i) d->hd[i] = c.take<float>(R * p->ldH[i]);
+    d->fused_img = c.take<unsigned char>(decode_fused_image_bytes(p));
+    return (c.off + 255) & ~size_t(255);
   }
+  d->z = c.take<float>(R * p->ldD);
+  for (int i = 0; i < p->model.n_hidden; ++i) d->hd[i] = c.take<float>(R * p->ldH[i]);
   d->y = c.take<float>(R * p->ldY);
   d->wideL = p->wide_host.empty() ? nullptr : c.take<float>(R * p->ldL);
   return (c.off + 255) & ~size_t(255);
@@ -1529,7 +1419,6 @@ size_t carve_decode(const suave_plan* p, int64_t rows, void* base, DecodeScratch
 // eval-mode decoder trunk + y_projection on w.z -> w.y: no dropout (model.py:3613-3617, 4397-4419)
 int decoder_trunk_eval(const suave_plan* p, const float* params, const DecodeScratch& w, int B, hipStream_t st) {
   const suave_model_t& m = p->model;
-  if (w.chain_img != nullptr) return decoder_chain_forward(p, params, w.z, B, nullptr, w.y, 0.f, nullptr, nullptr, 1, w.chain_img, st);
   suave_batch_t dummy;
   std::memset(&dummy, 0, sizeof(dummy));
   const float* act = w.z;
@@ -1548,6 +1437,9 @@ int decode_sample_impl(const suave_plan* p, const float* params, const float* z,
                        const float* noise_exp, uint64_t seed, int64_t row_offset, const DecodeScratch& w, hipStream_t st,
                        float* out_num, int32_t ld_num, int16_t* out_codes, int32_t ld_disc, float* y_full_out) {
   const suave_model_t& m = p->model;
+  if (w.fused_img != nullptr)  // decoder trunk -> y_projection -> sample draw in one launch (decode.hip)
+    return launch_decode_fused(p, params, z, component, B, noise_normal, noise_uniform, noise_exp, seed, row_offset,
+                               w.fused_img, out_num, ld_num, out_codes, ld_disc, y_full_out, st);
   SUAVE_CHECK_HIP(hipMemcpy2DAsync(w.z, sizeof(float) * p->ldD, z, sizeof(float) * m.latent_dim,
                                    sizeof(float) * m.latent_dim, B, hipMemcpyDeviceToDevice, st));
   if (int rc = decoder_trunk_eval(p, params, w, B, st)) return rc;
@@ -1600,7 +1492,8 @@ extern "C" int suave_decode_sample(const suave_plan* p, const float* params, con
   SUAVE_REQUIRE(workspace_bytes >= w.total_bytes, "workspace too small (see suave_workspace_bytes)");
   SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
   DecodeScratch d;
-  SUAVE_REQUIRE(carve_decode(p, n, workspace, &d) <= workspace_bytes, "workspace too small (see suave_workspace_bytes)");
+  SUAVE_REQUIRE(carve_decode(p, n, workspace, &d, decode_takes_fused(p, s_dense)) <= workspace_bytes,
+                "workspace too small (see suave_workspace_bytes)");
   return decode_sample_impl(p, params, z, s_dense, component, (int)n, noise_normal, noise_uniform, noise_exp, seed,
                             row_offset, d, static_cast<hipStream_t>(stream), out_num, ld_num, out_codes, ld_disc, y_full_out);
 }
@@ -1634,9 +1527,10 @@ extern "C" int suave_decode_sample_static(const suave_plan* p, const float* para
   SUAVE_CHECK_HIP(hipGetDevice(&dev));
   SUAVE_REQUIRE(dev == p->device, "decode_sample_static: the plan belongs to another device (each GPU has its own scratch)");
   DecodeScratch d;
-  const size_t need = carve_decode(p, n, p->static_scratch, &d);
+  const bool fused = decode_takes_fused(p, s_dense);
+  const size_t need = carve_decode(p, n, p->static_scratch, &d, fused);
   if (need > (size_t)SUAVE_STATIC_SCRATCH_BYTES) {
-    const size_t per_row = carve_decode(p, 4096, nullptr, &d) / 4096 + 1;
+    const size_t per_row = carve_decode(p, 4096, nullptr, &d, fused) / 4096 + 1;
     set_error("decode_sample_static: " + std::to_string((long long)n) + " rows need " + std::to_string(need) +
               " bytes of scratch, the static buffer holds " + std::to_string((size_t)SUAVE_STATIC_SCRATCH_BYTES) +
               " (about " + std::to_string((size_t)SUAVE_STATIC_SCRATCH_BYTES / per_row) + " rows of this model); split the request");
@@ -1667,7 +1561,7 @@ extern "C" int suave_decode_log_px(const suave_plan* p, const float* params, con
   SUAVE_CHECK_HIP(hipMemcpy2DAsync(w.z, sizeof(float) * p->ldD, z, sizeof(float) * m.latent_dim,
                                    sizeof(float) * m.latent_dim, B, hipMemcpyDeviceToDevice, st));
   DecodeScratch d{};
-  d.z = w.z; d.y = w.y; d.wideL = nullptr; d.chain_img = nullptr;
+  d.z = w.z; d.y = w.y; d.wideL = nullptr; d.fused_img = nullptr;
   for (int i = 0; i < m.n_hidden; ++i) d.hd[i] = w.hd[i];
   if (int rc = decoder_trunk_eval(p, params, d, B, st)) return rc;
   if (int rc = launch_expand(p, *batch, w.x, w.cells, st)) return rc;  // the packed cells of the batch rows
@@ -1784,7 +1678,7 @@ extern "C" int suave_decode_params(const suave_plan* p, const float* params, con
   SUAVE_REQUIRE(workspace_bytes >= wfull.total_bytes, "workspace too small (see suave_workspace_bytes)");
   SUAVE_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
   DecodeScratch w;
-  SUAVE_REQUIRE(carve_decode(p, n, workspace, &w) <= workspace_bytes, "workspace too small (see suave_workspace_bytes)");
+  SUAVE_REQUIRE(carve_decode(p, n, workspace, &w, false) <= workspace_bytes, "workspace too small (see suave_workspace_bytes)");
   const int B = (int)n;
   SUAVE_CHECK_HIP(hipMemcpy2DAsync(w.z, sizeof(float) * p->ldD, z, sizeof(float) * m.latent_dim,
                                    sizeof(float) * m.latent_dim, B, hipMemcpyDeviceToDevice, st));

@@ -252,49 +252,13 @@ int launch_head_params(const suave_plan* p, int col_index, const float* params, 
                        const int32_t* comp, int64_t n, float* out, int width, hipStream_t st);
 int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s, const HeadReduceArgs* head = nullptr);  // head: the encoder head's chunk slabs, summed by extra blocks of the same launch
 
-// ---- fused MLP chains (chain.hip) ---------------------------------------------------------------
-constexpr int kChainMaxWidth = 256;                    // widest layer (in or out) the register-chained kernel takes
-constexpr int kChainMaxLayers = SUAVE_MAX_HIDDEN + 1;
-constexpr int kChainRows = 128;                        // rows per block: 4 waves x 32 rows
-enum ChainEpi : int {
-  kChainBias = 0,      // out = acc + bias
-  kChainReluDrop = 1,  // out = dropout(relu(acc + bias))
-  kChainMask = 2,      // out = acc * (mask_src > 0 ? 1 / (1 - p) : 0)     (backward through ReLU + dropout)
-};
-struct ChainLayer {
-  const unsigned char* wimg;  // weight image (filled by launch_chain)
-  const float* bias;          // [N] or null
-  const float* biasp;         // padded copy [32 * ftiles], zeros past N (filled by launch_chain)
-  float* out;                 // [rows, ldo] fp32 or null: the layer's output does not leave the registers
-  int ldo;
-  const float* mask_src;      // kChainMask: forward activation of this layer's output [rows, ld_mask]
-  int ld_mask;
-  const uint8_t* keep;        // kChainReluDrop: injected keep mask [rows, N] or null -> hashed decision (gemm.hip's)
-  int N, K, ktiles, ftiles;   // filled by launch_chain
-  int epi;
-  uint32_t stream_id;         // dropout stream of this layer
-};
-struct ChainArgs {
-  ChainLayer L[kChainMaxLayers];
-  int n_layers;
-  const float* in;            // [rows, ld_in]
-  int ld_in, in_width;
-  int rows;
-  float drop_p;
-  uint64_t seed, step;
-  const int32_t* row_ids;     // table row of each data row (dropout key) or null -> row_begin + data row
-  int64_t row_begin;
-  int row_vdiv;               // > 1: virtual rows (data row, component), keyed as in GemmArgs
-};
-// weight of chain layer l: W [n_out, ld] row-major, or (transposed) the layer is x -> x * W with W [n_in, ld]
-struct ChainWeights {
-  const float* W;
-  int n_out, n_in, ld, transposed;
-};
-bool chain_enabled();                            // SUAVE_CHAIN != 0 and the split arithmetic (mode 3)
-bool chain_layer_ok(int n_out, int n_in);
-size_t chain_image_bytes(int n_out, int n_in);   // bytes of one layer's weight image
-int launch_chain(ChainArgs& a, const ChainWeights* w, unsigned char* images, hipStream_t stream);
+// ---- fused generative decode (decode.hip): decoder trunk -> y_projection -> sample draw in one launch -------------
+bool decode_fused_ok(const suave_plan* p);            // the model is inside the kernel's shapes (and arithmetic mode 4)
+size_t decode_fused_image_bytes(const suave_plan* p); // scratch of a call: the fp16 plane images of the decoder's weights
+int launch_decode_fused(const suave_plan* p, const float* params, const float* z, const int32_t* comp, int64_t n,
+                        const float* nn, const float* nu, const float* ne, uint64_t seed, int64_t row_offset,
+                        unsigned char* images, float* out_num, int ld_num, int16_t* out_codes, int ld_disc, float* y_out,
+                        hipStream_t st);
 
 // First encoder layer, embedded (wide categorical) columns: see embed.hip
 struct EmbedFwdArgs {

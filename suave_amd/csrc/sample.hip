@@ -20,65 +20,15 @@
 // decided again with detmath (about one race in 10^4).  Real and positive VALUES
 // owe the reference 1e-4 and take the hardware path outright; counts stay on
 // detmath (their inverse-CDF walk compares against every partial sum).
-#include <type_traits>
-
-#include "kernels.h"
-#include "detmath.h"
+#include "sample_col.h"
 
 namespace suave {
 
 namespace {
 
-// Decision margins of the two-stage races in k_sample_heads (see there).
-constexpr float kCatMargin = 2e-5f;
-constexpr float kOrdDp = 4e-5f;
-
 __device__ __forceinline__ float philox_u(const Philox& rng, uint32_t a, uint32_t b, uint32_t stream, uint32_t d) {
   return u01(rng(a, b, stream, d).x);
 }
-
-// (rate, uniform, normal) -> Poisson count; mirrors sampling_oracle.poisson_from_noise
-__device__ float poisson_from_noise(float rate, float u, float n) {
-  const bool small = rate < 64.0f;
-  const float r = small ? rate : 1.0f;
-  float p = detm::exp(-r);
-  float cdf = p;
-  float k = 0.f;
-  bool go = small && (u > cdf);
-  for (int i = 1; i <= 512 && go; ++i) {
-    const float fi = (float)i;
-    p = detm::dvd(detm::mul(p, r), fi);
-    cdf = detm::add(cdf, p);
-    k = fi;
-    go = (u > cdf) && ((p > 1e-30f) || (fi <= r));
-  }
-  float big = floorf(detm::add(detm::add(rate, detm::mul(detm::sqrt_rn(rate), n)), 0.5f));
-  big = fmaxf(big, 0.f);
-  return small ? k : big;
-}
-
-struct SampleArgs {
-  const suave_col_t* cols;
-  const int32_t* cls_off;  // [n_cols] offset of the column's classes in noise_exp
-  const float* params;
-  const float* y;          // [n, ldY]
-  const float* s;          // [n, K] dense assignments or null
-  const int32_t* comp;     // [n] component index (used when s == null)
-  int64_t n;
-  int n_cols, n_num, n_disc, K, ldY, Y, total_classes;
-  const float* noise_normal;   // [n, n_cols] or null
-  const float* noise_uniform;  // [n, n_cols] or null
-  const float* noise_exp;      // [n, total_classes] or null
-  uint64_t seed;
-  int64_t row_offset;
-  float* out_num;
-  int ld_num;
-  int16_t* out_codes;
-  int ld_disc;
-  int ldy, ldon, ldoc;  // LDS row strides
-  int head_off, head_len;  // staged weights: the likelihood heads' range of the flat parameter vector (0: not staged)
-  int skip_wide;           // the wide categorical columns are drawn by k_wide_sample from GEMM logits
-};
 
 // STAGED: the 64-row y tile and the outputs go through LDS (coalesced global accesses).  Schemas whose y row
 // does not fit (wide categoricals, BASELINE config #4) run unstaged: lane = row reads y from global memory.
@@ -130,154 +80,24 @@ __global__ __launch_bounds__(kSampleThreads, STAGED ? 2 : 1) void k_sample_heads
     const float* yrow = STAGED ? ytile + lane * a.ldy : a.y + (size_t)r * a.ldY;
     const float* srow = STAGED ? s_s + lane * K : (a.s ? a.s + (size_t)r * K : nullptr);
 
-    // the same dot with fused multiply-adds (values, and the first run of a race)
-    auto dotf = [&](const float* w, const float* yb, int yd) {
-      float acc = 0.f;
-      for (int i = 0; i < yd; ++i) acc = fmaf(w[i], yb[i], acc);
-      if (a.s) {
-        for (int j = 0; j < K; ++j) acc = fmaf(w[yd + j], srow[j], acc);
-      } else {
-        acc += w[yd + kc];
-      }
-      return acc;
-    };
-    // sequential, individually rounded dot of [y ; s] with [w_y ; w_s]
-    auto dot = [&](const float* w, const float* yb, int yd) {
-      float acc = 0.f;
-      for (int i = 0; i < yd; ++i) acc = detm::add(acc, detm::mul(w[i], yb[i]));
-      if (a.s) {
-        for (int j = 0; j < K; ++j) acc = detm::add(acc, detm::mul(w[yd + j], srow[j]));
-      } else {
-        acc = detm::add(acc, w[yd + kc]);
-      }
-      return acc;
-    };
-
     for (int c = wave; c < a.n_cols; c += kSampleWaves) {
       const suave_col_t col = a.cols[c];
       if (a.skip_wide && col_is_wide(col)) continue;
       const float* yb = yrow + col.y_off;
-      const int yd = col.y_dim;
       // (wide categorical columns keep their weights behind the staged range: they are read from global memory)
       // (never form w_s - head_off: an LDS address below the window's start does not survive the cast to a flat pointer)
       const bool in_lds = STAGED && col.w_off >= a.head_off && col.w_off < a.head_off + a.head_len;
       const float* w = in_lds ? w_s + (col.w_off - a.head_off) : a.params + col.w_off;
       const float* w2 = in_lds ? w_s + (max(col.w2_off, a.head_off) - a.head_off) : a.params + max(col.w2_off, 0);
+      float val = 0.f;
+      int code = 0;
+      sample_cell(a, col, c, [&](int i) { return yb[i]; }, w, w2, srow, kc, r, rid, rid_hi, rng, val, code);
       if (col.type <= SUAVE_TYPE_COUNT) {
-        // one Philox block per (row, column): words x, y -> the normal draw, word z -> the uniform draw
-        float nrm, uni = 0.f;
-        uint4 q = make_uint4(0u, 0u, 0u, 0u);
-        if (!a.noise_normal || (col.type == SUAVE_TYPE_COUNT && !a.noise_uniform))
-          q = rng(rid, (uint32_t)c, kStreamSampleNormal, rid_hi);
-        if (a.noise_normal) nrm = a.noise_normal[(size_t)r * a.n_cols + c];
-        else nrm = normal2(q.x, q.y).x;
-        float val;
-        if (col.type == SUAVE_TYPE_COUNT) {
-          if (a.noise_uniform) uni = a.noise_uniform[(size_t)r * a.n_cols + c];
-          else uni = u01(q.z);
-          const float rho = dot(w, yb, yd);
-          const float rate = detm::add(detm::softplus(rho), kEps);
-          val = poisson_from_noise(rate, uni, nrm);
-        } else {
-          // values, not decisions: hardware exp / log / sqrt (within 1e-5 of the oracle; the tests ask for 1e-4)
-          const float am = dotf(w, yb, yd);
-          const float bv = dotf(w2, yb, 0);
-          const float v = softplus_f(bv) + kEps;
-          if (col.type == SUAVE_TYPE_REAL) {  // decoder.py:90-91
-            const float sd = sqrtf(fmaxf(v, kEps));
-            val = fmaf(fmaf(nrm, sd, am), col.scale, col.shift);
-          } else {  // decoder.py:139
-            const float mean = fmaf(am, col.scale, col.shift);
-            const float vs = v * (col.scale * col.scale);
-            const float sd = sqrtf(fmaxf(vs, kEps));
-            val = __expf(fmaf(nrm, sd, mean)) - 1.0f;
-          }
-        }
         if (STAGED) onum[lane * a.ldon + col.x_index] = val;
         else if (valid) a.out_num[(size_t)r * a.ld_num + col.x_index] = val;
       } else {
-        const int C = col.n_classes;
-        const int coff = a.cls_off[c];
-        // classes are visited in order: one Philox block serves four consecutive classes
-        uint4 q4 = make_uint4(0u, 0u, 0u, 0u);
-        auto draw_e = [&](int cl) {
-          if (a.noise_exp) return a.noise_exp[(size_t)r * a.total_classes + coff + cl];
-          if ((cl & 3) == 0) q4 = rng(rid, ((uint32_t)c << 13) | (uint32_t)(cl >> 2), kStreamSampleExp, rid_hi);
-          const uint32_t word = (cl & 3) == 0 ? q4.x : (cl & 3) == 1 ? q4.y : (cl & 3) == 2 ? q4.z : q4.w;
-          return -__logf(u01(word));
-        };
-        int best_i = 0;
-        if (col.type == SUAVE_TYPE_CAT) {  // Gumbel-max == exponential race on softmax(logits)
-          const int ldw = cat_ldw(col, K);
-          // DET = false: fused dots and v_log_f32.  Against the detmath evaluation a score L - log(e) moves by at most
-          // (y_dim + K + 1) roundings of the dot's partial sums plus 2 ulp of the logarithm: far inside
-          // kCatMargin * (1 + |score|) for the few-term, O(1)..O(100) logits of a head.
-          auto race = [&](auto det, float& lead) {
-            constexpr bool DET = decltype(det)::value;
-            q4 = make_uint4(0u, 0u, 0u, 0u);
-            const float e0 = draw_e(0);
-            float best = DET ? detm::sub(0.f, detm::log(e0)) : -__logf(e0);
-            float second = -INFINITY;
-            int bi = 0;
-            for (int cl = 1; cl < C; ++cl) {
-              const float ecl = draw_e(cl);
-              float sc;
-              if (DET) sc = detm::sub(dot(w + (cl - 1) * ldw, yb, yd), detm::log(ecl));
-              else sc = dotf(w + (cl - 1) * ldw, yb, yd) - __logf(ecl);
-              if (sc > best) { second = best; best = sc; bi = cl; }
-              else second = fmaxf(second, sc);
-            }
-            lead = (best - second) - kCatMargin * (1.0f + fabsf(best));
-            return bi;
-          };
-          float lead;
-          best_i = race(std::false_type{}, lead);
-          if (!(lead > 0.f)) best_i = race(std::true_type{}, lead);  // too close (or NaN): the reference arithmetic decides
-        } else {  // ordinal: race on the clipped cumulative-link probabilities
-          // DET = false: hardware softplus / sigmoid / reciprocal.  A clipped probability then differs from detmath's by
-          // at most kOrdDp (C <= 32 accumulated softplus errors through sigmoid' <= 1/4, plus the sigmoid's own), so two
-          // scores p / e compare the same way whenever they are further apart than kOrdDp (1/e_a + 1/e_b) plus the
-          // rounding of the quotients.
-          auto race = [&](auto det, float& lead) {
-            constexpr bool DET = decltype(det)::value;
-            q4 = make_uint4(0u, 0u, 0u, 0u);
-            const float mo = DET ? dot(w2, yb, yd) : dotf(w2, yb, yd);
-            float thr = 0.f, prev = 0.f, best = -1.0f, second = -1.0f, ie_max = 0.f;
-            int bi = 0;
-            for (int cl = 0; cl < C; ++cl) {
-              float pcl;
-              if (cl < C - 1) {
-                float sg;
-                if (DET) {
-                  thr = detm::add(thr, detm::add(detm::softplus(dot(w + cl * K, yb, 0)), kEps));
-                  sg = detm::sigmoid(detm::sub(thr, mo));
-                  pcl = detm::sub(sg, prev);
-                } else {
-                  thr += softplus_f(dotf(w + cl * K, yb, 0)) + kEps;
-                  sg = sigmoid_f(thr - mo);
-                  pcl = sg - prev;
-                }
-                prev = sg;
-              } else {
-                pcl = DET ? detm::sub(1.0f, prev) : 1.0f - prev;
-              }
-              pcl = fminf(fmaxf(pcl, kEps), 1.0f);
-              const float ecl = draw_e(cl);
-              float sc;
-              if (DET) sc = detm::dvd(pcl, ecl);
-              else { const float ie = __frcp_rn(ecl); sc = pcl * ie; ie_max = fmaxf(ie_max, ie); }
-              if (sc > best) { second = best; best = sc; bi = cl; }
-              else second = fmaxf(second, sc);
-            }
-            lead = (best - second) - (2.0f * kOrdDp * ie_max + 4e-6f * best);
-            return bi;
-          };
-          float lead;
-          best_i = race(std::false_type{}, lead);
-          if (!(lead > 0.f)) best_i = race(std::true_type{}, lead);
-        }
-        if (STAGED) ocode[lane * a.ldoc + col.x_index] = best_i;
-        else if (valid) a.out_codes[(size_t)r * a.ld_disc + col.x_index] = (int16_t)best_i;
+        if (STAGED) ocode[lane * a.ldoc + col.x_index] = code;
+        else if (valid) a.out_codes[(size_t)r * a.ld_disc + col.x_index] = (int16_t)code;
       }
     }
     if (STAGED) {

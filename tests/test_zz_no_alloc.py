@@ -84,8 +84,12 @@ def test_static_decode_rejects_oversized_requests_and_accepts_empty():
     comp = torch.zeros((n,), dtype=torch.int32, device=eng.device)
     out_num = torch.empty((n, L.n_num), device=eng.device)
     out_codes = torch.empty((n, L.n_disc), dtype=torch.int16, device=eng.device)
+    # dense (soft) assignments take the per-layer path, whose activations and y_full live in the static buffer
+    s = torch.full((n, 10), 0.1, device=eng.device)
     with pytest.raises(slib.SuaveHipError, match="static buffer holds"):
-        eng.decode_sample_static(z, out_num, out_codes, component=comp)
-    eng.decode_sample_static(z[:14000], out_num, out_codes, component=comp)  # within the limit
+        eng.decode_sample_static(z, out_num, out_codes, assignments=s)
+    eng.decode_sample_static(z[:14000], out_num, out_codes, assignments=s[:14000])  # within the limit
+    # component indices take the fused kernel: the buffer only holds the weight images, any row count goes
+    eng.decode_sample_static(z, out_num, out_codes, component=comp)
     eng.decode_sample_static(z[:0], out_num, out_codes, component=comp)      # empty request
     torch.cuda.synchronize()
