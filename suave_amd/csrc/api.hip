@@ -1278,6 +1278,7 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
     if (hipMemcpy(p->cls_off_dev, cls_off.data(), sizeof(int32_t) * m.n_cols, hipMemcpyHostToDevice) != hipSuccess)
       return dfail("plan_create: hipMemcpy failed");
   }
+  if (decode_plan_init(p) != 0) { suave_plan_destroy(p); return 2; }  // (error text set)
   if (hipMemcpy(p->cols_dev, cols, sizeof(suave_col_t) * m.n_cols, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(p->chunks_dev, p->chunks_host.data(), sizeof(ColChunk) * p->chunks_host.size(), hipMemcpyHostToDevice) != hipSuccess ||
       (!p->chunks_small_host.empty() &&
@@ -1305,6 +1306,7 @@ extern "C" int suave_plan_destroy(suave_plan* p) {
   if (p->chunks_dev) (void)hipFree(p->chunks_dev);
   if (p->enc_map_dev) (void)hipFree(p->enc_map_dev);
   if (p->cls_off_dev) (void)hipFree(p->cls_off_dev);
+  decode_plan_free(p);
   if (p->xsrc_dev) (void)hipFree(p->xsrc_dev);
   if (p->wide_dev) (void)hipFree(p->wide_dev);
   if (p->embed_dev) (void)hipFree(p->embed_dev);

@@ -120,6 +120,14 @@ struct suave_plan {
   std::vector<suave::EmbedCol> embed_host;
   suave::EmbedCol* embed_dev = nullptr;
   int embed_classes_total = 0;
+  // fused decode (decode.hip): the heads' linear maps as one more MFMA layer -- u index of each column's first output
+  // row, and per u index {flat-parameter offset of the weight row, y_off, y_dim}
+  std::vector<int32_t> u_off_host;
+  int32_t* u_off_dev = nullptr;
+  int32_t* u_map_dev = nullptr;
+  int n_u = 0;
+  // ... and the kernel's schedule: output tiles in merged order, the columns each completes, dealt to two waves
+  std::vector<int16_t> dec_step_tile, dec_step_begin, dec_step_mid, dec_col_list;
   void* static_scratch = nullptr;  // this device's copy of api.hip's static scratch array (suave_decode_sample_static)
 };
 

@@ -253,6 +253,8 @@ int launch_head_params(const suave_plan* p, int col_index, const float* params, 
 int launch_reduce(const ReduceArgs& a, int max_elems, hipStream_t s, const HeadReduceArgs* head = nullptr);  // head: the encoder head's chunk slabs, summed by extra blocks of the same launch
 
 // ---- fused generative decode (decode.hip): decoder trunk -> y_projection -> sample draw in one launch -------------
+int decode_plan_init(suave_plan* p);                  // suave_plan_create / _destroy: device tables of the head-row layer
+void decode_plan_free(suave_plan* p);
 bool decode_fused_ok(const suave_plan* p);            // the model is inside the kernel's shapes (and arithmetic mode 4)
 size_t decode_fused_image_bytes(const suave_plan* p); // scratch of a call: the fp16 plane images of the decoder's weights
 int launch_decode_fused(const suave_plan* p, const float* params, const float* z, const int32_t* comp, int64_t n,

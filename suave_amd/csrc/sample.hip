@@ -80,6 +80,7 @@ __global__ __launch_bounds__(kSampleThreads, STAGED ? 2 : 1) void k_sample_heads
     const float* yrow = STAGED ? ytile + lane * a.ldy : a.y + (size_t)r * a.ldY;
     const float* srow = STAGED ? s_s + lane * K : (a.s ? a.s + (size_t)r * K : nullptr);
 
+    NumDraws nd;
     for (int c = wave; c < a.n_cols; c += kSampleWaves) {
       const suave_col_t col = a.cols[c];
       if (a.skip_wide && col_is_wide(col)) continue;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kSampleThreads, STAGED ? 2 : 1) void k_sample_heads
       const float* w2 = in_lds ? w_s + (max(col.w2_off, a.head_off) - a.head_off) : a.params + max(col.w2_off, 0);
       float val = 0.f;
       int code = 0;
-      sample_cell(a, col, c, [&](int i) { return yb[i]; }, w, w2, srow, kc, r, rid, rid_hi, rng, val, code);
+      sample_cell<false, true>(a, col, c, [&](int i) { return yb[i]; }, NoHeadU{}, w, w2, w, srow, kc, r, rid, rid_hi, rng, nd, val, code);
       if (col.type <= SUAVE_TYPE_COUNT) {
         if (STAGED) onum[lane * a.ldon + col.x_index] = val;
         else if (valid) a.out_num[(size_t)r * a.ld_num + col.x_index] = val;

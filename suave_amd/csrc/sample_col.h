@@ -17,6 +17,7 @@ namespace suave {
 // Decision margins of the two-stage races (see sample.hip).
 constexpr float kCatMargin = 2e-5f;
 constexpr float kOrdDp = 4e-5f;
+constexpr float kCountMargin = 1e-4f;
 
 // (rate, uniform, normal) -> Poisson count; mirrors sampling_oracle.poisson_from_noise
 __device__ inline float poisson_from_noise(float rate, float u, float n) {
@@ -61,13 +62,35 @@ struct SampleArgs {
   int skip_wide;           // the wide categorical columns are drawn by k_wide_sample from GEMM logits
 };
 
+// the numeric draws of one (row, pair of numeric columns): see sample_cell
+struct NumDraws {
+  int pair = -1;  // (wave-uniform) the pair these belong to
+  float n0, n1;
+  uint32_t u0, u1;
+};
+
+struct NoHeadU {
+  __device__ __forceinline__ float operator()(int) const { return 0.f; }
+};
+constexpr float kCatMarginU = 5e-5f;  // FAST_U: the logits come from an MFMA product (summation order, fp16 planes)
+
 // One cell: column `c` (descriptor `col`) of table row `r` (generator key rid / rid_hi).  `y(i)` is element i of the
 // column's y slice, `w` / `w2` its two weight blocks (LDS or global), `srow` the row's dense assignments (a.s != null)
 // or `kc` its component.  Numeric columns return the value in `val`, discrete ones the code in `code`.
-template <class YF>
-__device__ __forceinline__ void sample_cell(const SampleArgs& a, const suave_col_t& col, const int c, const YF& y, const float* w,
-                                            const float* w2, const float* srow, const int kc, const int64_t r, const uint32_t rid,
-                                            const uint32_t rid_hi, const Philox& rng, float& val, int& code) {
+// FAST_U (decode.hip, component indices only): the y part of every head's linear map was already multiplied on the
+// matrix cores -- u(j) = w_row_j . y_slice for the column's j-th output row (mean / logits rows / ordinal mean) -- and
+// the staged weights carry per-component tables in place: w2[k] = the sampling standard deviation (real, pos) and
+// w[cl * K + k] = softplus(partition weight) + eps (ordinal).  Values and the FIRST run of a race use them; a race
+// that is too close is decided again from y and the raw weights (`w_part_raw`: the ordinal partition block as stored in
+// the parameter vector) exactly as without FAST_U, so every outcome is the detmath one either way.
+// INJ = false compiles the injected-noise loads out (the caller guarantees the three noise pointers are null): a global
+// load on one side of a branch costs the other side an s_waitcnt vmcnt(0) at the join, and in a loop that also stores
+// its results that wait is the round trip of the previous column's store.
+template <bool FAST_U, bool INJ, class YF, class UF>
+__device__ __forceinline__ void sample_cell(const SampleArgs& a, const suave_col_t& col, const int c, const YF& y, const UF& u,
+                                            const float* w, const float* w2, const float* w_part_raw, const float* srow,
+                                            const int kc, const int64_t r, const uint32_t rid, const uint32_t rid_hi,
+                                            const Philox& rng, NumDraws& nd, float& val, int& code) {
   const int K = a.K;
   const int yd = col.y_dim;
   // the dot of [y ; s] with [w_y ; w_s] with fused multiply-adds (values, and the first run of a race)
@@ -93,42 +116,79 @@ __device__ __forceinline__ void sample_cell(const SampleArgs& a, const suave_col
     return acc;
   };
   if (col.type <= SUAVE_TYPE_COUNT) {
-    // one Philox block per (row, column): words x, y -> the normal draw, word z -> the uniform draw
+    // One Philox block per (row, PAIR of numeric columns 2 j, 2 j + 1 in xnum order): words x, y -> one Box-Muller
+    // transform, whose two normals go to the two columns; words z, w -> their uniform draws.  `nd` keeps the pair's
+    // draws of this lane, so a caller that visits both columns of a pair back to back generates them once.
     float nrm, uni = 0.f;
-    uint4 q = make_uint4(0u, 0u, 0u, 0u);
-    if (!a.noise_normal || (col.type == SUAVE_TYPE_COUNT && !a.noise_uniform))
-      q = rng(rid, (uint32_t)c, kStreamSampleNormal, rid_hi);
-    if (a.noise_normal) nrm = a.noise_normal[(size_t)r * a.n_cols + c];
-    else nrm = normal2(q.x, q.y).x;
+    const int pair = col.x_index >> 1, odd = col.x_index & 1;
+    const bool inj_n = INJ && a.noise_normal != nullptr, inj_u = INJ && a.noise_uniform != nullptr;
+    if ((!inj_n || (col.type == SUAVE_TYPE_COUNT && !inj_u)) && nd.pair != pair) {
+      const uint4 q = rng(rid, (uint32_t)pair, kStreamSampleNormal, rid_hi);
+      const float2 n2 = normal2(q.x, q.y);
+      nd.pair = pair; nd.n0 = n2.x; nd.n1 = n2.y; nd.u0 = q.z; nd.u1 = q.w;
+    }
+    if (inj_n) nrm = a.noise_normal[(size_t)r * a.n_cols + c];
+    else nrm = odd ? nd.n1 : nd.n0;
     if (col.type == SUAVE_TYPE_COUNT) {
-      if (a.noise_uniform) uni = a.noise_uniform[(size_t)r * a.n_cols + c];
-      else uni = u01(q.z);
-      const float rho = dot(w, yd);
-      const float rate = detm::add(detm::softplus(rho), kEps);
-      val = poisson_from_noise(rate, uni, nrm);
+      if (inj_u) uni = a.noise_uniform[(size_t)r * a.n_cols + c];
+      else uni = u01(odd ? nd.u1 : nd.u0);
+      // Two stages, like the races below.  First the CDF walk on hardware exp / log / reciprocal; its partial sums differ
+      // from the detmath ones by the rate's relative error (<= 4e-6: the dot's roundings + exp and log1p of softplus)
+      // times |d cdf / d rate| * rate <= sqrt(rate / 2 pi) <= 3.2 below rate 64, plus the roundings of the walk
+      // itself: under 2e-5.  The walk takes the same decisions as the reference arithmetic as long as u stays further
+      // than kCountMargin from every partial sum it is compared with; otherwise (and for rates near or beyond the
+      // branch point 64) the cell is drawn again with detmath -- the outcome is always the detmath one.
+      const float rate_f = softplus_f(dotf(w, yd)) + kEps;
+      bool sure = rate_f < 63.5f;
+      {
+        float p = __expf(-rate_f), cdf = p, k = 0.f, gap = fabsf(uni - cdf);
+        bool go = sure && (uni > cdf);
+        for (int i = 1; i <= 512 && go; ++i) {
+          const float fi = (float)i;
+          p = p * rate_f * __frcp_rn(fi);
+          cdf += p;
+          k = fi;
+          gap = fminf(gap, fabsf(uni - cdf));
+          go = (uni > cdf) && ((p > 1e-30f) || (fi <= rate_f));
+        }
+        sure = sure && gap > kCountMargin;
+        val = k;
+      }
+      if (!sure) {
+        const float rho = dot(w, yd);
+        const float rate = detm::add(detm::softplus(rho), kEps);
+        val = poisson_from_noise(rate, uni, nrm);
+      }
     } else {
       // values, not decisions: hardware exp / log / sqrt (within 1e-5 of the oracle; the tests ask for 1e-4)
-      const float am = dotf(w, yd);
-      const float bv = dotf(w2, 0);
-      const float v = softplus_f(bv) + kEps;
-      if (col.type == SUAVE_TYPE_REAL) {  // decoder.py:90-91
-        const float sd = sqrtf(fmaxf(v, kEps));
-        val = fmaf(fmaf(nrm, sd, am), col.scale, col.shift);
-      } else {  // decoder.py:139
-        const float mean = fmaf(am, col.scale, col.shift);
-        const float vs = v * (col.scale * col.scale);
-        const float sd = sqrtf(fmaxf(vs, kEps));
-        val = __expf(fmaf(nrm, sd, mean)) - 1.0f;
+      if constexpr (FAST_U) {
+        const float am = u(0) + w[yd + kc];
+        const float sd = w2[kc];
+        if (col.type == SUAVE_TYPE_REAL) val = fmaf(fmaf(nrm, sd, am), col.scale, col.shift);
+        else val = __expf(fmaf(nrm, sd, fmaf(am, col.scale, col.shift))) - 1.0f;
+      } else {
+        const float am = dotf(w, yd);
+        const float bv = dotf(w2, 0);
+        const float v = softplus_f(bv) + kEps;
+        if (col.type == SUAVE_TYPE_REAL) {  // decoder.py:90-91
+          const float sd = sqrtf(fmaxf(v, kEps));
+          val = fmaf(fmaf(nrm, sd, am), col.scale, col.shift);
+        } else {  // decoder.py:139
+          const float mean = fmaf(am, col.scale, col.shift);
+          const float vs = v * (col.scale * col.scale);
+          const float sd = sqrtf(fmaxf(vs, kEps));
+          val = __expf(fmaf(nrm, sd, mean)) - 1.0f;
+        }
       }
     }
     return;
   }
   const int C = col.n_classes;
-  const int coff = a.cls_off[c];
+  const int coff = ((const __attribute__((address_space(4))) int32_t*)(uintptr_t)a.cls_off)[c];  // (plan table: scalar load)
   // classes are visited in order: one Philox block serves four consecutive classes
   uint4 q4 = make_uint4(0u, 0u, 0u, 0u);
   auto draw_e = [&](int cl) {
-    if (a.noise_exp) return a.noise_exp[(size_t)r * a.total_classes + coff + cl];
+    if (INJ && a.noise_exp) return a.noise_exp[(size_t)r * a.total_classes + coff + cl];
     if ((cl & 3) == 0) q4 = rng(rid, ((uint32_t)c << 13) | (uint32_t)(cl >> 2), kStreamSampleExp, rid_hi);
     const uint32_t word = (cl & 3) == 0 ? q4.x : (cl & 3) == 1 ? q4.y : (cl & 3) == 2 ? q4.z : q4.w;
     return -__logf(u01(word));
@@ -150,11 +210,12 @@ __device__ __forceinline__ void sample_cell(const SampleArgs& a, const suave_col
         const float ecl = draw_e(cl);
         float sc;
         if (DET) sc = detm::sub(dot(w + (cl - 1) * ldw, yd), detm::log(ecl));
+        else if constexpr (FAST_U) sc = (u(cl - 1) + w[(cl - 1) * ldw + yd + kc]) - __logf(ecl);
         else sc = dotf(w + (cl - 1) * ldw, yd) - __logf(ecl);
         if (sc > best) { second = best; best = sc; bi = cl; }
         else second = fmaxf(second, sc);
       }
-      lead = (best - second) - kCatMargin * (1.0f + fabsf(best));
+      lead = (best - second) - (FAST_U ? kCatMarginU : kCatMargin) * (1.0f + fabsf(best));
       return bi;
     };
     float lead;
@@ -168,7 +229,10 @@ __device__ __forceinline__ void sample_cell(const SampleArgs& a, const suave_col
     auto race = [&](auto det, float& lead) {
       constexpr bool DET = decltype(det)::value;
       q4 = make_uint4(0u, 0u, 0u, 0u);
-      const float mo = DET ? dot(w2, yd) : dotf(w2, yd);
+      float mo;
+      if (DET) mo = dot(w2, yd);
+      else if constexpr (FAST_U) mo = u(0) + w2[yd + kc];
+      else mo = dotf(w2, yd);
       float thr = 0.f, prev = 0.f, best = -1.0f, second = -1.0f, ie_max = 0.f;
       int bi = 0;
       for (int cl = 0; cl < C; ++cl) {
@@ -176,11 +240,12 @@ __device__ __forceinline__ void sample_cell(const SampleArgs& a, const suave_col
         if (cl < C - 1) {
           float sg;
           if (DET) {
-            thr = detm::add(thr, detm::add(detm::softplus(dot(w + cl * K, 0)), kEps));
+            thr = detm::add(thr, detm::add(detm::softplus(dot(w_part_raw + cl * K, 0)), kEps));
             sg = detm::sigmoid(detm::sub(thr, mo));
             pcl = detm::sub(sg, prev);
           } else {
-            thr += softplus_f(dotf(w + cl * K, 0)) + kEps;
+            if constexpr (FAST_U) thr += w[cl * K + kc];
+            else thr += softplus_f(dotf(w + cl * K, 0)) + kEps;
             sg = sigmoid_f(thr - mo);
             pcl = sg - prev;
           }
