@@ -427,7 +427,7 @@ def main():
     gen = None
     if args.gen_rows > 0 and not wide:
         gen = generation_rates(eng, table, rows, args.gen_rows, device, rank, world, dist, fence, prof,
-                               chunk=args.gen_chunk or 1 << 18, mc_chunk=args.mc_chunk or 1 << 14)
+                               chunk=args.gen_chunk or 1 << 20, mc_chunk=args.mc_chunk or 1 << 15)
     elif args.gen_rows > 0:  # W1024: y_full is 68 KB a row -- smaller chunks, 1M generated rows, the table's rows imputed
         gen = generation_rates(eng, table, rows, min(args.gen_rows, 1 << 20), device, rank, world, dist, fence, prof,
                                chunk=1 << 16, mc_chunk=1 << 11, n_imp_max=1 << 17)

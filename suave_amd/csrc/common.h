@@ -159,6 +159,11 @@ struct Philox {
 // uniform in (0,1): 24 random bits, never 0 or 1
 __device__ __forceinline__ float u01(uint32_t r) { return (static_cast<float>(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
+// ln(x) for NORMAL positive x (no denormal scaling, unlike __logf): v_log_f32 and one multiply
+__device__ __forceinline__ float ln_normal(float x) { return 0.6931471806f * __builtin_amdgcn_logf(x); }
+// Exp(1) draw from a 32-bit word: u01 is in [2^-25, 1), the draw in [3e-8, 17.4)
+__device__ __forceinline__ float exp_draw(uint32_t r) { return -ln_normal(u01(r)); }
+
 // two N(0,1) from two 32-bit words (Box-Muller)
 __device__ __forceinline__ float2 normal2(uint32_t r0, uint32_t r1) {
   float u = u01(r0), v = u01(r1);

@@ -77,6 +77,10 @@ constexpr int kDecMaxNF3 = 16;                // y rows <= 512, head rows (u) <=
 constexpr int kDecMaxSteps = 2 * kDecMaxNF3;  // output tiles of a row tile: y tiles + u tiles
 constexpr int kDecMaxCols = 512;              // schema columns (the schedule travels in the kernel arguments)
 constexpr int kDecWin = 64, kDecWinLd = 65;   // y window: two 32-feature tiles, odd row stride (lane = row reads)
+#ifndef DEC_PREFETCH_ALL
+#define DEC_PREFETCH_ALL 1
+#endif
+constexpr bool kPrefetchAll = DEC_PREFETCH_ALL != 0;  // both halves of the next output tile's fragments under the sampling
 constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
 
 struct DecodeFusedArgs {
@@ -285,6 +289,9 @@ __global__ __launch_bounds__(256, 2) void k_decode_fused(DecodeFusedArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc2[F2][r] = 0.f; acc2x[F2][r] = 0.f; }
 
+    float4 b4n[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b4n[g] = *reinterpret_cast<const float4*>(a.bias[0] + 8 * g + 4 * kh);
     DEC_T(1);
     // ---- layers 1 + 2: one first-layer tile per stage, consumed at once as two k steps of the second layer ----
     for (int F = 0; F < NF1; ++F) {
@@ -294,7 +301,11 @@ __global__ __launch_bounds__(256, 2) void k_decode_fused(DecodeFusedArgs a) {
       const unsigned char* st = ring + (F & 1) * (size_t)a.stageA_bytes + lane_off;
       float4 b4[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const float4*>(a.bias[0] + 32 * F + 8 * g + 4 * kh);
+      for (int g = 0; g < 4; ++g) b4[g] = b4n[g];
+      if (F + 1 < NF1) {  // the next tile's bias: in flight under this iteration's MFMAs
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b4n[g] = *reinterpret_cast<const float4*>(a.bias[0] + 32 * (F + 1) + 8 * g + 4 * kh);
+      }
       f32x16 c, cx;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { c[r] = 0.f; cx[r] = 0.f; }
@@ -386,10 +397,11 @@ __global__ __launch_bounds__(256, 2) void k_decode_fused(DecodeFusedArgs a) {
       }
     };
     load_frags(0, 0);
+    if (!kPrefetchAll) { } else load_frags(0, 1);
     for (int t = 0; t < a.n_steps; ++t) {
       const int st = a.step_tile[t];
       const int kind = st >> 8, T = st & 255;
-      load_frags(t, 1);
+      if (!kPrefetchAll) load_frags(t, 1);
       float4 b4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const float4*>(a.bias[2] + 32 * t + 8 * g + 4 * kh);
@@ -403,7 +415,10 @@ __global__ __launch_bounds__(256, 2) void k_decode_fused(DecodeFusedArgs a) {
         cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfl[kt], h2h[kt], cx, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);  // (the next tile's fragments reuse these registers: keep the loads behind the MFMAs)
-      if (t + 1 < a.n_steps) load_frags(t + 1, 0);  // in flight under this tile's columns
+      if (t + 1 < a.n_steps) {  // in flight under this tile's columns
+        load_frags(t + 1, 0);
+        if (kPrefetchAll) load_frags(t + 1, 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
       DEC_T(5);
       __syncthreads();  // the previous step's columns are drawn: its window half (and, at t == 0, the ring) is free

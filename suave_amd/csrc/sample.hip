@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_wide_sample(WideSampleArgs a) {
         const uint32_t word[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          e[u] = a.noise_exp ? (c0 + u < C ? a.noise_exp[(size_t)r * a.total_classes + coff + c0 + u] : 1.0f) : -__logf(u01(word[u]));
+          e[u] = a.noise_exp ? (c0 + u < C ? a.noise_exp[(size_t)r * a.total_classes + coff + c0 + u] : 1.0f) : exp_draw(word[u]);
       };
       auto wave_argmax = [&](float& b, int& i) {  // first maximum wins
 #pragma unroll
@@ -244,14 +244,17 @@ struct PriorArgs {
   int32_t* comp;
 };
 
+// rows per block iteration of the latent-draw kernels: a thread per row draws the component (all 256 threads busy),
+// then the block writes the rows' z quads
+constexpr int kLatTile = 256;
 __global__ __launch_bounds__(256) void k_prior_latents(PriorArgs a) {
-  __shared__ int k_s[64];
+  __shared__ int k_s[kLatTile];
   const int tid = threadIdx.x;
   const Philox rng(a.seed);
-  const int64_t n_tiles = (a.n + 63) / 64;
+  const int64_t n_tiles = (a.n + kLatTile - 1) / kLatTile;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t r0 = tile * 64;
-    const int nrows = (int)min((int64_t)64, a.n - r0);
+    const int64_t r0 = tile * kLatTile;
+    const int nrows = (int)min((int64_t)kLatTile, a.n - r0);
     __syncthreads();
     if (tid < nrows) {
       const int64_t r = r0 + tid;
@@ -312,14 +315,14 @@ struct CondArgs {
 };
 
 __global__ __launch_bounds__(256) void k_cond_latents(CondArgs a) {
-  __shared__ int k_s[64];
-  __shared__ long long row_s[64];
+  __shared__ int k_s[kLatTile];
+  __shared__ long long row_s[kLatTile];
   const int tid = threadIdx.x;
   const Philox rng(a.seed);
-  const int64_t n_tiles = (a.n + 63) / 64;
+  const int64_t n_tiles = (a.n + kLatTile - 1) / kLatTile;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t r0 = tile * 64;
-    const int nrows = (int)min((int64_t)64, a.n - r0);
+    const int64_t r0 = tile * kLatTile;
+    const int nrows = (int)min((int64_t)kLatTile, a.n - r0);
     __syncthreads();
     if (tid < nrows) {
       const int64_t r = r0 + tid;
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(256) void k_cond_latents(CondArgs a) {
         if (a.e_comp) e = a.e_comp[(size_t)r * a.K + j];
         else {  // one Philox block = the draws of four components
           if ((j & 3) == 0) q4 = rng((uint32_t)gid, (uint32_t)(j >> 2), kStreamCondExp, (uint32_t)(gid >> 32));
-          e = -__logf(u01((j & 3) == 0 ? q4.x : (j & 3) == 1 ? q4.y : (j & 3) == 2 ? q4.z : q4.w));
+          e = exp_draw((j & 3) == 0 ? q4.x : (j & 3) == 1 ? q4.y : (j & 3) == 2 ? q4.z : q4.w);
         }
         const float sc = detm::dvd(pr[j], e);
         if (sc > best) { best = sc; kb = j; }
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(256) void k_posterior_draws(PostDrawArgs a) {
       if (a.e) e = a.e[(size_t)v * a.K + j];
       else {
         if ((j & 3) == 0) q4 = rng((uint32_t)gid, (uint32_t)(j >> 2), kStreamCondExp, (uint32_t)(gid >> 32));
-        e = -__logf(u01((j & 3) == 0 ? q4.x : (j & 3) == 1 ? q4.y : (j & 3) == 2 ? q4.z : q4.w));
+        e = exp_draw((j & 3) == 0 ? q4.x : (j & 3) == 1 ? q4.y : (j & 3) == 2 ? q4.z : q4.w);
       }
       const float sc = detm::sub(row[j], detm::log(e));
       if (sc > best) { best = sc; kb = j; }
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(256) void k_posterior_draws8(PostDrawArgs a) {
         for (int u = 0; u < 4; ++u) {
           const int j = 4 * l8 + u;
           if (j < K) {
-            const float e = a.e ? a.e[(size_t)v * K + j] : -__logf(u01(word[u]));
+            const float e = a.e ? a.e[(size_t)v * K + j] : exp_draw(word[u]);
             const float sc = detm::sub(lg[u], detm::log(e));
             if (sc > best) { best = sc; kb = j; }
           }
@@ -642,7 +645,7 @@ extern "C" int suave_prior_latents(const suave_plan* p, const float* params, con
   a.pm_w_off = p->model.pm_w_off; a.pm_b_off = p->model.pm_b_off;
   a.cdf = cdf; a.u = u; a.eps = eps; a.seed = seed; a.row_offset = row_offset; a.n = n;
   a.K = p->model.n_components; a.D = p->model.latent_dim; a.z = z; a.comp = component;
-  const int grid = (int)std::min<int64_t>((n + 63) / 64, 4096);
+  const int grid = (int)std::min<int64_t>((n + kLatTile - 1) / kLatTile, 4096);
   hipLaunchKernelGGL(k_prior_latents, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
@@ -663,7 +666,7 @@ extern "C" int suave_conditional_latents(const suave_plan* p, const int64_t* cla
   a.train_mu = train_mu; a.train_logvar = train_logvar; a.u_row = u_row; a.e_comp = e_comp; a.eps = eps;
   a.seed = seed; a.row_offset = row_offset; a.n = n; a.K = p->model.n_components; a.D = p->model.latent_dim;
   a.z = z; a.comp = component;
-  const int grid = (int)std::min<int64_t>((n + 63) / 64, 4096);
+  const int grid = (int)std::min<int64_t>((n + kLatTile - 1) / kLatTile, 4096);
   hipLaunchKernelGGL(k_cond_latents, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;

@@ -191,7 +191,7 @@ __device__ __forceinline__ void sample_cell(const SampleArgs& a, const suave_col
     if (INJ && a.noise_exp) return a.noise_exp[(size_t)r * a.total_classes + coff + cl];
     if ((cl & 3) == 0) q4 = rng(rid, ((uint32_t)c << 13) | (uint32_t)(cl >> 2), kStreamSampleExp, rid_hi);
     const uint32_t word = (cl & 3) == 0 ? q4.x : (cl & 3) == 1 ? q4.y : (cl & 3) == 2 ? q4.z : q4.w;
-    return -__logf(u01(word));
+    return exp_draw(word);
   };
   int best_i = 0;
   if (col.type == SUAVE_TYPE_CAT) {  // Gumbel-max == exponential race on softmax(logits)
@@ -203,15 +203,15 @@ __device__ __forceinline__ void sample_cell(const SampleArgs& a, const suave_col
       constexpr bool DET = decltype(det)::value;
       q4 = make_uint4(0u, 0u, 0u, 0u);
       const float e0 = draw_e(0);
-      float best = DET ? detm::sub(0.f, detm::log(e0)) : -__logf(e0);
+      float best = DET ? detm::sub(0.f, detm::log(e0)) : -ln_normal(e0);
       float second = -INFINITY;
       int bi = 0;
       for (int cl = 1; cl < C; ++cl) {
         const float ecl = draw_e(cl);
         float sc;
         if (DET) sc = detm::sub(dot(w + (cl - 1) * ldw, yd), detm::log(ecl));
-        else if constexpr (FAST_U) sc = (u(cl - 1) + w[(cl - 1) * ldw + yd + kc]) - __logf(ecl);
-        else sc = dotf(w + (cl - 1) * ldw, yd) - __logf(ecl);
+        else if constexpr (FAST_U) sc = (u(cl - 1) + w[(cl - 1) * ldw + yd + kc]) - ln_normal(ecl);
+        else sc = dotf(w + (cl - 1) * ldw, yd) - ln_normal(ecl);
         if (sc > best) { second = best; best = sc; bi = cl; }
         else second = fmaxf(second, sc);
       }
