@@ -289,7 +289,9 @@ int suave_decode_sample_static(const suave_plan* plan, const float* params, cons
 /* Posterior draws for the Monte-Carlo predictive: SUAVE._posterior_draws
  * (model.py:3304-3336).  enc_out [n_rows, K+2KD] as written by suave_encode;
  * n_draws = L; e [L, n_rows, K] Exp(1) and eps [L, n_rows, D] N(0,1) inject the
- * draws (NULL: generated from (seed, row_offset + l*n_rows + b)).  Outputs
+ * draws (NULL: generated from (seed, (row_offset + b) * L + l) -- row_offset is the
+ * global index of the first TABLE row, so draw l of a row does not depend on how a
+ * caller chunks or shards the rows).  Outputs
  * z [L*n_rows, D] and component [L*n_rows], draw-major like the reference's
  * `.view(L * batch, ...)` (model.py:3368-3369). */
 int suave_posterior_draws(const suave_plan* plan, const float* enc_out, int64_t n_rows, int32_t n_draws,

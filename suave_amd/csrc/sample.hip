@@ -400,7 +400,8 @@ __global__ __launch_bounds__(256) void k_posterior_draws(PostDrawArgs a) {
   const int E = a.K + 2 * a.K * a.D;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
     const int b = (int)(v % a.B);
-    const uint64_t gid = (uint64_t)(a.row_offset + v);
+    // generator key of (table row row_offset + b, draw l): independent of how the rows are chunked or sharded
+    const uint64_t gid = (uint64_t)(a.row_offset + b) * (uint64_t)a.L + (uint64_t)(v / a.B);
     const float* row = a.enc_out + (size_t)b * E;
     float best = -INFINITY;
     int kb = 0;
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void k_posterior_draws8(PostDrawArgs a) {
     for (int u = 0; u < 4; ++u) lg[u] = 4 * l8 + u < K ? row[4 * l8 + u] : 0.f;
     for (int l = 0; l < a.L; ++l) {
       const int64_t v = (int64_t)l * a.B + b;
-      const uint64_t gid = (uint64_t)(a.row_offset + v);
+      const uint64_t gid = (uint64_t)(a.row_offset + b) * (uint64_t)a.L + (uint64_t)l;
       const uint32_t glo = (uint32_t)gid, ghi = (uint32_t)(gid >> 32);
       float best = -INFINITY;
       int kb = has_k ? 4 * l8 : 0x7FFFFFFF;

@@ -23,9 +23,86 @@ from .types import Schema
 _EPS = 1e-6
 
 
-def fit_norm_stats(X: pd.DataFrame, schema: Schema) -> Dict[str, Dict[str, object]]:
-    """Per-column statistics, as ``standardize`` computes them (data.py:182-264)."""
+def _fit_norm_stats_sharded(X: pd.DataFrame, schema: Schema) -> Dict[str, Dict[str, object]]:
+    """``fit_norm_stats`` of a table whose rows are block-sharded over the ranks of torch.distributed: every rank passes
+    its block and gets the statistics of the whole table -- two passes (mean, then squared deviations) like the numpy
+    / pandas routines the one-process path calls, summed over ranks in float64; category lists are the sorted union."""
 
+    from . import parallel
+
+    schema.require_columns([c for c in X.columns if c in schema])
+    cols = list(schema.feature_names)
+    for column in cols:
+        if column not in X:
+            raise KeyError(f"column '{column}' of the schema is missing from the data")
+    numeric: Dict[str, np.ndarray] = {}
+    first = np.zeros((len(cols), 4), np.float64)  # count, sum, violation flag, any value <= 0
+    for j, column in enumerate(cols):
+        t = schema[column].type
+        if t not in ("real", "pos", "count"):
+            continue
+        v = pd.to_numeric(X[column], errors="coerce").to_numpy(dtype=np.float64)
+        if t == "pos":
+            first[j, 2] = float(np.any(v[~np.isnan(v)] < -1.0 + _EPS))
+            with np.errstate(invalid="ignore", divide="ignore"):
+                v = np.log1p(v)
+            v = np.where(np.isfinite(v), v, np.nan) if t == "pos" else v
+        if t == "count":
+            fin = v[~np.isnan(v)]
+            first[j, 2] = float(np.any(fin < 0))
+            first[j, 3] = float(np.any(fin <= 0))
+        ok = ~np.isnan(v)
+        first[j, 0], first[j, 1] = ok.sum(), v[ok].sum()
+        numeric[column] = v
+    tot = parallel.all_reduce_host(first[:, :2], "sum")
+    flags = parallel.all_reduce_host(first[:, 2:], "max")
+    second = np.zeros(len(cols), np.float64)
+    means = np.zeros(len(cols), np.float64)
+    for j, column in enumerate(cols):
+        if column in numeric and tot[j, 0] > 0:
+            means[j] = tot[j, 1] / tot[j, 0]
+            d = numeric[column] - means[j]
+            second[j] = np.nansum(d * d)
+    ssq = parallel.all_reduce_host(second, "sum")
+    cat_local = {c: X[c].astype("category").cat.categories.tolist() for c in cols if schema[c].type == "cat"}
+    cat_all = parallel.all_gather_objects(cat_local)
+    stats: Dict[str, Dict[str, object]] = {}
+    for j, column in enumerate(cols):
+        spec = schema[column]
+        if spec.type in ("real", "pos"):
+            if spec.type == "pos" and flags[j, 0] > 0:
+                raise ValueError(f"Column '{column}' of type 'pos' must be >= -1 to apply log1p")
+            n = tot[j, 0]
+            mean = float(means[j]) if n > 0 else 0.0
+            std = float(np.sqrt(ssq[j] / n)) if n > 0 else 1.0
+            if not np.isfinite(std) or std < _EPS:
+                std = 1.0
+            if not np.isfinite(mean):
+                mean = 0.0
+            stats[column] = ({"type": "real", "mean": mean, "std": std} if spec.type == "real" else
+                             {"type": "pos", "mean_log": mean, "std_log": std})
+        elif spec.type == "count":
+            if flags[j, 0] > 0:
+                raise ValueError(f"Column '{column}' of type 'count' must be non-negative")
+            stats[column] = {"type": "count", "offset": 1.0 if flags[j, 1] > 0 else 0.0}
+        elif spec.type == "cat":
+            union = set()
+            for part in cat_all:
+                union.update(part[column])
+            stats[column] = {"type": "cat", "categories": sorted(union)}
+        else:
+            n_classes = int(spec.n_classes or 0)
+            cats = X[column].cat.categories.tolist() if isinstance(X[column].dtype, pd.CategoricalDtype) else list(range(n_classes))
+            stats[column] = {"type": "ordinal", "n_classes": n_classes, "categories": cats}
+    return stats
+
+
+def fit_norm_stats(X: pd.DataFrame, schema: Schema, *, sharded: bool = False) -> Dict[str, Dict[str, object]]:
+    """Per-column statistics, as ``standardize`` computes them (data.py:182-264).  ``sharded``: X is this rank's block
+    of a row-sharded table and the statistics are those of the whole table (collective: every rank calls it)."""
+
+    if sharded:
+        return _fit_norm_stats_sharded(X, schema)
     schema.require_columns([c for c in X.columns if c in schema])
     stats: Dict[str, Dict[str, object]] = {}
     for column in schema.feature_names:

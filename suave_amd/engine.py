@@ -24,7 +24,14 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 class PackedTable:
     """The mixed-type table resident in HBM in packed form (include/suave_hip.h)."""
 
-    def __init__(self, xnum, codes, mask, device):
+    row_base = 0        # (class defaults: objects assembled field by field -- bench.py, tests -- are whole tables)
+    _n_global = None
+
+    @property
+    def n_global(self) -> int:
+        return self.n_rows if self._n_global is None else self._n_global
+
+    def __init__(self, xnum, codes, mask, device, *, row_base: int = 0, n_global: Optional[int] = None):
         if isinstance(mask, torch.Tensor):  # already on the device (data.pack_frame_device)
             self.xnum = xnum.to(device=device, dtype=torch.float32).contiguous()
             self.codes = codes.to(device=device, dtype=torch.int16).contiguous()
@@ -39,18 +46,39 @@ class PackedTable:
         self.ld_num = int(self.xnum.shape[1]) if self.xnum.dim() == 2 else 0
         self.ld_disc = int(self.codes.shape[1]) if self.codes.dim() == 2 else 0
         self.ld_mask = int(self.mask.shape[1])
+        # Row-sharded tables (data parallelism, SURVEY.md section 8e): this object holds rows [row_base, row_base +
+        # n_rows) of a table of n_global rows.  Batches address rows by their GLOBAL index -- the index that keys every
+        # in-kernel generator, so a sharded step draws what the one-GPU step draws -- and the array pointers handed to
+        # the library are biased by row_base rows, so that global row g resolves to local row g - row_base.
+        self.row_base = int(row_base)
+        self._n_global = None if n_global is None else int(n_global)
+
+    def local_range(self, start: int, count: int):
+        """[begin, end) (global indices) of the rows of global range [start, start + count) held here."""
+
+        b = max(int(start), self.row_base)
+        e = min(int(start) + int(count), self.row_base + self.n_rows)
+        return (b, max(e, b))
+
+    def local_rows(self, rows: torch.Tensor) -> torch.Tensor:
+        """The entries of ``rows`` (global row ids, any integer dtype) held here, order kept."""
+
+        if self.row_base == 0 and self.n_rows == self.n_global:
+            return rows
+        return rows[(rows >= self.row_base) & (rows < self.row_base + self.n_rows)]
 
     def batch(self, row_begin: int, n_rows: int, row_index: Optional[torch.Tensor] = None) -> BatchT:
         b = BatchT()
-        b.xnum = self.xnum.data_ptr() if self.xnum.numel() else None
-        b.codes = self.codes.data_ptr() if self.codes.numel() else None
-        b.mask = self.mask.data_ptr()
+        rb = self.row_base
+        b.xnum = self.xnum.data_ptr() - 4 * rb * self.ld_num if self.xnum.numel() else None
+        b.codes = self.codes.data_ptr() - 2 * rb * self.ld_disc if self.codes.numel() else None
+        b.mask = self.mask.data_ptr() - rb * self.ld_mask
         b.row_index = _ptr(row_index)
         b.row_begin = int(row_begin)
         b.n_rows = int(n_rows)
         b.ld_num, b.ld_disc, b.ld_mask = self.ld_num, self.ld_disc, self.ld_mask
-        if row_index is None and row_begin + n_rows > self.n_rows:
-            raise ValueError("batch exceeds the table")
+        if row_index is None and n_rows and (row_begin < rb or row_begin + n_rows > rb + self.n_rows):
+            raise ValueError("batch exceeds the table (rows are addressed by their global index)")
         return b
 
 

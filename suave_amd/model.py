@@ -149,6 +149,7 @@ class SUAVE:
         self._step = 0
         self._replay: Optional[DrawReplay] = None
         self._dp: Optional[parallel.DataParallel] = None  # set by fit when torch.distributed has > 1 rank
+        self._sharded = False  # fit(sharded=True): every rank holds its own block of the table's rows
         # which constructor arguments were left to the defaults (model.py:460-473; persisted by save)
         self._auto_configured: Dict[str, bool] = {
             "latent_dim": latent_dim is None, "hidden_dims": hidden_dims is None, "head_hidden_dims": False,
@@ -162,17 +163,67 @@ class SUAVE:
     def _noise_for(self, n_rows: int):
         return None if self._replay is None else self._replay.next_noise(n_rows, self._engine.device)
 
+    def _head_keys(self, rows: torch.Tensor) -> Dict[str, object]:
+        """Keys of the classifier head's dropout masks for one batch: (table rows, seed x batch counter) -- the same on
+        every rank and for every sharding of the batch.  Replayed parity runs keep torch's generator (the reference's)."""
+
+        self._head_batch = getattr(self, "_head_batch", 0) + 1
+        if self._replay is not None:
+            return {}
+        return {"rows": rows, "key": (self.random_state * 1000003 + self._head_batch) & 0x7FFFFFFF}
+
+    @staticmethod
+    def _rows_here(X, row_offset: Optional[int], *others):
+        """(global index of the first row computed here, this rank's rows of X, the same rows of ``others``).
+        ``row_offset`` given: the caller sharded X itself; otherwise X is the same on every rank of
+        torch.distributed and rank r takes ``parallel.shard_rows`` of it (everything on one rank)."""
+
+        g0, n_loc = parallel.generation_span(len(X), row_offset)
+        if row_offset is not None or n_loc == len(X):
+            return (g0, X) + tuple(others)
+        sl = slice(g0, g0 + n_loc)
+        cut = lambda o: None if o is None else (o.iloc[sl] if hasattr(o, "iloc") else np.asarray(o)[sl])
+        return (g0, X.iloc[sl]) + tuple(cut(o) for o in others)
+
+    @staticmethod
+    def _gathered(out, gather: bool, row_offset: Optional[int]):
+        """``gather=True``: every rank gets all ranks' rows, in row order (host objects: meant for modest outputs)."""
+
+        if not gather or row_offset is not None or not parallel.active():
+            return out
+        parts = parallel.all_gather_objects(out)
+        if isinstance(out, pd.DataFrame):
+            return pd.concat(parts)
+        if isinstance(out, torch.Tensor):
+            return torch.cat(parts)
+        if isinstance(out, dict):
+            cat = lambda vs: torch.cat(vs) if isinstance(vs[0], torch.Tensor) else np.concatenate(vs)
+            return {k: cat([p[k] for p in parts]) for k in out}
+        return np.concatenate(parts)
+
     def _record_step_gradient(self) -> None:
         if self._replay is not None:
             self._replay.grads.append(self._engine.grads.clone())
 
-    def _shard(self, rows: torch.Tensor) -> torch.Tensor:
-        """This rank's rows of a global batch (all of them on one GPU)."""
+    def _shard(self, rows: torch.Tensor, table: Optional[PackedTable] = None) -> torch.Tensor:
+        """This rank's rows of a global batch (global row ids): all of them on one GPU; with a replicated table a
+        contiguous share of the batch; with a row-sharded table the batch's rows that live here."""
 
-        return rows if self._dp is None else self._dp.shard(rows)
+        if self._dp is None:
+            return rows
+        if table is not None and self._sharded:
+            return table.local_rows(rows)
+        return self._dp.shard(rows)
 
-    def _span(self, n_rows: int):
-        return (0, n_rows) if self._dp is None else self._dp.span(n_rows)
+    def _range(self, table: PackedTable, start: int, count: int):
+        """This rank's part [begin, end) of the global row range [start, start + count) of ``table``."""
+
+        if self._dp is None:
+            return start, start + count
+        if self._sharded:
+            return table.local_range(start, count)
+        b, e = self._dp.span(count)
+        return start + b, start + e
 
     def _all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         return t if self._dp is None else self._dp.all_reduce(t)
@@ -205,9 +256,9 @@ class SUAVE:
 
         return data_utils.pack_frame_device(X, self.schema, self._norm_stats_per_col, self._engine)
 
-    def _table(self, X: pd.DataFrame) -> PackedTable:
+    def _table(self, X: pd.DataFrame, *, row_base: int = 0, n_global: Optional[int] = None) -> PackedTable:
         xnum, codes, mask = self._pack(X.reset_index(drop=True))
-        return PackedTable(xnum, codes, mask, self._engine.device)
+        return PackedTable(xnum, codes, mask, self._engine.device, row_base=row_base, n_global=n_global)
 
     def _frame(self, out_num: torch.Tensor, out_codes: torch.Tensor) -> pd.DataFrame:
         """Decoded columns (device, row-major) -> DataFrame (``sampling.decoder_outputs_to_frame``)."""
@@ -227,7 +278,8 @@ class SUAVE:
             batch_size: Optional[int] = None, kl_warmup_epochs: Optional[int] = None,
             warmup_epochs: Optional[int] = None, head_epochs: Optional[int] = None,
             finetune_epochs: Optional[int] = None, decoder_refine_epochs: Optional[int] = None,
-            joint_decoder_lr_scale: Optional[float] = None, early_stop_patience: Optional[int] = None) -> "SUAVE":
+            joint_decoder_lr_scale: Optional[float] = None, early_stop_patience: Optional[int] = None,
+            sharded: bool = False) -> "SUAVE":
         """The reference's staged schedule (model.py:883-1380): ELBO warm-up, then for behaviour="supervised" the
         classifier-head phase, joint fine-tuning and decoder refinement.  ``epochs`` overrides the warm-up length.
 
@@ -236,8 +288,15 @@ class SUAVE:
         is sharded by rows over the ranks (``parallel.DataParallel``), gradients are summed over RCCL with the
         decoder-side bucket overlapped with the encoder backward, epoch / validation sums and the EM statistics are
         all-reduced, and every rank ends with bit-identical parameters equal (to fp32 summation order) to those of
-        a one-GPU fit on the whole batches.  The classifier head's own dropout masks (torch's generator) are
-        per-rank and are the one thing that does not reproduce the one-GPU draw."""
+        a one-GPU fit on the whole batches.  The classifier head's dropout masks are keyed by the table row as well
+        (``supervised.ClassificationHead``), so they too are the one-GPU fit's.
+
+        ``sharded=True`` (with more than one rank): ``X`` / ``y`` are THIS RANK'S BLOCK of the table's rows -- rank r's
+        rows follow rank r-1's -- and only that block is packed and kept in HBM (BASELINE config #3: 2 M rows per GPU
+        of a 16 M-row table).  The train / validation split, the normalisation statistics, the per-epoch permutation
+        and every noise key are those of the concatenated table: a global batch is a slice of one permutation of the
+        global train rows, and each rank computes the rows of it that it holds.  Labels (small) are gathered on every
+        rank; so are the posterior caches at the end of the fit (conditional sampling draws from all training rows)."""
 
         if schema is not None:
             self.schema = schema
@@ -262,11 +321,21 @@ class SUAVE:
         lr_scale = float(self.joint_decoder_lr_scale if joint_decoder_lr_scale is None else joint_decoder_lr_scale)
         patience = int(self.early_stop_patience if early_stop_patience is None else early_stop_patience)
         X = X.loc[:, list(self.schema.feature_names)].reset_index(drop=True)
-        n = len(X)
-        rng = np.random.default_rng(self.random_state)
+        self._sharded = bool(sharded) and parallel.active()
+        n_local = len(X)
         y_arr = None if y is None else np.asarray(y).reshape(-1)
-        if y_arr is not None and len(y_arr) != n:
+        if y_arr is not None and len(y_arr) != n_local:
             raise ValueError("X and y must have matching first dimensions")
+        row_lo = 0  # global index of this rank's first row
+        if self._sharded:
+            sizes = [int(v) for v in parallel.all_gather_objects(n_local)]
+            row_lo = int(sum(sizes[: torch.distributed.get_rank()]))
+            n = int(sum(sizes))
+            if y_arr is not None:  # labels are small: every rank holds all of them (split, class weights, conditional draws)
+                y_arr = np.concatenate(parallel.all_gather_objects(y_arr))
+        else:
+            n = n_local
+        rng = np.random.default_rng(self.random_state)
         n_val = int(round(n * self.val_split)) if n > 1 else 0  # split_train_val (data.py:17-104)
         n_val = min(max(n_val, 0), max(n - 1, 0))
         if y_arr is not None and self.stratify and n_val > 0:  # per-class share of the validation rows
@@ -282,8 +351,11 @@ class SUAVE:
             order = rng.permutation(n)
             val_idx, train_idx = np.sort(order[:n_val]), np.sort(order[n_val:])
         n_val = len(val_idx)
-        X_train, X_val = X.iloc[train_idx], X.iloc[val_idx]
-        self._norm_stats_per_col = data_utils.fit_norm_stats(X_train, self.schema)  # statistics from the train split
+        # this rank's rows of the two splits: positions [base, base + count) of the sorted global split
+        tr_b, tr_e = np.searchsorted(train_idx, [row_lo, row_lo + n_local])
+        va_b, va_e = np.searchsorted(val_idx, [row_lo, row_lo + n_local])
+        X_train, X_val = X.iloc[train_idx[tr_b:tr_e] - row_lo], X.iloc[val_idx[va_b:va_e] - row_lo]
+        self._norm_stats_per_col = data_utils.fit_norm_stats(X_train, self.schema, sharded=self._sharded)  # train split
         y_train_t = y_val_t = None
         class_weights = None
         if y_arr is not None:
@@ -301,13 +373,14 @@ class SUAVE:
             y_train_t = torch.from_numpy(self._train_target_indices).to(eng.device)
             if n_val:
                 y_val_t = torch.from_numpy(self._map_targets(y_arr[val_idx])).to(eng.device)
-        train = self._table(X_train)
-        val = self._table(X_val) if n_val else None
+        train = self._table(X_train, row_base=int(tr_b), n_global=len(train_idx))
+        val = self._table(X_val, row_base=int(va_b), n_global=n_val) if n_val else None
         self._dp = parallel.DataParallel.from_environment(self._layout, eng.device)
         if self._dp is not None:
             if self._replay is not None:
                 raise RuntimeError("recorded draws (parity tests) are per batch row and cannot be replayed on sharded batches")
-            self._dp.check_replicated(train.mask, train.xnum, train.codes)
+            if not self._sharded:
+                self._dp.check_replicated(train.mask, train.xnum, train.codes)
         self._gen = torch.Generator(device=eng.device)
         self._gen.manual_seed(self.random_state)
         self._step = 0
@@ -362,7 +435,7 @@ class SUAVE:
         """_run_warmup_phase (model.py:1382-1560)."""
 
         eng = self._engine
-        n_train = train.n_rows
+        n_train = train.n_global
         eff = min(bs, n_train) if n_train else bs
         n_batches = max(1, math.ceil(max(n_train, 1) / max(eff, 1)))
         kl_steps = max(1, kl_epochs * n_batches)  # model.py:1448
@@ -379,7 +452,7 @@ class SUAVE:
                 self._step += 1
                 beta = self.beta * min(warm_step, kl_steps) / kl_steps  # losses.kl_warmup
                 nb = int(idx.numel())
-                self._backward(train, self._shard(idx), beta_scale=beta, tau=tau, global_rows=nb,
+                self._backward(train, self._shard(idx, train), beta_scale=beta, tau=tau, global_rows=nb,
                                noise=self._noise_for(nb))
                 self._record_step_gradient()
                 eng.adam_step(self.learning_rate)
@@ -387,7 +460,7 @@ class SUAVE:
             cnt = max(s[3], 1.0)
             self._train_history.append({"reconstruction": s[0] / cnt, "categorical_kl": s[1] / cnt,
                                         "gaussian_kl": s[2] / cnt})
-            if val is not None and val.n_rows:
+            if val is not None and val.n_global:
                 self._warmup_val_history.append(self._elbo_on_table(val, bs, tau, seed=self.random_state + 1 + epoch))
 
     def _epoch_sums(self) -> np.ndarray:
@@ -407,9 +480,10 @@ class SUAVE:
         """posterior["mean"] of _collect_posterior_statistics (model.py:1669-1741), kept on the device."""
 
         tau = self._inference_tau if self.behaviour == "unsupervised" else None
-        outs = [self._engine.encode(table, s0, min(65536, table.n_rows - s0), temperature=tau)["mean"]
-                for s0 in range(0, table.n_rows, 65536)]
-        return torch.cat(outs) if outs else torch.empty((0, self.latent_dim), device=self._engine.device)
+        lo, hi = table.row_base, table.row_base + table.n_rows
+        outs = [self._engine.encode(table, s0, min(65536, hi - s0), temperature=tau)["mean"] for s0 in range(lo, hi, 65536)]
+        mean = torch.cat(outs) if outs else torch.empty((0, self.latent_dim), device=self._engine.device)
+        return parallel.all_gather_rows(mean) if self._sharded else mean  # row-sharded table: every rank gets all rows
 
     def _train_head_phase(self, latent_mu: torch.Tensor, y_t: torch.Tensor, epochs: int, bs: int) -> None:
         """_train_head_phase (model.py:1743-1864): Adam on the classifier over cached latent means."""
@@ -424,7 +498,7 @@ class SUAVE:
         for _ in range(epochs):
             tot = torch.zeros((), device=latent_mu.device, dtype=torch.float64)
             for idx, _ in self._epoch_batches(n, eff):
-                loss = self._classifier.loss(self._classifier(latent_mu[idx]), y_t[idx])
+                loss = self._classifier.loss(self._classifier(latent_mu[idx], **self._head_keys(idx)), y_t[idx])
                 opt.zero_grad()
                 loss.backward()
                 opt.step()
@@ -438,7 +512,7 @@ class SUAVE:
                            weight: Optional[float]) -> Dict[str, float]:
         """_compute_validation_scores (model.py:2561-2634)."""
 
-        if val is None or val.n_rows == 0:
+        if val is None or val.n_global == 0:
             return {}
         tau = self._inference_tau if self.behaviour == "unsupervised" else self.gumbel_temperature
         self._val_calls = getattr(self, "_val_calls", 0) + 1
@@ -496,7 +570,7 @@ class SUAVE:
         clf_opt = torch.optim.Adam(clf.parameters(), lr=self.learning_rate)
         lrs = {"encoder": self.learning_rate, "decoder": self.learning_rate * lr_scale, "prior": self.learning_rate * lr_scale}
         clf.train()
-        n = train.n_rows
+        n = train.n_global
         eff = min(bs, n) if n else bs
         best_state = self._capture_state()
         best = self._validation_scores(val, bs, y_val_t, weight) or None
@@ -511,14 +585,15 @@ class SUAVE:
                 nb = int(idx.numel())  # the global batch; `loc` are this rank's rows of it
                 self._step += 1
                 nz = self._noise_for(nb)
-                loc, loc64 = self._shard(idx), self._shard(idx64)
+                loc, loc64 = self._shard(idx, train), self._shard(idx64, train)
                 fwd = eng.elbo(train, 0, int(loc.numel()), row_index=loc, beta_scale=self.beta, tau=tau, grad=False,
                                training=True, seed=self.random_state, step=self._step, want=("latent",), noise=nz)
                 latent = fwd["latent"].requires_grad_(True)
+                hk = self._head_keys(loc64)
                 if self._dp is None:
-                    class_loss = clf.loss(clf(latent), y_t[loc64])
+                    class_loss = clf.loss(clf(latent, **hk), y_t[loc64])
                 else:  # the weighted mean over the GLOBAL batch: this rank's terms over the global weight sum
-                    class_loss = clf.loss_terms(clf(latent), y_t[loc64]) / clf.loss_weight(y_t[idx64])
+                    class_loss = clf.loss_terms(clf(latent, **hk), y_t[loc64]) / clf.loss_weight(y_t[idx64])
                 clf_opt.zero_grad()
                 (class_loss * weight).backward()
                 self._backward(train, loc, beta_scale=self.beta, tau=tau, global_rows=nb,
@@ -559,7 +634,7 @@ class SUAVE:
         w = torch.zeros(K, device=eng.device, dtype=torch.float64)
         m1 = torch.zeros((K, D), device=eng.device, dtype=torch.float64)
         m2 = torch.zeros((K, D), device=eng.device, dtype=torch.float64)
-        r0, r1 = self._span(train.n_rows)  # sufficient statistics are sums over rows: shard, then all-reduce
+        r0, r1 = self._range(train, 0, train.n_global)  # sufficient statistics are sums over rows: shard, then all-reduce
         for s0 in range(r0, r1, 65536):
             o = eng.encode(train, s0, min(65536, r1 - s0))
             p = o["probs"].double()
@@ -584,7 +659,7 @@ class SUAVE:
         """_refine_decoder_after_joint (model.py:2088-2445): encoder and classifier frozen."""
 
         self._refine_history = []
-        if self.behaviour != "supervised" or epochs <= 0 or train.n_rows == 0:
+        if self.behaviour != "supervised" or epochs <= 0 or train.n_global == 0:
             return 0
         eng, mode = self._engine, self.decoder_refine_mode
         patience = max(int(patience), 0)
@@ -609,7 +684,7 @@ class SUAVE:
         self._val_calls = getattr(self, "_val_calls", 0)
 
         def val_elbo():
-            if val is None or val.n_rows == 0:
+            if val is None or val.n_global == 0:
                 return {}
             self._val_calls += 1
             return self._elbo_on_table(val, bs, tau, seed=self.random_state + 7919 * self._val_calls)
@@ -631,7 +706,7 @@ class SUAVE:
         best_state = self._capture_state()
         best = decorate(after_em or val_elbo())
         bad, done = 0, 0
-        n = train.n_rows
+        n = train.n_global
         eff = min(bs, n)
         lam = float(self.decoder_refine_prior_lambda)
         for _ in range(epochs):
@@ -639,7 +714,7 @@ class SUAVE:
             for _, idx in self._epoch_batches(n, eff):
                 self._step += 1
                 nb = int(idx.numel())
-                self._backward(train, self._shard(idx), beta_scale=self.beta, tau=tau, global_rows=nb,
+                self._backward(train, self._shard(idx, train), beta_scale=self.beta, tau=tau, global_rows=nb,
                                noise=self._noise_for(nb))
                 if anchors and lam != 0.0:  # + lambda * sum_t mse(prior_t, anchor_t)  (model.py:2338-2346)
                     for slot, snap in anchors:
@@ -667,11 +742,11 @@ class SUAVE:
 
         eng = self._engine
         eng.sums.zero_()
-        eff = min(batch_size, table.n_rows)
-        for i, start in enumerate(range(0, table.n_rows, eff)):
-            nb = min(eff, table.n_rows - start)
-            b, e = self._span(nb)  # noise is keyed by (seed, step, table row): the sums do not depend on the sharding
-            eng.elbo(table, start + b, e - b, beta_scale=self.beta, tau=tau, grad=False, training=False, seed=seed,
+        eff = min(batch_size, table.n_global)
+        for i, start in enumerate(range(0, table.n_global, eff)):
+            nb = min(eff, table.n_global - start)
+            b, e = self._range(table, start, nb)  # noise is keyed by (seed, step, table row): the sums do not depend on the sharding
+            eng.elbo(table, b, e - b, beta_scale=self.beta, tau=tau, grad=False, training=False, seed=seed,
                      step=i, accumulate_sums=True, noise=self._noise_for(nb))
         s = self._epoch_sums()
         n = max(s[3], 1.0)
@@ -687,32 +762,43 @@ class SUAVE:
         tau = self._inference_tau if self.behaviour == "unsupervised" else None
         outs = []
         chunk = max(batch_size, 65536)
-        for start in range(0, train.n_rows, chunk):
-            outs.append(eng.encode(train, start, min(chunk, train.n_rows - start), temperature=tau))
-        if not outs:
+        lo, hi = train.row_base, train.row_base + train.n_rows
+        for start in range(lo, hi, chunk):
+            outs.append(eng.encode(train, start, min(chunk, hi - start), temperature=tau))
+        E = K + 2 * K * D
+        cat = lambda key, width: (torch.cat([o[key] for o in outs]) if outs else
+                                  torch.empty((0, width), device=eng.device))
+        enc, probs, mean, plv = cat("enc_out", E), cat("probs", K), cat("mean", D), cat("logvar", D)
+        if self._sharded:  # a row-sharded fit: conditional sampling draws from ALL training rows -> every rank holds them
+            enc, probs, mean, plv = (parallel.all_gather_rows(t) for t in (enc, probs, mean, plv))
+        if enc.shape[0] == 0:
             self._train_cache = {}
             return
-        enc = torch.cat([o["enc_out"] for o in outs])
         self._train_cache = {
-            "probs": torch.cat([o["probs"] for o in outs]).contiguous(),
+            "probs": probs.contiguous(),
             "mu": enc[:, K:K + K * D].reshape(-1, K, D).contiguous(),
             "logvar": enc[:, K + K * D:].reshape(-1, K, D).contiguous(),
-            "mean": torch.cat([o["mean"] for o in outs]),
-            "post_logvar": torch.cat([o["logvar"] for o in outs]),       # _train_latent_logvar (model.py:2735-2737)
+            "mean": mean,
+            "post_logvar": plv,                                          # _train_latent_logvar (model.py:2735-2737)
             "logits": enc[:, :K].contiguous(),                           # _train_component_logits
         }
 
     # ------------------------------------------------------------------
-    def encode(self, X: pd.DataFrame, *, return_components: bool = False):
+    def encode(self, X: pd.DataFrame, *, return_components: bool = False, row_offset: Optional[int] = None,
+               gather: bool = False):
+        """model.py:4174-4282.  ``row_offset`` / ``gather``: rows sharded over the ranks of torch.distributed as in
+        ``sample`` (no randomness here: sharding only decides which rows this rank computes)."""
+
         self._require_fitted("encode")
+        _, X = self._rows_here(X, row_offset)
         table = self._table(X.loc[:, list(self.schema.feature_names)])
         K, D = self.n_components, self.latent_dim
         if table.n_rows == 0:
             empty = np.empty((0, D), np.float32)
             if not return_components:
-                return empty
-            return {"mean": empty, "assignments": np.empty((0, K), np.float32), "component_mu": empty.copy(),
-                    "component_logvar": empty.copy()}
+                return self._gathered(empty, gather, row_offset)
+            return self._gathered({"mean": empty, "assignments": np.empty((0, K), np.float32), "component_mu": empty.copy(),
+                                   "component_logvar": empty.copy()}, gather, row_offset)
         tau = self._inference_tau if self.behaviour == "unsupervised" else None
         parts: Dict[str, list] = {"mean": [], "assignments": [], "component_mu": [], "component_logvar": []}
         for s0 in range(0, table.n_rows, _ROW_CHUNK):  # the workspace is sized by the chunk, not by the table
@@ -727,8 +813,8 @@ class SUAVE:
             parts["component_mu"].append(enc[:, K:K + K * D].reshape(-1, K, D)[rows, k].cpu().numpy())
             parts["component_logvar"].append(enc[:, K + K * D:].reshape(-1, K, D)[rows, k].cpu().numpy())
         if not return_components:
-            return np.concatenate(parts["mean"])
-        return {key: np.concatenate(v) for key, v in parts.items()}
+            return self._gathered(np.concatenate(parts["mean"]), gather, row_offset)
+        return self._gathered({key: np.concatenate(v) for key, v in parts.items()}, gather, row_offset)
 
     # ------------------------------------------------------------------
     def _prior_cdf(self) -> torch.Tensor:
@@ -742,9 +828,16 @@ class SUAVE:
         return torch.from_numpy(np.cumsum(p).astype(np.float32)).to(self._engine.device)
 
     def sample(self, n_samples: int, conditional: bool = False, y=None, batch_size: Optional[int] = None,
-               seed: Optional[int] = None, _noise: Optional[Dict[str, torch.Tensor]] = None) -> pd.DataFrame:
+               seed: Optional[int] = None, row_offset: Optional[int] = None, gather: bool = False,
+               _noise: Optional[Dict[str, torch.Tensor]] = None) -> pd.DataFrame:
         """Generate rows (model.py:4284-4431).  Row ``i`` depends only on ``(seed, i)``: the output is independent
         of ``batch_size`` and of how rows are sharded over GPUs.
+
+        Multi-GPU (no counterpart in the reference): with torch.distributed initialised on more than one rank, every
+        rank makes the SAME call and generates rows ``parallel.shard_rows(n_samples, rank, world)`` of it, keyed by the
+        global row index -- no collective on the data path; the returned frame is this rank's shard, indexed by the
+        global row numbers (``gather=True``: every rank gets the whole frame).  A caller that shards by itself passes
+        ``row_offset``: its ``n_samples`` rows (and ``y`` entries) are global rows ``row_offset ..``.
 
         ``_noise`` injects the draws instead of generating them from ``seed`` (parity tests): ``u`` [n] and ``eps``
         [n,D] of the prior draw, or ``u_row`` [n], ``e_comp`` [n,K] and ``eps`` of the conditional draw, and
@@ -765,6 +858,9 @@ class SUAVE:
             y_arr = np.asarray(y, dtype=object).reshape(-1)
             if y_arr.shape[0] != n_samples:
                 raise ValueError("y must have length equal to n_samples when conditional=True")
+            if row_offset is None:  # this rank's rows of the request
+                gb, gn = parallel.generation_span(n_samples, None)
+                y_arr = y_arr[gb:gb + gn]
             try:
                 lab = np.asarray([self._class_to_index[v.item() if isinstance(v, np.generic) else v] for v in y_arr],
                                  np.int32)
@@ -782,34 +878,40 @@ class SUAVE:
             class_off_t = torch.from_numpy(class_off).to(eng.device)
         else:
             cdf = self._prior_cdf()
-        asm = data_utils.FrameAssembler(self.schema, self._norm_stats_per_col, eng, n_samples, min(chunk, max(n_samples, 1)))
+        g0, n_here = parallel.generation_span(n_samples, row_offset)
+        asm = data_utils.FrameAssembler(self.schema, self._norm_stats_per_col, eng, n_here, min(chunk, max(n_here, 1)))
         nz = _noise or {}
+        inj0 = 0 if row_offset is not None else g0  # injected draw tensors cover the whole request
 
         def rows_of(key, start, nb):  # the chunk's rows of an injected draw tensor
             t = nz.get(key)
-            return None if t is None else t[start:start + nb].contiguous()
+            return None if t is None else t[inj0 + start:inj0 + start + nb].contiguous()
 
-        for start in range(0, n_samples, chunk):
-            nb = min(chunk, n_samples - start)
+        for start in range(0, n_here, chunk):
+            nb = min(chunk, n_here - start)
             if conditional:
                 z, comp = eng.conditional_latents(labels_t[start:start + nb].contiguous(), class_off_t, class_rows_t,
                                                   self._train_cache["probs"], self._train_cache["mu"],
                                                   self._train_cache["logvar"], u_row=rows_of("u_row", start, nb),
                                                   e_comp=rows_of("e_comp", start, nb), eps=rows_of("eps", start, nb),
-                                                  seed=seed, row_offset=start)
+                                                  seed=seed, row_offset=g0 + start)
             else:
                 z, comp = eng.prior_latents(nb, cdf, u=rows_of("u", start, nb), eps=rows_of("eps", start, nb),
-                                            seed=seed, row_offset=start)
-            onum, ocodes = eng.decode_sample(z, component=comp, seed=seed + 1, row_offset=start,
+                                            seed=seed, row_offset=g0 + start)
+            onum, ocodes = eng.decode_sample(z, component=comp, seed=seed + 1, row_offset=g0 + start,
                                              noise_normal=rows_of("normal", start, nb),
                                              noise_uniform=rows_of("uniform", start, nb),
                                              noise_exp=rows_of("exp", start, nb))
             asm.add(start, onum, ocodes)
-        return asm.frame()
+        out = asm.frame()
+        if g0:
+            out.index = pd.RangeIndex(g0, g0 + n_here)
+        return self._gathered(out, gather, row_offset)
 
     # ------------------------------------------------------------------
     def impute(self, X: pd.DataFrame, *, only_missing: bool = True,
                assignment_strategy: Optional[Literal["soft", "hard", "sample"]] = None, seed: Optional[int] = None,
+               row_offset: Optional[int] = None, gather: bool = False,
                _noise: Optional[Dict[str, torch.Tensor]] = None, _routing: Optional[Dict[str, torch.Tensor]] = None
                ) -> pd.DataFrame:
         """Single-pass imputation at the posterior mean latent (model.py:3512-3692).
@@ -828,6 +930,8 @@ class SUAVE:
             raise ValueError("assignment_strategy must be one of 'soft', 'hard' or 'sample'")
         eng = self._engine
         seed = self.random_state if seed is None else int(seed)
+        n_all = len(X)
+        g0, X = self._rows_here(X, row_offset)  # rows sharded over ranks as in sample(): keys use the global row index
         aligned = X.loc[:, list(self.schema.feature_names)].reset_index(drop=True)
         xnum, codes, mask = self._pack(aligned)
         table = PackedTable(xnum, codes, mask, eng.device)
@@ -839,9 +943,13 @@ class SUAVE:
             if nz.get("assign_exp") is not None:
                 e_all = nz["assign_exp"].to(eng.device)
             else:
+                # torch's generator is not keyed by row: a rank of a sharded call draws the whole request's tensor (the
+                # same on every rank) and keeps its rows; a caller-sharded call (row_offset) gets a stream of its own
                 g = torch.Generator(device=eng.device)
-                g.manual_seed(seed)
-                e_all = torch.empty((table.n_rows, K), device=eng.device).exponential_(generator=g)
+                g.manual_seed(seed if row_offset is None else (seed * 1000003 + int(row_offset)) & 0x7FFFFFFF)
+                e_all = torch.empty((n_all, K), device=eng.device).exponential_(generator=g)
+                if row_offset is None:
+                    e_all = e_all[g0:g0 + table.n_rows]
         rows_of = lambda key, s0, nb: None if nz.get(key) is None else nz[key][s0:s0 + nb].contiguous()
         nums, cods, lat, asg = [], [], [], []
         for s0 in range(0, table.n_rows, _ROW_CHUNK):  # row chunks: the generators are keyed by the table row
@@ -863,7 +971,7 @@ class SUAVE:
             if _routing is not None:
                 lat.append(z)
                 asg.append(assign if assign is not None else torch.nn.functional.one_hot(comp.long(), K).float())
-            onum, ocodes = eng.decode_sample(z, component=comp, assignments=assign, seed=seed + 1, row_offset=s0,
+            onum, ocodes = eng.decode_sample(z, component=comp, assignments=assign, seed=seed + 1, row_offset=g0 + s0,
                                              noise_normal=rows_of("normal", s0, nb), noise_uniform=rows_of("uniform", s0, nb),
                                              noise_exp=rows_of("exp", s0, nb))
             nums.append(onum)
@@ -875,7 +983,7 @@ class SUAVE:
         onum_all = torch.cat(nums) if nums else torch.empty((0, max(lay.n_num, 1)), device=eng.device)
         ocodes_all = torch.cat(cods) if cods else torch.empty((0, max(lay.n_disc, 1)), dtype=torch.int16, device=eng.device)
         recon = self._frame(onum_all, ocodes_all)
-        return self._merge_observed(X, aligned, recon, mask.cpu().numpy(), only_missing)
+        return self._gathered(self._merge_observed(X, aligned, recon, mask.cpu().numpy(), only_missing), gather, row_offset)
 
     # ------------------------------------------------------------------
     def _ensure_classifier(self, what: str) -> None:
@@ -925,9 +1033,11 @@ class SUAVE:
         codes = codes.masked_fill(m[:, disc_idx] == 0, -1)
         return PackedTable(xnum, codes, m, dev)
 
-    def predict_proba(self, X: pd.DataFrame, attr=None, *, mask=None, L: int = 100, seed: Optional[int] = None):
+    def predict_proba(self, X: pd.DataFrame, attr=None, *, mask=None, L: int = 100, seed: Optional[int] = None,
+                      row_offset: Optional[int] = None, gather: bool = False):
         """attr=None: calibrated classifier probabilities (model.py:3797-3815).  Otherwise the Monte-Carlo posterior
-        predictive of a categorical / ordinal attribute (model.py:3816-3867)."""
+        predictive of a categorical / ordinal attribute (model.py:3816-3867); ``row_offset`` / ``gather`` as in
+        ``sample`` (rows sharded over the ranks of torch.distributed, draws keyed by the global row)."""
 
         if attr is None:
             self._ensure_classifier("predict_proba")
@@ -945,24 +1055,24 @@ class SUAVE:
             raise ValueError("L must be a positive integer")
         eng = self._engine
         seed = self.random_state if seed is None else int(seed)
+        g0, X, mask = self._rows_here(X, row_offset, mask)  # this rank's rows; keys use the global row index
         table = self._masked_attr_table(X, attr_name, mask)
         n_classes = int(spec.n_classes)
-        if table.n_rows == 0:
-            return torch.empty((0, n_classes), dtype=torch.float32)
-        outs = []
+        outs = [torch.empty((0, n_classes), dtype=torch.float32)]
         chunk = max(1, (1 << 20) // int(L))  # at most ~1M decoded rows at a time, as predict_confidence_interval
         for s0 in range(0, table.n_rows, chunk):
             nb = min(chunk, table.n_rows - s0)
             enc = eng.encode(table, s0, nb)["enc_out"]
-            z, comp = eng.posterior_draws(enc, int(L), seed=seed, row_offset=s0 * int(L))
+            z, comp = eng.posterior_draws(enc, int(L), seed=seed, row_offset=g0 + s0)
             probs = eng.decode_params(z, j, component=comp)
             probs = probs.view(int(L), nb, -1).mean(dim=0).clamp(min=1e-8)
             outs.append((probs / probs.sum(dim=-1, keepdim=True).clamp_min(1e-8)).cpu())
-        return torch.cat(outs)
+        return self._gathered(torch.cat(outs), gather, row_offset)
 
     def predict_confidence_interval(self, X: pd.DataFrame, attr, *, mask=None, L: int = 1000, ci: float = 0.95,
                                     statistic: Optional[str] = None, return_samples: bool = False,
-                                    seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
+                                    seed: Optional[int] = None, row_offset: Optional[int] = None,
+                                    gather: bool = False) -> Dict[str, torch.Tensor]:
         """Monte-Carlo posterior predictive statistics of a real / pos / count attribute (model.py:3869-4013):
         L draws of (s, z) ~ q(.|x_obs), one draw of the attribute's likelihood per latent draw."""
 
@@ -978,23 +1088,24 @@ class SUAVE:
             raise ValueError("statistic must be one of None, 'mean' or 'median'")
         eng = self._engine
         seed = self.random_state if seed is None else int(seed)
+        g0, X, mask = self._rows_here(X, row_offset, mask)
         table = self._masked_attr_table(X, attr_name, mask)
         B = table.n_rows
         if B == 0:
             empty = torch.empty(0, dtype=torch.float32)
-            out = {"point": empty, "lower": empty, "upper": empty}
+            out = {"point": empty, "lower": empty, "upper": empty, "std": empty}
             if return_samples:
-                out["samples"] = empty.view(0, 0)
-            return out
+                out["samples"] = empty.view(0, 0 if not parallel.active() else int(L))
+            return self._gathered(out, gather, row_offset)
         i_num = [n for n in self.schema.feature_names if self.schema[n].type in ("real", "pos", "count")].index(attr_name)
         samples = torch.empty((int(L), B), dtype=torch.float32, device=eng.device)
         chunk = max(1, (1 << 20) // int(L))  # at most ~1M decoded rows at a time
         for s0 in range(0, B, chunk):
             nb = min(chunk, B - s0)
             enc = eng.encode(table, s0, nb)["enc_out"]
-            z, comp = eng.posterior_draws(enc, int(L), seed=seed, row_offset=s0 * int(L))
-            onum, _ = eng.decode_sample(z, component=comp, seed=seed + 1, row_offset=s0 * int(L))
-            col = onum[:, i_num].view(int(L), nb)
+            z, comp = self._mc_draws(enc, int(L), seed, g0 + s0)
+            onum, _ = eng.decode_sample(z, component=comp, seed=seed + 1, row_offset=(g0 + s0) * int(L))
+            col = onum[:, i_num].view(nb, int(L)).transpose(0, 1)
             if spec.type == "count":  # decoder_outputs_to_frame rounds counts (sampling.py:160-163)
                 col = col.round().clamp(min=0)
             samples[:, s0:s0 + nb] = col
@@ -1008,7 +1119,7 @@ class SUAVE:
         out = {"point": point.cpu(), "lower": lower.cpu(), "upper": upper.cpu(), "std": samples.std(dim=0, unbiased=False).cpu()}
         if return_samples:
             out["samples"] = samples.transpose(0, 1).contiguous().cpu()
-        return out
+        return self._gathered(out, gather, row_offset)
 
     def predict(self, X: pd.DataFrame, attr=None, *, mask=None, L: int = 50, mode: str = "point",
                 seed: Optional[int] = None):
@@ -1051,8 +1162,17 @@ class SUAVE:
         return self
 
     # ------------------------------------------------------------------
-    def impute_mc(self, X: pd.DataFrame, *, L: int = 32, only_missing: bool = True, seed: Optional[int] = None
-                  ) -> pd.DataFrame:
+    def _mc_draws(self, enc: torch.Tensor, L: int, seed: int, first_row: int):
+        """L posterior draws per row of ``enc`` in ROW-major order (row b's draws are rows b L .. b L + L - 1): with
+        it the decode's generator key of (row, draw) is (global row) * L + draw, whatever the chunking or sharding."""
+
+        z, comp = self._engine.posterior_draws(enc, L, seed=seed, row_offset=first_row)
+        nb = int(enc.shape[0])
+        return (z.view(L, nb, -1).transpose(0, 1).reshape(nb * L, -1).contiguous(),
+                comp.view(L, nb).transpose(0, 1).reshape(-1).contiguous())
+
+    def impute_mc(self, X: pd.DataFrame, *, L: int = 32, only_missing: bool = True, seed: Optional[int] = None,
+                  row_offset: Optional[int] = None, gather: bool = False) -> pd.DataFrame:
         """Posterior-predictive Monte-Carlo imputation (BASELINE config #5): ``L`` draws of (s, z) ~ q(.|x_obs) per
         row, every cell decoded per draw; missing numeric cells get the mean over the draws (counts rounded),
         missing categorical / ordinal cells the most frequent drawn level.  This generalises the per-attribute MC
@@ -1064,6 +1184,7 @@ class SUAVE:
         eng = self._engine
         seed = self.random_state if seed is None else int(seed)
         names = list(self.schema.feature_names)
+        g0, X = self._rows_here(X, row_offset)
         aligned = X.loc[:, names].reset_index(drop=True)
         xnum, codes, mask = self._pack(aligned)
         table = PackedTable(xnum, codes, mask, eng.device)
@@ -1076,16 +1197,16 @@ class SUAVE:
         for s0 in range(0, B, chunk):
             nb = min(chunk, B - s0)
             enc = eng.encode(table, s0, nb)["enc_out"]
-            z, comp = eng.posterior_draws(enc, L, seed=seed, row_offset=s0 * L)
-            onum, ocodes = eng.decode_sample(z, component=comp, seed=seed + 1, row_offset=s0 * L)
+            z, comp = self._mc_draws(enc, L, seed, g0 + s0)
+            onum, ocodes = eng.decode_sample(z, component=comp, seed=seed + 1, row_offset=(g0 + s0) * L)
             if lay.n_num:
-                v = onum.view(L, nb, -1)
+                v = onum.view(nb, L, -1)
                 v = torch.where(is_count, v.round().clamp(min=0), v)
-                onum_all[s0:s0 + nb, : lay.n_num] = v.mean(dim=0)
+                onum_all[s0:s0 + nb, : lay.n_num] = v.mean(dim=1)
             if lay.n_disc:
-                ocode_all[s0:s0 + nb, : lay.n_disc] = torch.mode(ocodes.view(L, nb, -1), dim=0).values
+                ocode_all[s0:s0 + nb, : lay.n_disc] = torch.mode(ocodes.view(nb, L, -1), dim=1).values
         recon = self._frame(onum_all, ocode_all)
-        return self._merge_observed(X, aligned, recon, mask.cpu().numpy(), only_missing)
+        return self._gathered(self._merge_observed(X, aligned, recon, mask.cpu().numpy(), only_missing), gather, row_offset)
 
     def _merge_observed(self, X, aligned, recon, mask, only_missing):
         if only_missing:

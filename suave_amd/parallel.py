@@ -34,6 +34,71 @@ def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def active(group=None) -> bool:
+    """torch.distributed is initialised with more than one rank."""
+
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def generation_span(n_rows: int, row_offset: Optional[int], group=None) -> Tuple[int, int]:
+    """Which rows a generation / inference call of the product computes here, as (first global row, count).
+
+    ``row_offset`` given: the caller shards by itself -- its ``n_rows`` rows are global rows ``row_offset ..``.
+    Otherwise, with more than one rank, the request is the same on every rank and rank r takes
+    ``shard_rows(n_rows, r, world)`` of it; on one rank: everything.  Either way every generator is keyed by the
+    GLOBAL row index, so the union of the ranks' outputs is the one-GPU output whatever the number of GPUs."""
+
+    if row_offset is not None:
+        return int(row_offset), int(n_rows)
+    if not active(group):
+        return 0, int(n_rows)
+    b, e = shard_rows(n_rows, dist.get_rank(group), dist.get_world_size(group))
+    return b, e - b
+
+
+def all_gather_objects(obj, group=None) -> list:
+    """One Python object per rank, in rank order (small host data: sizes, label arrays, frames on request)."""
+
+    if not active(group):
+        return [obj]
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, obj, group=group)
+    return out
+
+
+def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Concatenate the ranks' tensors along dim 0 in rank order (row counts may differ)."""
+
+    if not active(group):
+        return t
+    world = dist.get_world_size(group)
+    counts = [int(c) for c in all_gather_objects(int(t.shape[0]), group)]
+    staged = dist.get_backend(group) != "nccl" and t.is_cuda  # gloo rehearsal: through host memory
+    src = t.cpu() if staged else t
+    width = max(counts)
+    pad = src.new_zeros((width,) + tuple(src.shape[1:]))
+    pad[: src.shape[0]] = src
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    out = torch.cat([p[:c] for p, c in zip(parts, counts)])
+    return out.to(t.device) if staged else out
+
+
+def all_reduce_host(values, op: str = "sum", group=None):
+    """float64 numpy array summed / maxed over ranks (normalisation statistics of a sharded table)."""
+
+    import numpy as np
+
+    arr = np.asarray(values, dtype=np.float64)
+    if not active(group):
+        return arr
+    t = torch.from_numpy(arr.copy())
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=group)
+    return t.cpu().numpy()
+
+
 def global_batch_rows(local_rows: int, group=None) -> int:
     """Sum of the ranks' batch rows (ragged last batches differ between ranks)."""
 
@@ -199,15 +264,25 @@ class DataParallel:
                 dist.broadcast(t.data, src=src, group=self.group)
 
     def check_replicated(self, *tensors: torch.Tensor) -> None:
-        """Every rank must have been given the same table: compare a (rows, checksum) pair over ranks."""
+        """Every rank must have been given the same table.  Compared over ranks: the row count and, per tensor, a
+        64-bit order-sensitive hash of its bits (sum of word_i * (2654435761 i + 1) modulo 2^64, one device reduction
+        each) -- tables with the same rows in another order, or with equal column sums, do not pass."""
 
-        sig = torch.tensor([float(sum(int(t.shape[0]) for t in tensors))] +
-                           [float(t.double().sum().item()) if t.numel() else 0.0 for t in tensors], dtype=torch.float64)
-        lo, hi = sig.clone(), sig.clone()
+        sig = [sum(int(t.shape[0]) for t in tensors)]
+        for t in tensors:
+            if t.numel() == 0:
+                sig.append(0)
+                continue
+            flat = t.contiguous().view(-1)
+            words = flat.view(torch.int32) if flat.element_size() == 4 else flat.to(torch.int32)
+            pos = torch.arange(words.numel(), device=words.device, dtype=torch.int64)
+            sig.append(int(((pos * 2654435761 + 1) * words.to(torch.int64)).sum().item()))  # int64 wraps: modulo 2^64
+        sig_t = torch.tensor(sig, dtype=torch.int64)
+        lo, hi = sig_t.clone(), sig_t.clone()
         if not self.host_staged:
             lo, hi = lo.to(self.device), hi.to(self.device)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
         if not torch.equal(lo.cpu(), hi.cpu()):
-            raise ValueError("data-parallel fit needs the SAME X / y on every rank (rows are sharded inside fit); "
-                             "the ranks' tables differ")
+            raise ValueError("data-parallel fit needs the SAME X / y on every rank (rows are sharded inside fit; pass "
+                             "sharded=True when every rank holds its own block of rows); the ranks' tables differ")

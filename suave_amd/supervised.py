@@ -23,6 +23,40 @@ from torch import nn
 from torch.nn import functional as F
 
 
+class RowKeyedDropout(nn.Module):
+    """nn.Dropout whose keep decisions can be keyed by the TABLE ROW of each batch row instead of torch's generator:
+    a stateless hash of (key, layer, row id, feature).  With keys a row draws the same mask on whichever rank
+    computes it, so a data-parallel fit reproduces the one-GPU fit's head dropout (the reference has one device and
+    one generator stream: suave/modules/heads.py:47-49).  Without keys (``ctx`` None) it is ``F.dropout``."""
+
+    def __init__(self, p: float, layer: int = 0) -> None:
+        super().__init__()
+        self.p, self.layer = float(p), int(layer)
+        self.ctx = None  # (row ids int64 [B], key int), set around a forward by ClassificationHead
+
+    @staticmethod
+    def _h32(x: torch.Tensor) -> torch.Tensor:  # lowbias32 on int64 lanes holding uint32 values
+        m = 0xFFFFFFFF
+        x = x ^ (x >> 16)
+        x = (x * 0x7FEB352D) & m
+        x = x ^ (x >> 15)
+        x = (x * 0x846CA68B) & m
+        return x ^ (x >> 16)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.training or self.p <= 0.0:
+            return x
+        if self.ctx is None:
+            return F.dropout(x, self.p, True)
+        rows, key = self.ctx
+        m = 0xFFFFFFFF
+        r = self._h32((rows.to(torch.int64) * 0x9E3779B1 + (int(key) & m) + self.layer * 0x85EBCA77) & m)
+        cols = (torch.arange(x.shape[-1], device=x.device, dtype=torch.int64) * 0x632BE5AB + 0x165667B1) & m
+        h = self._h32(r.unsqueeze(-1) ^ cols.unsqueeze(0))
+        keep = ((h >> 8).to(torch.float32) * (1.0 / 16777216.0)) >= self.p
+        return x * keep.to(x.dtype) * (1.0 / (1.0 - self.p))
+
+
 class ClassificationHead(nn.Module):
     """heads.py:12-91: optional ``Linear -> ReLU -> Dropout`` stack, then ``linear``; weighted cross-entropy.
     Parameter names match the reference ``state_dict`` (``hidden_layers.<i>.*``, ``linear.*``, ``class_weight``)."""
@@ -42,10 +76,10 @@ class ClassificationHead(nn.Module):
         for h in hidden_dims:
             layers += [nn.Linear(prev, h), nn.ReLU()]
             if dropout:
-                layers.append(nn.Dropout(float(dropout)))
+                layers.append(RowKeyedDropout(float(dropout), layer=len(layers)))
             prev = h
         self.hidden_layers = nn.Sequential(*layers) if layers else None
-        self._final_dropout = nn.Dropout(float(dropout)) if dropout and not hidden_dims else None
+        self._final_dropout = RowKeyedDropout(float(dropout)) if dropout and not hidden_dims else None
         self.linear = nn.Linear(prev, n_classes)
         if class_weight is not None:
             w = torch.as_tensor(np.asarray(class_weight), dtype=torch.float32)
@@ -57,12 +91,22 @@ class ClassificationHead(nn.Module):
             self.register_buffer("class_weight", torch.ones(n_classes))
             self._use_weight = False
 
-    def forward(self, latents: torch.Tensor) -> torch.Tensor:
-        if self.hidden_layers is not None:
-            latents = self.hidden_layers(latents)
-        elif self._final_dropout is not None:
-            latents = self._final_dropout(latents)
-        return self.linear(latents)
+    def forward(self, latents: torch.Tensor, rows: Optional[torch.Tensor] = None, key: int = 0) -> torch.Tensor:
+        """``rows`` (table row id of each batch row) + ``key`` (seed / step) key the dropout masks by row; without
+        them the masks come from torch's generator as in the reference."""
+
+        drops = [mod for mod in self.modules() if isinstance(mod, RowKeyedDropout)]
+        for d in drops:
+            d.ctx = None if rows is None else (rows, key)
+        try:
+            if self.hidden_layers is not None:
+                latents = self.hidden_layers(latents)
+            elif self._final_dropout is not None:
+                latents = self._final_dropout(latents)
+            return self.linear(latents)
+        finally:
+            for d in drops:
+                d.ctx = None
 
     def loss(self, logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
         return F.cross_entropy(logits, targets, weight=self.class_weight if self._use_weight else None)

@@ -47,7 +47,8 @@ def _run(case, world, tmp_path, backend=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["unsup_warmup", "sup_warmup", "sup_schedule"])
+@pytest.mark.parametrize("case", ["unsup_warmup", "sup_warmup", "sup_schedule", "sup_schedule_drop",
+                                  "sup_schedule_sharded", "unsup_sharded", "s64_sharded"])
 def test_two_rank_fit_matches_one_rank(case, tmp_path):
     two = _run(case, 2, tmp_path)
     one = _run(case, 1, tmp_path)[0]
@@ -77,3 +78,24 @@ def test_rccl_overlap_plumbing_on_one_rank(tmp_path):
     rccl = _run("sup_schedule", 1, tmp_path, backend="nccl")[0]
     for key in one:
         assert np.max(np.abs(one[key].astype(np.float64) - rccl[key])) <= 1e-5, key
+
+
+@pytest.mark.gpu
+def test_two_rank_generation_is_the_one_rank_output_sharded_by_rows(tmp_path):
+    """SUAVE.sample / impute / impute_mc / encode / predict_proba(attr) under torch.distributed: every rank computes
+    its ``shard_rows`` share keyed by the GLOBAL row index, with no collective.  The ranks' shards are disjoint, cover
+    every row, and their union is the one-rank output: bit for bit on the discrete columns (and on everything else
+    the kernels produce: same kernels, same keys, same inputs)."""
+
+    two = _run("generation", 2, tmp_path)
+    one = _run("generation", 1, tmp_path)[0]
+    assert np.array_equal(two[0]["params"], two[1]["params"])
+    for key in [k for k in one if k.startswith("gen_")]:
+        a, b, ref = two[0][key], two[1][key], one[key]
+        if key == "gen_proba":  # gathered on request: every rank holds all rows
+            assert np.array_equal(a, b) and np.array_equal(a, ref), key
+            continue
+        have_a, have_b = ~np.isnan(a).all(axis=1), ~np.isnan(b).all(axis=1)
+        assert not (have_a & have_b).any() and (have_a | have_b).all(), f"{key}: shards overlap or leave rows out"
+        union = np.where(have_a[:, None], a, b)
+        assert np.array_equal(union, ref, equal_nan=True), key

@@ -174,3 +174,63 @@ def test_data_parallel_host_logic():
     assert np.array_equal(res[0][3], res[1][3]) and np.allclose(res[0][3], want, rtol=1e-5, atol=1e-7)
     assert np.array_equal(res[0][4], res[1][4])
     assert res[0][5] and res[1][5]
+
+
+def _shard_worker(rank, world, port, out_q):
+    """Row-sharded tables and generation spans (round 3): the host logic of fit(sharded=True) and of the rank-aware
+    sample / impute family."""
+
+    import pandas as pd
+
+    from suave_amd import data as data_utils
+    from suave_amd.types import Schema
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    # generation spans: same request on every rank -> disjoint shards keyed by the global row; explicit offsets pass through
+    res["span"] = parallel.generation_span(1001, None)
+    res["span_explicit"] = parallel.generation_span(10, 500)
+    # all_gather_rows with different row counts per rank
+    t = torch.arange(3 + rank, dtype=torch.float32).unsqueeze(1) + 100 * rank
+    res["gathered"] = parallel.all_gather_rows(t).numpy()
+    # normalisation statistics of a table whose rows are block-sharded over the ranks == those of the whole table
+    rng = np.random.default_rng(0)
+    n = 400
+    X = pd.DataFrame({"a": rng.normal(5, 2, n), "b": np.exp(rng.normal(0, 1, n)), "c": rng.poisson(3, n).astype(float),
+                      "d": rng.integers(0, 3, n), "e": rng.integers(0, 4, n)})
+    X.loc[rng.random(n) < 0.1, "a"] = np.nan
+    X.loc[:, "d"] = X["d"].where(X.index >= 150, 0)  # rank 0's block sees a single category
+    sch = Schema({"a": {"type": "real"}, "b": {"type": "pos"}, "c": {"type": "count"},
+                  "d": {"type": "cat", "n_classes": 3}, "e": {"type": "ordinal", "n_classes": 4}})
+    cut = [0, 150, n]
+    res["stats"] = data_utils.fit_norm_stats(X.iloc[cut[rank]:cut[rank + 1]], sch, sharded=True)
+    res["stats_whole"] = data_utils.fit_norm_stats(X, sch)
+    out_q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_host_logic():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0]["span"] == (0, 501) and got[1]["span"] == (501, 500)
+    assert got[0]["span_explicit"] == got[1]["span_explicit"] == (500, 10)
+    want = np.concatenate([np.arange(3.0), 100 + np.arange(4.0)])[:, None]
+    assert np.array_equal(got[0]["gathered"], want) and np.array_equal(got[1]["gathered"], want)
+    for r in range(world):
+        whole, part = got[r]["stats_whole"], got[r]["stats"]
+        for col in whole:
+            for key, v in whole[col].items():
+                if isinstance(v, float):
+                    assert abs(part[col][key] - v) <= 1e-12 * max(1.0, abs(v)), (col, key)
+                else:
+                    assert part[col][key] == v, (col, key)
