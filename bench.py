@@ -215,7 +215,7 @@ def generation_rates(eng, table, rows, gen_rows, device, rank, world, dist, fenc
     lv = torch.empty((n_cache, K, D), device=device)
     for s0 in range(0, n_cache, chunk):
         nb = min(chunk, n_cache - s0)
-        o = eng.encode(table, s0, nb)
+        o = eng.encode(table, table.row_base + s0, nb)
         probs[s0:s0 + nb] = o["probs"]
         mu[s0:s0 + nb] = o["enc_out"][:, K:K + K * D].view(nb, K, D)
         lv[s0:s0 + nb] = o["enc_out"][:, K + K * D:].view(nb, K, D)
@@ -277,9 +277,7 @@ def generation_rates(eng, table, rows, gen_rows, device, rank, world, dist, fenc
     def run_impute():  # reference-exact single pass at the posterior-mean latent, hard assignment (model.py:3627-3651)
         for s0 in range(0, n_imp, chunk):
             nb = min(chunk, n_imp - s0)
-            o = eng.encode(table, s0, nb)
-            comp = o["probs"].argmax(dim=1).to(torch.int32)
-            z = o["enc_out"][:, K:K + K * D].view(nb, K, D)[torch.arange(nb, device=device), comp.long()].contiguous()
+            z, comp = eng.encode_hard(table, table.row_base + s0, nb)
             eng.decode_sample(z, component=comp, seed=9, row_offset=rank * n_imp + s0)
 
     timed(run_impute, n_imp, "impute_single_pass")
@@ -288,8 +286,8 @@ def generation_rates(eng, table, rows, gen_rows, device, rank, world, dist, fenc
     def run_impute_mc():  # posterior-predictive MC, 32 draws per row, every cell decoded (model.py:3304-3421 generalised)
         for s0 in range(0, n_imp, mc_chunk):
             nb = min(mc_chunk, n_imp - s0)
-            o = eng.encode(table, s0, nb)
-            z, comp = eng.posterior_draws(o["enc_out"], Ldraws, seed=10, row_offset=(rank * n_imp + s0) * Ldraws)
+            o = eng.encode(table, table.row_base + s0, nb)
+            z, comp = eng.posterior_draws(o["enc_out"], Ldraws, seed=10, row_offset=rank * n_imp + s0, row_major=True)
             eng.decode_sample(z, component=comp, seed=11, row_offset=(rank * n_imp + s0) * Ldraws)
 
     timed(run_impute_mc, n_imp, "impute_mc32")
@@ -359,9 +357,11 @@ def main():
     rows = args.rows or (1_000_000 if world == 1 else 2_000_000)
     B = min(args.batch, rows)
     xnum, codes, mask = synth_table_device(layout, rows, device, seed=20201021 + rank)
-    table = PackedTable.__new__(PackedTable)
-    table.xnum, table.codes, table.mask = xnum, codes, mask
-    table.n_rows, table.ld_num, table.ld_disc, table.ld_mask = rows, xnum.shape[1], codes.shape[1], mask.shape[1]
+    # This rank's block of the table's rows.  N > 1 is the product's row-sharded data path (SUAVE.fit(sharded=True),
+    # suave_amd/parallel.py): the table has rows * N rows of which this rank holds [rank * rows, (rank + 1) * rows);
+    # a global batch is a slice of one permutation of ALL row ids (same generator on every rank) and each rank
+    # computes the rows of it that it holds, addressed -- and keyed, for every in-kernel generator -- by global row id.
+    table = PackedTable(xnum, codes, mask, device, row_base=rank * rows, n_global=rows * world)
 
     # N > 1: the decoder-side gradient bucket is all-reduced behind the library's event while the encoder backward
     # still runs, the encoder bucket after it (suave_amd/parallel.py DataParallel, suave_elbo_backward_overlap)
@@ -370,15 +370,30 @@ def main():
     warmup_steps = max(1, 10 * n_batches)  # kl_warmup_epochs = 10 (model.py:59, :1448)
     state = {"perm": None, "step": 0}
     lr = 1e-3
+    gen_perm = torch.Generator(device=device)
+    gen_perm.manual_seed(4321)
+
+    def sharded_batches():  # endless: epoch after epoch of (global batch rows, this rank's rows of the batch)
+        while True:
+            perm = torch.randperm(rows * world, device=device, generator=gen_perm, dtype=torch.int64)
+            for b, e, loc in parallel.sharded_epoch_batches(perm, B * world, table.row_base, rows):
+                if e - b == B * world:  # (full batches only: the timed steps all do the same work)
+                    yield e - b, loc
+
+    batch_iter = sharded_batches() if world > 1 else None
 
     def one_step():
-        i = state["step"] % n_batches
-        if i == 0:  # per-epoch permutation of this rank's shard (model.py:1465)
-            state["perm"] = torch.randperm(rows, device=device, dtype=torch.int32)
         state["step"] += 1
-        idx = state["perm"][i * B:(i + 1) * B]
         beta = 1.5 * min(state["step"], warmup_steps) / warmup_steps  # losses.kl_warmup
-        eng.elbo(table, 0, B, row_index=idx, beta_scale=beta, tau=1.0, grad=True, global_rows=B * world,
+        if world > 1:
+            nb, idx = next(batch_iter)
+        else:
+            i = (state["step"] - 1) % n_batches
+            if i == 0:  # per-epoch permutation (model.py:1465)
+                state["perm"] = torch.randperm(rows, device=device, dtype=torch.int32)
+            idx = state["perm"][i * B:(i + 1) * B]
+            nb = B
+        eng.elbo(table, 0, int(idx.numel()), row_index=idx, beta_scale=beta, tau=1.0, grad=True, global_rows=nb,
                  seed=1234, step=state["step"], accumulate_sums=True, ready_event=dp.ready if dp else None)
         if dp is not None:  # RCCL sum of the flat gradient (each rank already scaled by 1/global_rows)
             dp.reduce_gradients(eng.grads)

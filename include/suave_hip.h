@@ -233,6 +233,15 @@ int suave_encode(const suave_plan* plan, const float* params, const suave_batch_
                  float inv_temperature, void* workspace, size_t workspace_bytes, void* stream,
                  float* enc_out, float* post_mean, float* post_logvar, float* probs);
 
+/* Encoder pass + the hard assignment of SUAVE.impute / SUAVE.encode(return_components=True)
+ * (model.py:3627-3634, :4254-4258): component [B] = argmax_k softmax(logits * inv_temperature)
+ * (first maximum) and z [B,D] = mu of that component -- the (latent, assignment) pair the
+ * decoder receives under assignment_strategy="hard", without writing the [B, K+2KD] head
+ * output to HBM for the caller to gather from. */
+int suave_encode_hard(const suave_plan* plan, const float* params, const suave_batch_t* batch,
+                      float inv_temperature, void* workspace, size_t workspace_bytes, void* stream,
+                      int32_t* component, float* z);
+
 /* Prior latent draw: sampling.sample_prepared_mixture_latents (sampling.py:38-56).
  * cdf [K] cumulative softmax(prior_logits); u [n] uniform and eps [n,D] normal
  * draws, or NULL to generate from (seed, row_offset + i). */

@@ -1356,9 +1356,10 @@ extern "C" int suave_elbo_backward_overlap(const suave_plan* plan, const float* 
                    static_cast<hipStream_t>(stream), out, grads, dlatent, static_cast<hipEvent_t>(decoder_ready_event));
 }
 
-extern "C" int suave_encode(const suave_plan* p, const float* params, const suave_batch_t* batch,
-                            float inv_temperature, void* workspace, size_t workspace_bytes, void* stream,
-                            float* enc_out, float* post_mean, float* post_logvar, float* probs) {
+namespace {
+int encode_impl(const suave_plan* p, const float* params, const suave_batch_t* batch, float inv_temperature, void* workspace,
+                size_t workspace_bytes, void* stream, float* enc_out, float* post_mean, float* post_logvar, float* probs,
+                int32_t* hard_comp, float* hard_mu) {
   suave::drop_stale_hip_error();
   SUAVE_REQUIRE(p != nullptr && params != nullptr, "plan/params is null");
   if (int rc = check_batch(p, batch)) return rc;
@@ -1376,7 +1377,22 @@ extern "C" int suave_encode(const suave_plan* p, const float* params, const suav
   if (int rc = fwd_layer(p, params, m.enc_head, act, ld_act, w.encout, p->ldE, B, false, 0.f, nullptr, batch, nullptr, 0, 1, s))
     return rc;
   return launch_posterior_stats(w.encout, p->ldE, m.n_components, m.latent_dim, B, inv_temperature, enc_out, post_mean,
-                                post_logvar, probs, s);
+                                post_logvar, probs, s, hard_comp, hard_mu);
+}
+}  // namespace
+
+extern "C" int suave_encode(const suave_plan* p, const float* params, const suave_batch_t* batch,
+                            float inv_temperature, void* workspace, size_t workspace_bytes, void* stream,
+                            float* enc_out, float* post_mean, float* post_logvar, float* probs) {
+  return encode_impl(p, params, batch, inv_temperature, workspace, workspace_bytes, stream, enc_out, post_mean, post_logvar,
+                     probs, nullptr, nullptr);
+}
+
+extern "C" int suave_encode_hard(const suave_plan* p, const float* params, const suave_batch_t* batch,
+                                 float inv_temperature, void* workspace, size_t workspace_bytes, void* stream,
+                                 int32_t* component, float* z) {
+  return encode_impl(p, params, batch, inv_temperature, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr, nullptr,
+                     component, z);
 }
 
 namespace {

@@ -243,7 +243,8 @@ int reparam_grid(int n_rows);
 int launch_reparam(const LatentFwdArgs& a, hipStream_t s);
 int launch_latent_bwd(const LatentBwdArgs& a, hipStream_t s);
 int launch_posterior_stats(const float* encout, int ldE, int K, int D, int n_rows, float inv_temp, float* enc_out_user,
-                           float* post_mean, float* post_logvar, float* probs, hipStream_t s);
+                           float* post_mean, float* post_logvar, float* probs, hipStream_t s, int32_t* hard_comp = nullptr,
+                           float* hard_mu = nullptr);
 int launch_sample_heads(const suave_plan* p, const int32_t* cls_off_dev, const float* params, const float* y,
                         const float* s, const int32_t* comp, int64_t n, const float* nn, const float* nu,
                         const float* ne, uint64_t seed, int64_t row_offset, float* out_num, int ld_num,

@@ -706,8 +706,10 @@ __global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
 __global__ __launch_bounds__(256) void k_posterior_stats(const float* __restrict__ encout, int ldE, int K, int D, int n_rows,
                                                          float inv_temp, float* __restrict__ enc_out_user,
                                                          float* __restrict__ post_mean, float* __restrict__ post_logvar,
-                                                         float* __restrict__ probs) {
+                                                         float* __restrict__ probs, int32_t* __restrict__ hard_comp,
+                                                         float* __restrict__ hard_mu) {
   __shared__ float p_s[64 * SUAVE_MAX_COMPONENTS];
+  __shared__ int kmax_s[64];
   const int tid = threadIdx.x;
   const int E = K + 2 * K * D;
   for (int r0 = blockIdx.x * 64; r0 < n_rows; r0 += gridDim.x * 64) {
@@ -719,13 +721,24 @@ __global__ __launch_bounds__(256) void k_posterior_stats(const float* __restrict
       float sum = 0.f;
       for (int j = 0; j < K; ++j) { const float e = __expf(lg[j] * inv_temp - mx); p_s[tid * SUAVE_MAX_COMPONENTS + j] = e; sum += e; }
       const float inv = 1.0f / sum;
+      float pbest = -1.0f;
+      int kbest = 0;
       for (int j = 0; j < K; ++j) {
         const float p = p_s[tid * SUAVE_MAX_COMPONENTS + j] * inv;
         p_s[tid * SUAVE_MAX_COMPONENTS + j] = p;
         if (probs) probs[(size_t)(r0 + tid) * K + j] = p;
+        if (p > pbest) { pbest = p; kbest = j; }  // posterior_probs.argmax: the first maximum (model.py:3627-3634)
       }
+      kmax_s[tid] = kbest;
+      if (hard_comp) hard_comp[r0 + tid] = kbest;
     }
     __syncthreads();
+    if (hard_mu) {
+      for (int idx = tid; idx < nrows * D; idx += 256) {
+        const int lr = idx / D, d = idx % D;
+        hard_mu[(size_t)(r0 + lr) * D + d] = encout[(size_t)(r0 + lr) * ldE + K + kmax_s[lr] * D + d];
+      }
+    }
     for (int idx = tid; idx < nrows * D; idx += 256) {
       const int lr = idx / D, d = idx % D;
       const float* row = encout + (size_t)(r0 + lr) * ldE + K;
@@ -1137,12 +1150,12 @@ int launch_latent_bwd(const LatentBwdArgs& a, hipStream_t s) {
 }
 
 int launch_posterior_stats(const float* encout, int ldE, int K, int D, int n_rows, float inv_temp, float* enc_out_user,
-                           float* post_mean, float* post_logvar, float* probs, hipStream_t s) {
+                           float* post_mean, float* post_logvar, float* probs, hipStream_t s, int32_t* hard_comp, float* hard_mu) {
   if (n_rows <= 0) return 0;
   const int grid = std::min((n_rows + 63) / 64, 2048);
   ProfScope prof_scope(kProfLatent, s);
   hipLaunchKernelGGL(k_posterior_stats, dim3(grid), dim3(256), 0, s, encout, ldE, K, D, n_rows, inv_temp, enc_out_user,
-                     post_mean, post_logvar, probs);
+                     post_mean, post_logvar, probs, hard_comp, hard_mu);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -264,6 +264,23 @@ class Engine:
         _lib.check(rc, "suave_encode")
         return {"enc_out": enc, "mean": pm, "logvar": plv, "probs": pr}
 
+    def encode_hard(self, table: PackedTable, row_begin: int, n_rows: int, *, temperature: Optional[float] = None):
+        """The hard assignment of SUAVE.impute (model.py:3627-3634): (z = mu of the most probable component [B,D],
+        component [B]) straight from the library (suave_encode_hard)."""
+
+        B = int(n_rows)
+        ws = self.workspace(B)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        nbytes = ws.numel() - (base - ws.data_ptr())
+        batch = table.batch(row_begin, B, None)
+        z = torch.empty((B, self.layout.latent_dim), dtype=torch.float32, device=self.device)
+        comp = torch.empty((B,), dtype=torch.int32, device=self.device)
+        inv_t = 1.0 if temperature is None else 1.0 / max(float(temperature), 1e-6)
+        rc = self.lib.suave_encode_hard(self._plan, self.params.data_ptr(), C.byref(batch), inv_t, base, nbytes,
+                                        self._stream(), comp.data_ptr(), z.data_ptr())
+        _lib.check(rc, "suave_encode_hard")
+        return z, comp
+
     # -- generation ------------------------------------------------------------
     def prior_latents(self, n: int, cdf: torch.Tensor, *, u=None, eps=None, seed: int = 0, row_offset: int = 0):
         D = self.layout.latent_dim
@@ -329,8 +346,11 @@ class Engine:
         _lib.check(rc, "suave_decode_sample_static")
 
     # -- Monte-Carlo posterior predictive ------------------------------------------
-    def posterior_draws(self, enc_out: torch.Tensor, L: int, *, e=None, eps=None, seed: int = 0, row_offset: int = 0):
-        """SUAVE._posterior_draws: returns z [L*B, D] and component [L*B] (draw-major)."""
+    def posterior_draws(self, enc_out: torch.Tensor, L: int, *, e=None, eps=None, seed: int = 0, row_offset: int = 0,
+                        row_major: bool = False):
+        """SUAVE._posterior_draws: returns z [L*B, D] and component [L*B], draw-major like the reference (row l B + b)
+        or, ``row_major``, with each row's draws together (row b L + l).  ``row_offset``: global index of the first
+        table row (the generators are keyed by (row, draw))."""
 
         B = int(enc_out.shape[0])
         D = self.layout.latent_dim
@@ -339,6 +359,11 @@ class Engine:
         rc = self.lib.suave_posterior_draws(self._plan, enc_out.data_ptr(), B, int(L), _ptr(e), _ptr(eps), int(seed),
                                             int(row_offset), self._stream(), z.data_ptr(), comp.data_ptr())
         _lib.check(rc, "suave_posterior_draws")
+        if row_major and L > 1 and B > 0:
+            # row b's draws become rows b L .. b L + L - 1: a decode of them with row_offset = (first table row) * L
+            # keys (row, draw) by (global row) * L + draw, whatever the chunking or the sharding
+            z = z.view(L, B, D).transpose(0, 1).reshape(B * L, D).contiguous()
+            comp = comp.view(L, B).transpose(0, 1).reshape(-1).contiguous()
         return z, comp
 
     def decode_log_px(self, z: torch.Tensor, component: torch.Tensor, table: PackedTable, row_begin: int = 0, *,

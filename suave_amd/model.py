@@ -431,6 +431,19 @@ class SUAVE:
         for start in range(0, n_rows, max(eff, 1)):  # last batch ragged, no drop-last (model.py:1475-1476)
             yield perm[start:start + eff], perm32[start:start + eff]
 
+    def _elbo_batches(self, table: PackedTable, eff: int):
+        """One epoch of global batches over ``table``: (global row ids of the batch int64, this rank's rows of it int32)
+        -- the whole batch on one GPU, a contiguous share of it with a replicated table, the rows held here with a
+        row-sharded table (selected once per epoch: no per-step host sync)."""
+
+        if self._dp is None or not self._sharded:
+            for idx64, idx in self._epoch_batches(table.n_global, eff):
+                yield idx64, self._shard(idx)
+            return
+        perm = torch.randperm(table.n_global, device=self._engine.device, generator=self._gen, dtype=torch.int64)
+        for b, e, loc in parallel.sharded_epoch_batches(perm, eff, table.row_base, table.n_rows):
+            yield perm[b:e], loc
+
     def _warmup_phase(self, train: PackedTable, val: Optional[PackedTable], n_epochs: int, bs: int, kl_epochs: int) -> None:
         """_run_warmup_phase (model.py:1382-1560)."""
 
@@ -447,12 +460,12 @@ class SUAVE:
             if self.behaviour == "unsupervised":
                 self._inference_tau = tau
             eng.sums.zero_()
-            for _, idx in self._epoch_batches(n_train, eff):
+            for idx, loc in self._elbo_batches(train, eff):
                 warm_step += 1
                 self._step += 1
                 beta = self.beta * min(warm_step, kl_steps) / kl_steps  # losses.kl_warmup
                 nb = int(idx.numel())
-                self._backward(train, self._shard(idx, train), beta_scale=beta, tau=tau, global_rows=nb,
+                self._backward(train, loc, beta_scale=beta, tau=tau, global_rows=nb,
                                noise=self._noise_for(nb))
                 self._record_step_gradient()
                 eng.adam_step(self.learning_rate)
@@ -581,11 +594,11 @@ class SUAVE:
         for _ in range(epochs):
             eng.sums.zero_()
             ce_tot = torch.zeros((), device=eng.device, dtype=torch.float64)
-            for idx64, idx in self._epoch_batches(n, eff):
-                nb = int(idx.numel())  # the global batch; `loc` are this rank's rows of it
+            for idx64, loc in self._elbo_batches(train, eff):
+                nb = int(idx64.numel())  # the global batch; `loc` are this rank's rows of it
                 self._step += 1
                 nz = self._noise_for(nb)
-                loc, loc64 = self._shard(idx, train), self._shard(idx64, train)
+                loc64 = loc.long()
                 fwd = eng.elbo(train, 0, int(loc.numel()), row_index=loc, beta_scale=self.beta, tau=tau, grad=False,
                                training=True, seed=self.random_state, step=self._step, want=("latent",), noise=nz)
                 latent = fwd["latent"].requires_grad_(True)
@@ -711,10 +724,10 @@ class SUAVE:
         lam = float(self.decoder_refine_prior_lambda)
         for _ in range(epochs):
             eng.sums.zero_()
-            for _, idx in self._epoch_batches(n, eff):
+            for idx, loc in self._elbo_batches(train, eff):
                 self._step += 1
                 nb = int(idx.numel())
-                self._backward(train, self._shard(idx, train), beta_scale=self.beta, tau=tau, global_rows=nb,
+                self._backward(train, loc, beta_scale=self.beta, tau=tau, global_rows=nb,
                                noise=self._noise_for(nb))
                 if anchors and lam != 0.0:  # + lambda * sum_t mse(prior_t, anchor_t)  (model.py:2338-2346)
                     for slot, snap in anchors:
@@ -954,13 +967,15 @@ class SUAVE:
         nums, cods, lat, asg = [], [], [], []
         for s0 in range(0, table.n_rows, _ROW_CHUNK):  # row chunks: the generators are keyed by the table row
             nb = min(_ROW_CHUNK, table.n_rows - s0)
-            out = eng.encode(table, s0, nb, temperature=tau)
-            enc, probs = out["enc_out"], out["probs"]
-            mu = enc[:, K:K + K * D].reshape(-1, K, D)
             comp = assign = None
-            if strategy == "hard":  # model.py:3627-3634
-                comp = probs.argmax(dim=1).to(torch.int32)
-                z = mu[torch.arange(mu.shape[0], device=mu.device), comp.long()].contiguous()
+            if strategy == "hard":  # model.py:3627-3634: argmax of the posterior probabilities, that component's mean
+                z, comp = eng.encode_hard(table, s0, nb, temperature=tau)
+            else:
+                out = eng.encode(table, s0, nb, temperature=tau)
+                enc, probs = out["enc_out"], out["probs"]
+                mu = enc[:, K:K + K * D].reshape(-1, K, D)
+            if strategy == "hard":
+                pass
             elif strategy == "soft":  # model.py:3635-3637
                 assign = probs.contiguous()
                 z = out["mean"]
@@ -1166,10 +1181,7 @@ class SUAVE:
         """L posterior draws per row of ``enc`` in ROW-major order (row b's draws are rows b L .. b L + L - 1): with
         it the decode's generator key of (row, draw) is (global row) * L + draw, whatever the chunking or sharding."""
 
-        z, comp = self._engine.posterior_draws(enc, L, seed=seed, row_offset=first_row)
-        nb = int(enc.shape[0])
-        return (z.view(L, nb, -1).transpose(0, 1).reshape(nb * L, -1).contiguous(),
-                comp.view(L, nb).transpose(0, 1).reshape(-1).contiguous())
+        return self._engine.posterior_draws(enc, L, seed=seed, row_offset=first_row, row_major=True)
 
     def impute_mc(self, X: pd.DataFrame, *, L: int = 32, only_missing: bool = True, seed: Optional[int] = None,
                   row_offset: Optional[int] = None, gather: bool = False) -> pd.DataFrame:

@@ -56,6 +56,29 @@ def generation_span(n_rows: int, row_offset: Optional[int], group=None) -> Tuple
     return b, e - b
 
 
+def sharded_epoch_batches(perm: torch.Tensor, batch: int, row_base: int, n_local: int):
+    """The global batches of one epoch over a ROW-SHARDED table, as seen by the rank that holds rows [row_base,
+    row_base + n_local): yields ``(start, stop, rows)`` -- the batch is ``perm[start:stop]`` (a permutation of the
+    global row ids, the same on every rank) and ``rows`` are its entries held here, order kept, as int32.
+
+    The selection is made once per epoch (one compaction of the permutation and one per-batch count vector: two host
+    syncs an epoch) so that no step waits for the host."""
+
+    n = int(perm.numel())
+    batch = max(int(batch), 1)
+    p32 = perm.to(torch.int32)
+    sel = (p32 >= int(row_base)) & (p32 < int(row_base) + int(n_local))
+    local = p32[sel]
+    n_batches = (n + batch - 1) // batch
+    pad = torch.zeros(n_batches * batch, dtype=torch.int32, device=perm.device)
+    pad[:n] = sel.to(torch.int32)
+    ends = pad.view(n_batches, batch).sum(dim=1).cumsum(0).cpu().tolist()
+    begin = 0
+    for i in range(n_batches):
+        yield i * batch, min((i + 1) * batch, n), local[begin:int(ends[i])]
+        begin = int(ends[i])
+
+
 def all_gather_objects(obj, group=None) -> list:
     """One Python object per rank, in rank order (small host data: sizes, label arrays, frames on request)."""
 
