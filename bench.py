@@ -295,6 +295,143 @@ def generation_rates(eng, table, rows, gen_rows, device, rank, world, dist, fenc
     return res
 
 
+def m20_schema():
+    """SURVEY.md §8d config #1 ("MIMIC-demo-shaped"): 8 real, 5 pos, 2 count, 3 cat (C = 2, 2, 4), 2 ordinal (C = 4, 5)."""
+
+    spec = {}
+    for i in range(8):
+        spec[f"r{i}"] = {"type": "real"}
+    for i in range(5):
+        spec[f"p{i}"] = {"type": "pos"}
+    for i in range(2):
+        spec[f"c{i}"] = {"type": "count"}
+    for i, c in enumerate((2, 2, 4)):
+        spec[f"k{i}"] = {"type": "cat", "n_classes": c}
+    for i, c in enumerate((4, 5)):
+        spec[f"o{i}"] = {"type": "ordinal", "n_classes": c}
+    return spec
+
+
+def m20_subrecord(device):
+    """BASELINE config #1 through the PRODUCT: ``SUAVE.fit`` on a 10 000-row M20 frame (8 000 train / 2 000 validation),
+    latent 32, K = 10, hidden (256, 128), batch 256 -- the runs SURVEY.md section 6 timed on the reference (PyTorch
+    eager, 8 CPU threads, survey container), with the numpy oracle's step on this host beside them."""
+
+    import pandas as pd
+    import torch
+
+    from suave_amd.model import SUAVE
+    from suave_amd.types import Schema
+
+    spec = m20_schema()
+    rng = np.random.default_rng(20201021)
+    n = 10_000
+    cols = {}
+    for name, sp in spec.items():
+        t = sp["type"]
+        v = (rng.normal(50.0, 12.0, n) if t == "real" else np.exp(rng.normal(1.0, 0.5, n)) if t == "pos" else
+             rng.poisson(3.0, n).astype(np.float64) if t == "count" else rng.integers(0, sp["n_classes"], n).astype(np.float64))
+        v[rng.random(n) < 0.1] = np.nan
+        cols[name] = v
+    X, y = pd.DataFrame(cols), (rng.random(n) < 0.3).astype(np.int64)
+    out = {"workload": "M20: 10 000 rows x 20 mixed cols (8 real / 5 pos / 2 count / 3 cat / 2 ordinal, 10% missing), "
+                       "val_split 0.2, latent 32, K=10, hidden (256,128), batch 256, SUAVE.fit end to end (host loop, "
+                       "per-epoch validation, pandas -> packed table included)"}
+    common = dict(latent_dim=32, n_components=10, hidden_dims=(256, 128), batch_size=256, val_split=0.2, random_state=0,
+                  device=str(device))
+
+    def timed(fn):
+        fn()  # warm-up: code objects, allocator, first-call plan creation
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, float(m._train_history[-1]["reconstruction"])
+
+    t, rec = timed(lambda: SUAVE(Schema(spec), behaviour="unsupervised", **common).fit(X, epochs=5))
+    out["unsupervised_warmup5"] = {"seconds": t, "rows_per_s": 5 * 8000 / t, "final_reconstruction": rec}
+    t, rec = timed(lambda: SUAVE(Schema(spec), behaviour="supervised", **common).fit(
+        X, y, warmup_epochs=3, head_epochs=1, finetune_epochs=1, decoder_refine_epochs=0))
+    out["supervised_3_1_1_0"] = {"seconds": t, "elbo_step_rows_per_s": 32000 / t, "final_reconstruction": rec,
+                                 "reference_survey": {"seconds": 7.2, "rows_per_s": 4400.0,
+                                                      "note": "SURVEY.md section 6: reference PyTorch eager, 8 threads, survey container"}}
+    stats = {nme: ({"mean": 50.0, "std": 12.0} if sp["type"] == "real" else {"mean_log": 1.2, "std_log": 0.45}
+                   if sp["type"] == "pos" else {"offset": 1.0} if sp["type"] == "count" else {}) for nme, sp in spec.items()}
+    out["cpu_baseline"] = cpu_baseline(spec, stats, 0.1, budget_s=6.0, batch=256, latent=32, hidden=(256, 128), label="M20")
+    return out
+
+
+def w1024_subrecord(device, steps=5, warmup=2):
+    """BASELINE config #4 on the driver's clock: the W1024 training step (batch 32 768) timed like the headline one,
+    GEMM-class roofline from a second, event-bracketed pass; HBM traffic per launch from the committed PMC passes."""
+
+    import torch
+
+    from suave_amd import lib as slib
+    from suave_amd.engine import Engine, PackedTable
+    from suave_amd.plan import ModelLayout
+    from suave_amd.types import Schema
+
+    spec, stats = w1024_schema()
+    layout = ModelLayout(Schema(spec), K_COMP, 128, (384, 256), 0.1, "supervised", stats)
+    eng = Engine(layout, device)
+    eng.load_state(layout.init_params(seed=0))
+    rows, B = 65536, 32768
+    xnum, codes, mask = synth_table_device(layout, rows, device, seed=20201021)
+    table = PackedTable(xnum, codes, mask, device)
+    st = {"step": 0, "perm": None}
+
+    def one_step():
+        i = st["step"] % (rows // B)
+        if i == 0:
+            st["perm"] = torch.randperm(rows, device=device, dtype=torch.int32)
+        st["step"] += 1
+        eng.elbo(table, 0, B, row_index=st["perm"][i * B:(i + 1) * B], beta_scale=1.0, tau=1.0, grad=True, global_rows=B,
+                 seed=1234, step=st["step"], accumulate_sums=True)
+        eng.adam_step(1e-3)
+
+    for _ in range(warmup):
+        one_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = (C.c_double * 8)()
+    cnt = (C.c_int64 * 8)()
+    slib.load().suave_profile_enable(1)
+    for _ in range(steps):
+        one_step()
+    torch.cuda.synchronize()
+    slib.load().suave_profile_enable(0)
+    slib.check(slib.load().suave_profile_read(ms, cnt, 8), "suave_profile_read")
+    rec = {"workload": "W1024: 65 536 rows x 1024 mixed cols (400 real / 200 pos / 100 count / 224 cat up to 256 classes / "
+                       "100 ordinal, 10% masked), latent 128, K=10, hidden (384,256), dropout 0.10, fwd+bwd+Adam",
+           "batch": B, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+           "rows_per_s": B * steps / elapsed,
+           "kernel_ms_per_step": {PROF_CLASSES[i]: ms[i] / steps for i in range(8) if cnt[i] > 0}}
+    if cnt[0] > 0:
+        flops = gemm_flops_per_row(layout) * B * steps
+        achieved = flops / (ms[0] * 1e-3) / 1e12
+        rec["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS / 3, "unit": "TFLOP/s",
+                           "frac": achieved / (PEAK_BF16_MFMA_TFLOPS / 3), "avg_launch_us": 1e3 * ms[0] / cnt[0],
+                           "launches_per_step": cnt[0] // steps, "traffic": None}
+        for name in ("r03_pmc_traffic_w1024.json", "r02_pmc_traffic_w1024.json"):
+            f = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(f):
+                with open(f) as fh:
+                    tt = json.load(fh)
+                rec["roofline"]["traffic"] = tt.get("gemm", {}).get("hbm_bytes_per_launch")
+                rec["roofline"]["traffic_source"] = name
+                ps = tt.get("per_step", {}).get("all_library_kernels", {})
+                rec["hbm_bytes_per_step"] = 1e6 * (ps.get("read_MB", 0.0) + ps.get("write_MB", 0.0)) or None
+                break
+    del eng, table, xnum, codes, mask
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,6 +443,8 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="table rows per GPU (default 1M at N=1, 2M at N>1)")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-subrecords", action="store_true",
+                    help="skip the w1024 (config #4) and m20 (config #1) sub-records of the default S64 line")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-timed", action="store_true",
                     help="bracket the launches of the timed region itself with HIP events (default: a second pass of K steps)")
@@ -520,6 +659,11 @@ def main():
             line["roofline"]["traffic_source"] = t.get("source")
             if "roofline_likelihood_kl" in line:
                 line["roofline_likelihood_kl"]["traffic"] = t.get("likelihood_kl", {}).get("hbm_bytes_per_launch")
+        if world == 1 and not wide and not args.no_subrecords:
+            print("[bench] w1024 sub-record (config #4) ...", file=sys.stderr, flush=True)
+            line["w1024"] = w1024_subrecord(device)
+            print("[bench] m20 sub-record (config #1: SUAVE.fit) ...", file=sys.stderr, flush=True)
+            line["m20"] = m20_subrecord(device)
         if world == 1 and not args.no_cpu_baseline:
             print("[bench] cpu baseline (numpy oracle) ...", file=sys.stderr, flush=True)
             line["cpu_baseline"] = (cpu_baseline(spec, stats, args.dropout, batch=128, latent=latent, hidden=hidden, label="W1024")

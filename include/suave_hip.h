@@ -242,6 +242,14 @@ int suave_encode_hard(const suave_plan* plan, const float* params, const suave_b
                       float inv_temperature, void* workspace, size_t workspace_bytes, void* stream,
                       int32_t* component, float* z);
 
+/* The word -> variate maps every in-kernel generator of this library uses, applied to caller-given
+ * 32-bit words: uniform in (0,1) (never 0 or 1), Exp(1), N(0,1) (Box-Muller over words 2j, 2j+1;
+ * normal[2j], normal[2j+1] are its two outputs).  No counterpart in the reference (torch's
+ * generators draw these): it lets a test pin the maps' range at the extreme words, and a caller
+ * that replays a Philox stream reproduce the library's draws.  Any output may be NULL. */
+int suave_rng_draws(const uint32_t* words, int64_t n, void* stream, float* uniform, float* exponential,
+                    float* normal);
+
 /* Prior latent draw: sampling.sample_prepared_mixture_latents (sampling.py:38-56).
  * cdf [K] cumulative softmax(prior_logits); u [n] uniform and eps [n,D] normal
  * draws, or NULL to generate from (seed, row_offset + i). */

@@ -1396,6 +1396,31 @@ extern "C" int suave_encode_hard(const suave_plan* p, const float* params, const
 }
 
 namespace {
+// the library's word -> variate maps (common.h) on caller-given words: normal[i] pairs words 2*(i/2), 2*(i/2)+1
+__global__ void k_rng_draws(const uint32_t* words, int64_t n, float* uniform, float* exponential, float* normal) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (uniform) uniform[i] = suave::u01(words[i]);
+  if (exponential) exponential[i] = suave::exp_draw(words[i]);
+  if (normal) {
+    const int64_t j = i & ~int64_t(1);
+    const float2 z = suave::normal2(words[j], words[j + 1 < n ? j + 1 : j]);
+    normal[i] = (i & 1) ? z.y : z.x;
+  }
+}
+}  // namespace
+
+extern "C" int suave_rng_draws(const uint32_t* words, int64_t n, void* stream, float* uniform, float* exponential,
+                               float* normal) {
+  SUAVE_REQUIRE(words != nullptr && n >= 0, "words is null");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_rng_draws, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), words, n,
+                     uniform, exponential, normal);
+  SUAVE_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+namespace {
 
 // Scratch of the decode path: z with padded rows, the decoder's hidden activations, y_full.
 struct DecodeScratch {

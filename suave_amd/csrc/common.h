@@ -156,12 +156,13 @@ struct Philox {
   }
 };
 
-// uniform in (0,1): 24 random bits, never 0 or 1
-__device__ __forceinline__ float u01(uint32_t r) { return (static_cast<float>(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+// uniform in (0,1): 23 random bits, (m + 1/2) / 2^23 -- exact in binary32, so never 0 and never 1 (with 24 bits the
+// top value m + 1/2 = 2^24 - 1/2 rounds to 2^24: u = 1, an Exp(1) draw of 0 and a Gumbel draw of +inf once in 2^24)
+__device__ __forceinline__ float u01(uint32_t r) { return (static_cast<float>(r >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
 // ln(x) for NORMAL positive x (no denormal scaling, unlike __logf): v_log_f32 and one multiply
 __device__ __forceinline__ float ln_normal(float x) { return 0.6931471806f * __builtin_amdgcn_logf(x); }
-// Exp(1) draw from a 32-bit word: u01 is in [2^-25, 1), the draw in [3e-8, 17.4)
+// Exp(1) draw from a 32-bit word: u01 is in [2^-24, 1 - 2^-24], the draw in [6e-8, 16.7)
 __device__ __forceinline__ float exp_draw(uint32_t r) { return -ln_normal(u01(r)); }
 
 // two N(0,1) from two 32-bit words (Box-Muller)
