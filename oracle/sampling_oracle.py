@@ -120,7 +120,70 @@ def det_dot(w_y, w_s, y, s):
 # build-defined noise -> value maps
 # ---------------------------------------------------------------------------
 POISSON_SWITCH = F32(64.0)
+POISSON_HUGE = F32(65536.0)
 POISSON_MAX_ITERS = 512
+POISSON_WALK_MAX = 4096
+POISSON_WALK_STOP = F32(1e-9)
+
+
+def _poisson_mode_pmf(rate):
+    """p(k0; rate) at k0 = floor(rate) >= 64, binary32 with individually rounded operations:
+    p = exp(k0 log1p(d / k0) - d - c) / sqrt(2 pi k0),  d = rate - k0 in [0, 1) (exact),
+    k0 log1p(x) - d = d x (-1/2 + x/3 - x^2/4 + x^3/5) for x = d / k0 <= 1/64 (next term < 2e-10), and the
+    Stirling correction c = 1/(12 k0) - 1/(360 k0^3) (next term < 1e-12).  No large terms cancel."""
+
+    rate = np.asarray(rate, F32)
+    k0 = np.floor(rate).astype(F32)
+    d = (rate - k0).astype(F32)
+    x = (d / k0).astype(F32)
+    poly = (F32(0.2) * x).astype(F32)
+    poly = (poly + F32(-0.25)).astype(F32)
+    poly = (poly * x).astype(F32)
+    poly = (poly + F32(0.33333334)).astype(F32)
+    poly = (poly * x).astype(F32)
+    poly = (poly + F32(-0.5)).astype(F32)
+    e = ((d * x).astype(F32) * poly).astype(F32)
+    ik = (F32(1.0) / k0).astype(F32)
+    ik2 = (ik * ik).astype(F32)
+    c = (ik * (F32(0.083333336) - (ik2 * F32(0.0027777778)).astype(F32)).astype(F32)).astype(F32)
+    den = np.sqrt((F32(6.2831855) * k0).astype(F32)).astype(F32)
+    return k0, (det_exp((e - c).astype(F32)) / den).astype(F32)
+
+
+def poisson_mode_walk(rate, u):
+    """Exact Poisson draw from ONE uniform for 64 <= rate < 65536: inversion over the values in the order
+    k0, k0+1, k0-1, k0+2, k0-2, ... (k0 = floor(rate), the mode): value k owns the next p(k) of [0, 1) in that order,
+    so P(k) = p(k) whatever the order, and starting at the mode the walk ends after ~1.6 sqrt(rate) values.
+    p(k0) from `_poisson_mode_pmf`, the neighbours by the recurrences p(k+1) = p(k) rate / (k+1) and
+    p(k-1) = p(k) k / rate.  The walk stops when both tails fall below 1e-9 (they no longer move a binary32 sum
+    near 1); a u beyond the accumulated mass (rounding: < 1e-5) takes the mode."""
+
+    rate = np.asarray(rate, F32)
+    u = np.asarray(u, F32)
+    k0, p0 = _poisson_mode_pmf(rate)
+    acc = p0.copy()
+    out = k0.copy()
+    go = u > acc
+    pu, pd = p0.copy(), p0.copy()
+    for i in range(1, POISSON_WALK_MAX + 1):
+        if not go.any():
+            break
+        fi = F32(i)
+        ku = (k0 + fi).astype(F32)
+        pu = ((pu * rate).astype(F32) / ku).astype(F32)
+        acc_u = (acc + pu).astype(F32)
+        hit_u = go & ~(u > acc_u)
+        out = np.where(hit_u, ku, out).astype(F32)
+        go = go & ~hit_u
+        kd_prev = (k0 - (fi - F32(1.0))).astype(F32)   # the value whose probability pd holds
+        pd = ((pd * kd_prev).astype(F32) / rate).astype(F32)
+        acc_d = (acc_u + pd).astype(F32)
+        hit_d = go & ~(u > acc_d)
+        out = np.where(hit_d, (kd_prev - F32(1.0)).astype(F32), out).astype(F32)
+        go = go & ~hit_d
+        acc = acc_d
+        go = go & ((pu > POISSON_WALK_STOP) | (pd > POISSON_WALK_STOP))
+    return out.astype(F32)
 
 
 def poisson_from_noise(rate, u, n):
@@ -128,9 +191,12 @@ def poisson_from_noise(rate, u, n):
 
     ``torch.poisson`` consumes a data-dependent number of uniforms and cannot be
     replayed, so the build defines its own map and the oracle
-    evaluates the same map on the reference's ``rate``: CDF inversion by
-    sequential search for ``rate < 64`` (exact Poisson up to binary32 CDF
-    resolution), rounded normal approximation above.
+    evaluates the same map on the reference's ``rate``.  Three ranges:
+      * ``rate < 64``: CDF inversion by sequential search from 0 (exact Poisson up to binary32 CDF resolution);
+      * ``64 <= rate < 65536``: inversion from the mode (`poisson_mode_walk`), exact in the same sense;
+      * ``rate >= 65536``: the normal draw with its first Cornish-Fisher (skewness) term,
+        floor(rate + sqrt(rate) n + (n^2 - 1)/6 + 1/2): the error of this expansion is O(1/rate) < 2e-5 in
+        distribution, and binary32 counts are not all representable much above this range anyway.
     """
 
     rate = np.asarray(rate, F32)
@@ -152,9 +218,15 @@ def poisson_from_noise(rate, u, n):
         p = np.where(go, p_new, p).astype(F32)
         cdf = np.where(go, cdf_new, cdf).astype(F32)
         go = go & (u > cdf) & ((p > F32(1e-30)) | (fi <= r))
-    big = np.floor(rate + np.sqrt(rate) * n + F32(0.5))
+    mid = ~small & (rate < POISSON_HUGE)
+    walk = np.zeros(rate.shape, F32)
+    if mid.any():
+        walk[mid] = poisson_mode_walk(rate[mid], u[mid])
+    skew = (((n * n).astype(F32) - F32(1.0)).astype(F32) * F32(0.16666667)).astype(F32)
+    big = (rate + (np.sqrt(rate).astype(F32) * n).astype(F32)).astype(F32)
+    big = np.floor(((big + skew).astype(F32) + F32(0.5)).astype(F32))
     big = np.maximum(big, F32(0.0))
-    return np.where(small, k, big).astype(F32)
+    return np.where(small, k, np.where(mid, walk, big)).astype(F32)
 
 
 def argmax_first(score):

@@ -19,9 +19,49 @@ constexpr float kCatMargin = 2e-5f;
 constexpr float kOrdDp = 4e-5f;
 constexpr float kCountMargin = 1e-4f;
 
-// (rate, uniform, normal) -> Poisson count; mirrors sampling_oracle.poisson_from_noise
+// Exact Poisson draw from one uniform for 64 <= rate < 65536: inversion over the values in the order k0, k0+1, k0-1,
+// k0+2, ... from the mode k0 = floor(rate) (value k owns the next p(k) of [0,1) in that order, so P(k) = p(k)); about
+// 1.6 sqrt(rate) values on average.  p(k0) = exp(k0 log1p(d/k0) - d - c) / sqrt(2 pi k0) with d = rate - k0 (exact),
+// the log1p series written so that no large terms cancel, and Stirling's c = 1/(12 k0) - 1/(360 k0^3); neighbours by
+// p(k+1) = p(k) rate/(k+1), p(k-1) = p(k) k/rate.  Mirrors sampling_oracle.poisson_mode_walk operation by operation.
+__device__ inline float poisson_mode_walk(float rate, float u) {
+  const float k0 = floorf(rate);
+  const float d = detm::sub(rate, k0);
+  const float x = detm::dvd(d, k0);
+  float poly = detm::mul(0.2f, x);
+  poly = detm::add(poly, -0.25f);
+  poly = detm::mul(poly, x);
+  poly = detm::add(poly, 0.33333334f);
+  poly = detm::mul(poly, x);
+  poly = detm::add(poly, -0.5f);
+  const float e = detm::mul(detm::mul(d, x), poly);
+  const float ik = detm::dvd(1.0f, k0);
+  const float c = detm::mul(ik, detm::sub(0.083333336f, detm::mul(detm::mul(ik, ik), 0.0027777778f)));
+  const float p0 = detm::dvd(detm::exp(detm::sub(e, c)), detm::sqrt_rn(detm::mul(6.2831855f, k0)));
+  float acc = p0, out = k0, pu = p0, pd = p0;
+  bool go = u > acc;
+#pragma unroll 1
+  for (int i = 1; i <= 4096 && go; ++i) {
+    const float fi = (float)i;
+    const float ku = detm::add(k0, fi);
+    pu = detm::dvd(detm::mul(pu, rate), ku);
+    acc = detm::add(acc, pu);
+    if (!(u > acc)) { out = ku; break; }
+    const float kd = detm::sub(k0, detm::sub(fi, 1.0f));  // the value whose probability pd holds
+    pd = detm::dvd(detm::mul(pd, kd), rate);
+    acc = detm::add(acc, pd);
+    if (!(u > acc)) { out = detm::sub(kd, 1.0f); break; }
+    go = (pu > 1e-9f) || (pd > 1e-9f);  // (smaller terms no longer move a binary32 sum near 1; then: the mode)
+  }
+  return out;
+}
+
+// (rate, uniform, normal) -> Poisson count; mirrors sampling_oracle.poisson_from_noise: sequential CDF inversion from
+// 0 below rate 64, inversion from the mode up to 65536 (both exact up to binary32 CDF resolution), the normal draw with
+// its first Cornish-Fisher term beyond
 __device__ inline float poisson_from_noise(float rate, float u, float n) {
   const bool small = rate < 64.0f;
+  if (!small && rate < 65536.0f) return poisson_mode_walk(rate, u);
   const float r = small ? rate : 1.0f;
   float p = detm::exp(-r);
   float cdf = p;
@@ -34,7 +74,9 @@ __device__ inline float poisson_from_noise(float rate, float u, float n) {
     k = fi;
     go = (u > cdf) && ((p > 1e-30f) || (fi <= r));
   }
-  float big = floorf(detm::add(detm::add(rate, detm::mul(detm::sqrt_rn(rate), n)), 0.5f));
+  const float skew = detm::mul(detm::sub(detm::mul(n, n), 1.0f), 0.16666667f);
+  float big = detm::add(rate, detm::mul(detm::sqrt_rn(rate), n));
+  big = floorf(detm::add(detm::add(big, skew), 0.5f));
   big = fmaxf(big, 0.f);
   return small ? k : big;
 }

@@ -229,6 +229,15 @@ def make_columns(kind: str):
             orc.Column("w1", "cat", n_classes=17),
             orc.Column("n0", "count", stats={"offset": 1.0}),
         ]
+    if kind == "bigcount6":  # count heads whose rates cover every range of the build's Poisson map (gen_decode boosts them)
+        return [
+            orc.Column("r0", "real", stats={"mean": 3.0, "std": 2.0}),
+            orc.Column("n0", "count", stats={"offset": 1.0}),
+            orc.Column("n1", "count", stats={"offset": 1.0}),
+            orc.Column("c0", "cat", n_classes=3),
+            orc.Column("n2", "count", stats={"offset": 0.0}),
+            orc.Column("n3", "count", stats={"offset": 1.0}),
+        ]
     raise ValueError(kind)
 
 
@@ -450,14 +459,21 @@ def gen_joint(name, kind, K, D, hidden, B, mask_rate, seed, n_classes=3, cls_wei
     print("wrote", name, "joint loss", float(joint))
 
 
-def gen_decode(name, kind, K, D, hidden, B, seed):
+def gen_decode(name, kind, K, D, hidden, B, seed, rate_boost=None):
     """Decoder forward on placeholder batches (sampling path, model.py:4397-4420):
-    head params, log-likelihoods with both masks, injected draws and samples."""
+    head params, log-likelihoods with both masks, injected draws and samples.
+    ``rate_boost`` {count column: [K] values}: added to the component part of that head's rate_layer weight, so that
+    rate = softplus(w_y . y + w_s[k]) lands in a chosen range per component (softplus(x) ~ x beyond 20)."""
 
     rng = np.random.default_rng(seed)
     cols = make_columns(kind)
     model, om = build_reference(cols, K, D, hidden, 0.0, "supervised", seed)
     model._decoder.eval()
+    if rate_boost:
+        with torch.no_grad():
+            for cname, vals in rate_boost.items():
+                wgt = model._decoder.heads[cname].rate_layer.weight
+                wgt[0, -K:] += torch.tensor(vals, dtype=wgt.dtype)
     xnum, codes, mask = make_batch(cols, B, 0.3, rng)
     _, data_t, mask_t = to_torch_batches(om, xnum, codes, mask)
     z = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32))
@@ -1071,6 +1087,10 @@ def main():
         (gen_elbo, ("elbo_sup_wide7", "wide7", 3, 6, (16, 8), 48, 0.3, 0.0, "supervised", 61), {}),
         (gen_elbo, ("elbo_unsup_wide7", "wide7", 2, 4, (16, 8), 24, 0.3, 0.0, "unsupervised", 62), {"temperature": 0.8}),
         (gen_decode, ("decode_wide7", "wide7", 3, 6, (16, 8), 32, 63), {}),
+        # count rates around the branch point 64, in the mode-walk range (64 .. 65536) and beyond it
+        (gen_decode, ("decode_bigcount6", "bigcount6", 3, 6, (16, 8), 96, 64),
+         {"rate_boost": {"n0": [60.0, 64.0, 70.0], "n1": [100.0, 400.0, 1000.0], "n2": [5000.0, 30000.0, 65530.0],
+                         "n3": [66000.0, 200000.0, 3.0]}}),
         (gen_joint, ("joint_sup_mixed7", "mixed7", 3, 6, (16, 8), 48, 0.3, 71), {}),
         (gen_predictive, ("predictive_mixed7", "mixed7", 3, 6, (16, 8), 24, 81), {}),
         (gen_impute, ("impute_mixed8", 91), {}),

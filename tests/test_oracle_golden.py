@@ -101,10 +101,13 @@ def test_posterior_statistics_match_reference():
     assert rel_err(pp, fx["out/post_probs_t05"]) < TOL
 
 
-@pytest.mark.parametrize("name", ["decode_mixed12", "decode_ydim", "decode_wide7"])
+@pytest.mark.parametrize("name", ["decode_mixed12", "decode_ydim", "decode_wide7", "decode_bigcount6"])
 def test_decode_matches_reference(name):
     """Head parameters, both log-likelihood masks, and sampled values (bit-exact for
-    categorical / ordinal / count) on injected draws."""
+    categorical / ordinal / count) on injected draws.  decode_bigcount6 holds count rates up to 200 000: a count is a
+    step function of its rate, and at a rate r the last-bit difference between this trunk's y and torch's moves the
+    steps by ~1e-7 r, so cells with r >= 2048 are asked to agree in 90 % of the rows here (the map itself is pinned
+    bit for bit on the reference's own rates in test_oracle_known_answers)."""
 
     fx = load_golden(name)
     om, P, meta = fixture_model(fx)
@@ -127,6 +130,10 @@ def test_decode_matches_reference(name):
         got = samples[c.name]
         if c.type in ("real", "pos"):
             assert rel_err(got, ref) < TOL, c.name
+        elif c.type == "count":
+            same = got.astype(np.int64) == ref.astype(np.int64)
+            big = fx[f"out/{c.name}/params/rate"].reshape(-1) >= 2048
+            assert same[~big].all() and (not big.any() or same[big].mean() >= 0.9), c.name
         else:
             assert np.array_equal(got.astype(np.int64), ref.astype(np.int64)), c.name
 

@@ -199,27 +199,57 @@ def test_sampled_elbo_equals_expectation_at_zero_temperature():
     np.testing.assert_allclose(elbo_new, elbo_exp, atol=1e-5, rtol=1e-4)
 
 
-def test_poisson_map_moments_both_branches():
-    """The build-defined (rate, u, n) -> count map (oracle/sampling_oracle.poisson_from_noise == sample.hip
-    poisson_from_noise; torch.poisson cannot be replayed).  Below rate 64: CDF inversion, an exact Poisson draw up to
-    binary32 CDF resolution -- mean, variance and skewness 1/sqrt(rate) are reproduced.  From rate 64 on: the
-    rounded normal floor(rate + sqrt(rate) n + 1/2) -- mean and variance (+1/12 from the rounding) are Poisson's,
-    the skewness is 0 where Poisson's is 1/sqrt(rate) <= 0.125: the documented approximation of that branch
-    (INTEGRATION.md).  No reference fixture pins the large-rate branch: parity unpinned there."""
+def test_poisson_map_is_poisson_in_every_range():
+    """The build-defined (rate, u, n) -> count map (oracle/sampling_oracle.poisson_from_noise == sample_col.h
+    poisson_from_noise; torch.poisson cannot be replayed) against scipy.stats.poisson.
+      * rate < 64 (sequential inversion from 0) and 64 <= rate < 65536 (inversion from the mode): on the uniform grid
+        u = (i + 1/2) / 2^20 the frequency of EVERY value equals its pmf to the grid's resolution -- the map is an exact
+        Poisson sampler up to binary32 CDF resolution; first three moments and the 97.5 % quantile follow.
+      * rate >= 65536: normal draw with the first Cornish-Fisher term; mean, variance and skewness 1/sqrt(rate)."""
+
+    from scipy import stats
 
     from oracle import sampling_oracle as sorc
 
-    rng = np.random.default_rng(12)
-    n = 400_000
-    u, z = rng.random(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
-
-    def moments(rate):
-        k = sorc.poisson_from_noise(np.full(n, rate, np.float32), u, z).astype(np.float64)
+    N = 1 << 20
+    u = ((np.arange(N) + 0.5) / N).astype(np.float32)
+    zero = np.zeros(N, np.float32)
+    for rate in (3.0, 20.0, 63.9, 64.0, 100.0, 100.7, 1000.0, 1000.999):
+        k = sorc.poisson_from_noise(np.full(N, rate, np.float32), u, zero).astype(np.int64)
+        r = float(np.float32(rate))
+        lo = int(k.min())
+        freq = np.bincount(k - lo) / N
+        pmf = stats.poisson.pmf(np.arange(lo, lo + len(freq)), r)
+        assert np.abs(freq - pmf).max() < 3e-6, rate
         m, v = k.mean(), k.var()
-        return m, v, ((k - m) ** 3).mean() / v ** 1.5
+        sk = ((k - m) ** 3).mean() / v ** 1.5
+        assert abs(m - r) < 1e-3 * max(1.0, np.sqrt(r)) and abs(v - r) < 2e-3 * r and abs(sk - r ** -0.5) < 2e-3, rate
+        q = stats.poisson.ppf(0.975, r)
+        assert abs((k <= q).mean() - stats.poisson.cdf(q, r)) < 3e-6 * (q - lo + 1), rate
+        assert np.quantile(k, 0.975, method="inverted_cdf") == q, rate
+    rng = np.random.default_rng(12)
+    z = rng.standard_normal(N).astype(np.float32)
+    for rate in (65536.0, 1.0e6):
+        k = sorc.poisson_from_noise(np.full(N, rate, np.float32), u, z).astype(np.float64)
+        m, v = k.mean(), k.var()
+        sk = ((k - m) ** 3).mean() / v ** 1.5
+        assert abs(m - rate) < 4 * np.sqrt(rate / N) + 0.1 and abs(v - rate) < 6e-3 * rate
+        assert abs(sk - rate ** -0.5) < 4 * np.sqrt(6.0 / N), (rate, sk)
 
-    m, v, sk = moments(20.0)
-    assert abs(m - 20.0) < 0.05 and abs(v - 20.0) < 0.25 and abs(sk - 20.0 ** -0.5) < 0.02
-    m, v, sk = moments(100.0)
-    assert abs(m - 100.0) < 0.1 and abs(v - (100.0 + 1.0 / 12.0)) < 1.0
-    assert abs(sk) < 0.02  # symmetric: Poisson(100) has skewness 0.1
+
+def test_poisson_map_on_the_reference_rates_of_the_bigcount_fixture():
+    """decode_bigcount6: the reference's Decoder.forward on count heads whose rates span 2.5 .. 200 000 (every range
+    of the map), with the map in place of torch.poisson (make_golden.NoiseTape).  The oracle's map on the
+    REFERENCE's rates and the recorded draws must give the reference's samples bit for bit, in every range."""
+
+    from oracle import sampling_oracle as sorc
+    from tests.helpers import load_golden
+
+    fx = load_golden("decode_bigcount6")
+    seen = set()
+    for c in ("n0", "n1", "n2", "n3"):
+        rate = fx[f"out/{c}/params/rate"].reshape(-1)
+        got = sorc.poisson_from_noise(rate, fx[f"noise/{c}/uniform"].reshape(-1), fx[f"noise/{c}/normal"].reshape(-1))
+        assert np.array_equal(np.rint(got).astype(np.int64), fx[f"out/{c}/sample"].reshape(-1).astype(np.int64)), c
+        seen |= {0 if r < 64 else 1 if r < 65536 else 2 for r in rate}
+    assert seen == {0, 1, 2}
