@@ -287,21 +287,28 @@ int suave_decode_sample(const suave_plan* plan, const float* params, const float
 
 /* suave_decode_sample for callers that cannot allocate -- no counterpart in the reference.  It is for code under
  * HIP graph capture, tight serving loops and harnesses that forbid hipMalloc: same arguments and results as
- * suave_decode_sample minus the workspace.  The decoder's activations and y_full (device memory beyond the inputs
- * and outputs) live in a file-scope device array of SUAVE_STATIC_SCRATCH_BYTES inside the library, one copy per
- * GPU, resolved once per device by suave_plan_create (hipGetSymbolAddress) and held until the process ends.  The
- * call makes no hipMalloc / hipFree and calls no allocating routine (with suave_profile_enable(1) the event pool may
- * grow: leave profiling off).  Rows are limited by the buffer: n * 4 * (ldD + sum of hidden widths + y_rows, each
- * rounded up to 4 floats and every array to 256 bytes) <= SUAVE_STATIC_SCRATCH_BYTES -- 14 979 rows for the
- * 64-column benchmark model; a larger n fails with an error that names the limit.  Every call on one GPU shares
- * that GPU's array, so calls that overlap on one GPU (two streams, two threads) race: serialise them.  The array
- * keeps the previous call's contents; no kernel of this path needs it cleared. */
+ * suave_decode_sample minus the workspace.  The call's scratch (device memory beyond the inputs and outputs) lives
+ * in a file-scope device array of SUAVE_STATIC_SCRATCH_BYTES inside the library, one copy per GPU, resolved once per
+ * device by suave_plan_create (hipGetSymbolAddress; if that fails the plan still works and only this entry point
+ * reports the missing address) and held until the process ends.  The call makes no hipMalloc / hipFree and calls no
+ * allocating routine (with suave_profile_enable(1) the event pool may grow: leave profiling off).
+ * What the scratch holds, and so the row limit, is what the library carves for the call (carve_decode, api.hip):
+ *   - component-index calls on a model inside the fused decode kernel's shapes (two hidden layers, no categorical
+ *     column above 16 classes, default arithmetic): the decoder's fp16 weight images only -- no per-row scratch, any n;
+ *   - every other call (dense assignments s, wide categorical columns, other depths): per row 4 bytes x (ldD + the
+ *     hidden widths + ldY, + ldL logits of the wide categorical columns when the schema has any), every array rounded
+ *     up to 256 bytes -- 14 979 rows for the 64-column benchmark model with dense assignments.
+ * suave_decode_static_max_rows returns the limit for a plan and a kind of call (dense_assignments: s will be
+ * non-NULL); a larger n fails with an error that names it.  Every call on one GPU shares that GPU's array, so calls
+ * that overlap on one GPU (two streams, two threads) race: serialise them.  The array keeps the previous call's
+ * contents; no kernel of this path needs it cleared. */
 #define SUAVE_STATIC_SCRATCH_BYTES (32u << 20)
 int suave_decode_sample_static(const suave_plan* plan, const float* params, const float* z, const float* s,
                                const int32_t* component, int64_t n, const float* noise_normal,
                                const float* noise_uniform, const float* noise_exp, uint64_t seed,
                                int64_t row_offset, void* stream, float* out_num, int32_t ld_num,
                                int16_t* out_codes, int32_t ld_disc, float* y_full_out);
+int suave_decode_static_max_rows(const suave_plan* plan, int32_t dense_assignments, int64_t* max_rows);
 
 /* Posterior draws for the Monte-Carlo predictive: SUAVE._posterior_draws
  * (model.py:3304-3336).  enc_out [n_rows, K+2KD] as written by suave_encode;
@@ -337,8 +344,10 @@ int suave_decode_params(const suave_plan* plan, const float* params, const float
  * as category codes (the mapping of labels to codes is pandas' and stays with the caller); ordinal columns as
  * numeric levels, out-of-range levels become missing.  rejected[c] (device, zeroed by the caller) counts the
  * values of column c that the reference rejects: pos < -1 and count < 0 (it raises ValueError), ordinal levels
- * outside [0, n_classes) (it warns and treats them as missing).  cols: DEVICE array of the plan's n_cols
- * descriptors in schema order. */
+ * outside [0, n_classes) (it warns and treats them as missing).  For a REAL column (which the reference never
+ * rejects) rejected[c] counts the finite cells whose normalised value exceeds 60 000 in magnitude: such a table is
+ * beyond the default arithmetic's fp16 planes and wants suave_gemm_arithmetic_set(3) (the Python host does that by
+ * itself and logs it).  cols: DEVICE array of the plan's n_cols descriptors in schema order. */
 #define SUAVE_RAW_F64 0
 #define SUAVE_RAW_F32 1
 #define SUAVE_RAW_I64 2

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Calibration: achievable HBM write / copy bandwidth with plain torch kernels."""
 import torch
 dev = torch.device("cuda:0")

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """End-to-end cost of the data formats either side of the path (f1 / f2) on the S64 schema: DataFrame -> packed table
 on the host (data.pack_frame + upload) against the device packer (data.pack_frame_device), and generated rows ->
 DataFrame through data.frame_from_packed (per-chunk .cpu() + pd.concat) against data.FrameAssembler.

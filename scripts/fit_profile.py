@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Where the wall time of SUAVE.fit goes on a 1 M x 64 table (cProfile, top entries by cumulative time).
 usage (through gpurun, repo root): python scripts/fit_profile.py [rows] [epochs]"""
 import cProfile, os, pstats, sys, time

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Tuning aid: time the fp32 MFMA GEMM on the S64 layer shapes through the debug entry point."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
-#!/usr/bin/env python3
-"""Tuning aid: one launch of each S64 GEMM shape (run under rocprofv3 --pmc ...)."""
+"""Tuning aid: one launch of each S64 GEMM shape.  Under the profiler the interpreter itself goes after `--`
+(`rocprofv3 --pmc ... -- python3 scripts/gemm_pmc.py`): no shebang / env hop after the GPU is initialised."""
 import os, sys
 sys.argv = [sys.argv[0]]
 os.environ.setdefault("GB", "65536")

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """What HBM gives plain streaming kernels on this box (torch fill / copy / sum on 1 GiB), for reading the step's
 per-kernel bandwidths against: python scripts/hbm_rates.py   (through gpurun)"""
 import torch

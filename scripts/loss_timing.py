@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Phase timing of the likelihood kernel (needs a build with SUAVE_EXTRA_FLAGS=-DSUAVE_LOSS_TIMING; debugging aid)."""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Summarise a rocprofv3 --pmc counter_collection CSV: per kernel (name + grid), mean of each counter over dispatches."""
 import csv, glob, sys, collections
 path = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob("gpurun_out/pmc*/**/*_counter_collection.csv", recursive=True))[-1]

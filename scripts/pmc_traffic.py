@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py`.
 
     python scripts/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> > profiles/r01_pmc_traffic.json

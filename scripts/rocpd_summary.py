@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Summarise rocprofv3's default rocpd SQLite output: per kernel mean duration, and mean of each PMC counter."""
 import collections, glob, sqlite3, sys
 paths = sys.argv[1:] or sorted(glob.glob("gpurun_out/**/*_results.db", recursive=True))[-1:]
@@ -33,7 +32,7 @@ for path in paths:
                 continue
             acc[disp[did][:2]][pmc.get(d.get("pmc_id"), "?")].append(d.get("value", 0.0))
         for k, dd in acc.items():
-            if any(w in k[0] for w in ("chain", "gemm", "loss", "sample", "k_")):
+            if any(w in k[0] for w in ("decode", "gemm", "loss", "sample", "k_")):
                 print(f"{k[0][:60]} blocks={k[1]}")
                 for cn, v in sorted(dd.items()):
                     print(f"    {cn:32s} {sum(v)/len(v):18.1f} (n={len(v)})")

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Gradient / ELBO-term error of the HIP step against the numpy oracle on the S64 schema, for the current
 SUAVE_GEMM_SPLIT mode: prints the worst err / scale over all parameter tensors (the parity bar is 1e-4)."""
 import os, sys

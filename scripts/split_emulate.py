@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """CPU emulation of the split-precision GEMM arithmetics on the REAL tensors of an S64 ELBO step: every `@` of the
 numpy oracle (forward, data gradients, weight gradients) is replaced by the plane products a candidate MFMA path
 would run, and the resulting gradients are compared with the plain fp32 oracle the parity tests use (bar: 1e-4 of

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Print the per-kernel timeline of the last training step from a rocprofv3 --kernel-trace CSV."""
 import csv, glob, sys
 path = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob("gpurun_out/prof*/**/*_kernel_trace.csv", recursive=True))[-1]

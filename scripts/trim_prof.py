@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Condense a rocprofv3 --kernel-trace --stats kernel_stats.csv into profiles/<name>.csv (library kernels in
 full, everything else summed into one 'other (torch plumbing: table synthesis, randperm)' line)."""
 import csv, sys

@@ -1295,7 +1295,7 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
       return dfail("plan_create: hipMalloc/hipMemcpy of the embedding table failed");
     if (round_up(m.enc[0].n_out, 4) > 1024) return fail("plan_create: first hidden layer wider than 1024 with embedded columns");
   }
-  if (int rc = resolve_static_scratch(p)) { suave_plan_destroy(p); return rc; }
+  resolve_static_scratch(p);  // (a failure leaves static_scratch null: only suave_decode_sample_static needs it, and says so)
   *out = p;
   return 0;
 }
@@ -1550,12 +1550,35 @@ static __device__ __align__(256) unsigned char scratch[SUAVE_STATIC_SCRATCH_BYTE
 namespace suave {
 int resolve_static_scratch(suave_plan* p) {
   void* ptr = nullptr;
-  SUAVE_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
-  SUAVE_REQUIRE(ptr != nullptr && (reinterpret_cast<uintptr_t>(ptr) & 255) == 0, "static scratch: bad device address");
+  p->static_scratch = nullptr;
+  if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess) {
+    (void)hipGetLastError();  // the plan works without it; suave_decode_sample_static reports the null address
+    return 1;
+  }
+  if (ptr == nullptr || (reinterpret_cast<uintptr_t>(ptr) & 255) != 0) return 1;
   p->static_scratch = ptr;
   return 0;
 }
 }  // namespace suave
+
+extern "C" int suave_decode_static_max_rows(const suave_plan* p, int32_t dense_assignments, int64_t* max_rows) {
+  SUAVE_REQUIRE(p != nullptr && max_rows != nullptr, "decode_static_max_rows: null argument");
+  DecodeScratch d;
+  const float* dense = dense_assignments ? reinterpret_cast<const float*>(p) : nullptr;  // (only tested against null)
+  const bool fused = decode_takes_fused(p, dense);
+  const int64_t cap = (int64_t(1) << 31) - 1;  // (n is an int inside the kernels)
+  if (carve_decode(p, 1, nullptr, &d, fused) > (size_t)SUAVE_STATIC_SCRATCH_BYTES) { *max_rows = 0; return 0; }
+  int64_t lo = 1, hi = cap;  // carve_decode is non-decreasing in the row count
+  while (lo < hi) {
+    const int64_t mid = lo + (hi - lo + 1) / 2;
+    if (carve_decode(p, mid, nullptr, &d, fused) <= (size_t)SUAVE_STATIC_SCRATCH_BYTES) lo = mid;
+    else hi = mid - 1;
+  }
+  *max_rows = lo;
+  return 0;
+}
+
+extern "C" int suave_decode_static_max_rows(const suave_plan* p, int32_t dense_assignments, int64_t* max_rows);
 
 extern "C" int suave_decode_sample_static(const suave_plan* p, const float* params, const float* z, const float* s_dense,
                                           const int32_t* component, int64_t n, const float* noise_normal,
@@ -1573,10 +1596,12 @@ extern "C" int suave_decode_sample_static(const suave_plan* p, const float* para
   const bool fused = decode_takes_fused(p, s_dense);
   const size_t need = carve_decode(p, n, p->static_scratch, &d, fused);
   if (need > (size_t)SUAVE_STATIC_SCRATCH_BYTES) {
-    const size_t per_row = carve_decode(p, 4096, nullptr, &d, fused) / 4096 + 1;
+    int64_t fit = 0;
+    suave_decode_static_max_rows(p, s_dense != nullptr, &fit);
     set_error("decode_sample_static: " + std::to_string((long long)n) + " rows need " + std::to_string(need) +
               " bytes of scratch, the static buffer holds " + std::to_string((size_t)SUAVE_STATIC_SCRATCH_BYTES) +
-              " (about " + std::to_string((size_t)SUAVE_STATIC_SCRATCH_BYTES / per_row) + " rows of this model); split the request");
+              " (" + std::to_string((long long)fit) + " rows of this model and this kind of call: suave_decode_static_max_rows); "
+              "split the request");
     return 1;
   }
   return decode_sample_impl(p, params, z, s_dense, component, (int)n, noise_normal, noise_uniform, noise_exp, seed,

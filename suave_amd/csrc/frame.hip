@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void k_pack_columns(const suave_pack_col_t* __
           double v;
           if (col.kind == SUAVE_TYPE_REAL) {
             v = (x - col.a) / fmax(col.b, kEps);
+            if (fabs(v) > 60000.0 && isfinite(v)) ++bad_here;  // not rejected: counted (beyond the fp16 planes' range)
           } else if (col.kind == SUAVE_TYPE_POS) {
             if (x < -1.0 + kEps) ++bad_here;  // the reference raises: must be >= -1 to apply log1p
             v = (log1p(x) - col.a) / fmax(col.b, kEps);

@@ -276,9 +276,11 @@ def _raw_array(series: pd.Series) -> Tuple[np.ndarray, int]:
 
 
 def pack_frame_device(X: pd.DataFrame, schema: Schema, stats: Mapping[str, Mapping[str, object]], engine,
-                      chunk_rows: int = 1 << 22):
+                      chunk_rows: int = 1 << 22, info: Optional[Dict[str, int]] = None):
     """``pack_frame`` on the GPU: returns ``(xnum, codes, mask)`` as device tensors, same values (the float64
-    normalisation arithmetic runs in the kernel; log1p / log may differ from numpy's in the last float32 bit)."""
+    normalisation arithmetic runs in the kernel; log1p / log may differ from numpy's in the last float32 bit).
+    ``info`` (optional dict) receives ``beyond_fp16``: the number of real cells whose normalised value exceeds 60 000
+    in magnitude (the packer's counter of real columns) -- such a table needs ``suave_gemm_arithmetic_set(3)``."""
 
     import torch
 
@@ -337,6 +339,8 @@ def pack_frame_device(X: pd.DataFrame, schema: Schema, stats: Mapping[str, Mappi
         torch.cuda.current_stream(dev).synchronize()  # the raw columns may go now
         del keep
     rej = rejected.cpu().numpy()
+    if info is not None:
+        info["beyond_fp16"] = int(sum(int(rej[j]) for j, column in enumerate(names) if schema[column].type == "real"))
     for j, column in enumerate(names):
         t = schema[column].type
         if t == "pos" and rej[j]:
@@ -394,8 +398,15 @@ class FrameAssembler:
         nb = int(out_num.shape[0]) if out_num.numel() else int(out_codes.shape[0])
         self.engine.unpack_columns(self.desc, self.n_out, nb, out_num, out_codes, self.dev, self.chunk_rows)
         for h, d in zip(self.host, self.dev):
-            if h.shape[0]:
-                h[:, start:start + nb].copy_(d[: h.shape[0], :nb], non_blocking=True)
+            if not h.shape[0]:
+                continue
+            if nb == self.n and nb == self.chunk_rows:  # one chunk: both sides are whole, contiguous blocks
+                h.copy_(d[: h.shape[0]], non_blocking=True)
+                continue
+            # a chunk of a larger request: [columns, nb] is a strided window of both blocks, which torch would stage
+            # through a pageable temporary; one column's rows are contiguous on both sides -- a plain async DMA each
+            for r in range(h.shape[0]):
+                h[r, start:start + nb].copy_(d[r, :nb], non_blocking=True)
 
     def frame(self) -> pd.DataFrame:
         import torch

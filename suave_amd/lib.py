@@ -32,6 +32,7 @@ EXPORTS = (
     "suave_posterior_draws",
     "suave_encode_hard",
     "suave_rng_draws",
+    "suave_decode_static_max_rows",
     "suave_head_params_width",
     "suave_decode_params",
     "suave_decode_log_px",
@@ -91,6 +92,7 @@ def load():
     lib.suave_encode.argtypes = [vp, vp, C.POINTER(BatchT), f32, vp, sz, vp, vp, vp, vp, vp]
     lib.suave_encode_hard.argtypes = [vp, vp, C.POINTER(BatchT), f32, vp, sz, vp, vp, vp]
     lib.suave_rng_draws.argtypes = [vp, i64, vp, vp, vp, vp]
+    lib.suave_decode_static_max_rows.argtypes = [vp, i32, C.POINTER(C.c_int64)]
     lib.suave_prior_latents.argtypes = [vp, vp, vp, vp, vp, u64, i64, i64, vp, vp, vp]
     lib.suave_conditional_latents.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, i64, i64, vp, vp, vp]
     lib.suave_decode_sample.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, u64, i64, vp, sz, vp, vp, i32, vp, i32, vp]

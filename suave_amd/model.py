@@ -44,6 +44,10 @@ _REFINE_MODES = ("decoder_only", "decoder_prior", "prior_em_only", "prior_em_dec
 _ROW_CHUNK = 262144  # rows per device call of the inference methods (bounds the workspace; results do not depend on it)
 
 
+class _NonFiniteSums(Exception):
+    """An epoch of the first attempt of ``fit`` gave non-finite ELBO sums on the fp16-plane arithmetic."""
+
+
 class DrawReplay:
     """Recorded draws of a reference run, consumed in call order by the training phases (parity tests): the
     per-epoch permutations and, per ELBO call (training batches and validation batches alike), the Exp(1) draws
@@ -237,6 +241,31 @@ class SUAVE:
         if dp is not None:
             dp.reduce_gradients(self._engine.grads)
 
+    @staticmethod
+    def _arithmetic() -> int:
+        import ctypes as C
+
+        from . import lib as _lib
+
+        mode = C.c_int(0)
+        _lib.check(_lib.load().suave_gemm_arithmetic_get(C.byref(mode)), "suave_gemm_arithmetic_get")
+        return int(mode.value)
+
+    def _use_wide_arithmetic(self, why: str) -> bool:
+        """Switch the library's matrix products from the default two fp16 planes per operand (range 65504) to three
+        bf16 planes (fp32's exponent range, ~1.6x slower products) -- for the whole process, like
+        ``suave_gemm_arithmetic_set``; logged once.  False when the arithmetic was not the default one (nothing to do)."""
+
+        from . import lib as _lib
+
+        if self._arithmetic() != 4:
+            return False
+        _lib.check(_lib.load().suave_gemm_arithmetic_set(3), "suave_gemm_arithmetic_set")
+        warnings.warn(f"{why}: matrix products switched from two fp16 planes to three bf16 planes for this process "
+                      "(suave_gemm_arithmetic_set(3)); results keep the 1e-4 parity bar, products run ~1.6x slower",
+                      RuntimeWarning, stacklevel=3)
+        return True
+
     def _select_device(self) -> torch.device:
         if self._device is not None:
             return torch.device(self._device)
@@ -254,7 +283,11 @@ class SUAVE:
     def _pack(self, X: pd.DataFrame):
         """DataFrame -> packed table columns on the device (normalisation fused: ``suave_pack_columns``)."""
 
-        return data_utils.pack_frame_device(X, self.schema, self._norm_stats_per_col, self._engine)
+        info: Dict[str, int] = {}
+        out = data_utils.pack_frame_device(X, self.schema, self._norm_stats_per_col, self._engine, info=info)
+        if info.get("beyond_fp16", 0):
+            self._use_wide_arithmetic(f"{info['beyond_fp16']} normalised cells exceed fp16's range")
+        return out
 
     def _table(self, X: pd.DataFrame, *, row_base: int = 0, n_global: Optional[int] = None) -> PackedTable:
         xnum, codes, mask = self._pack(X.reset_index(drop=True))
@@ -381,6 +414,38 @@ class SUAVE:
                 raise RuntimeError("recorded draws (parity tests) are per batch row and cannot be replayed on sharded batches")
             if not self._sharded:
                 self._dp.check_replicated(train.mask, train.xnum, train.codes)
+        # The schedule runs once; if an epoch's ELBO sums come out non-finite under the default arithmetic (two fp16
+        # planes per operand: an activation or scaled gradient beyond 65504 overflows where the reference's fp32 does
+        # not), the arithmetic is switched to three bf16 planes (fp32's exponent range) and the schedule runs again
+        # from the same initial state and seeds.  The sums are all-reduced, so every rank takes the same decision.
+        for _attempt in (0, 1):
+            self._nonfinite = False
+            self._head_batch = 0
+            self._val_calls = 0
+            self._abort_on_nonfinite = _attempt == 0 and self._replay is None and self._arithmetic() == 4
+            if _attempt:
+                eng.load_state(self._layout.init_params(seed=self.random_state))
+            try:
+                self._run_schedule(train, val, y_train_t, y_val_t, class_weights, n_epochs, n_head, n_joint, n_refine, bs,
+                                   kl_epochs, lr_scale, patience)
+            except _NonFiniteSums:
+                self._use_wide_arithmetic("an epoch of the fit produced non-finite ELBO sums")
+                continue
+            break
+        if self._nonfinite:
+            warnings.warn("non-finite ELBO sums during fit (not an overflow of the fp16 planes: the matrix products "
+                          "run, or were re-run, on an arithmetic with fp32's exponent range)", RuntimeWarning, stacklevel=2)
+        self._cache_training_statistics(train, bs)
+        self._temperature_scaler = sup.TemperatureScaler()
+        self._is_calibrated = False
+        self._is_fitted = True
+        return self
+
+    def _run_schedule(self, train, val, y_train_t, y_val_t, class_weights, n_epochs, n_head, n_joint, n_refine, bs,
+                      kl_epochs, lr_scale, patience) -> None:
+        """The staged schedule on packed tables, from freshly initialised parameters (model.py:1168-1380)."""
+
+        eng = self._engine
         self._gen = torch.Generator(device=eng.device)
         self._gen.manual_seed(self.random_state)
         self._step = 0
@@ -404,11 +469,6 @@ class SUAVE:
             self._refine_decoder(train, val, n_refine, bs, patience)
         else:
             self._joint_val_metrics = self._warmup_val_history[-1] if self._warmup_val_history else None
-        self._cache_training_statistics(train, bs)
-        self._temperature_scaler = sup.TemperatureScaler()
-        self._is_calibrated = False
-        self._is_fitted = True
-        return self
 
     def _map_targets(self, values) -> np.ndarray:
         """model.py `_map_targets_to_indices`: labels -> class indices, unknown labels raise."""
@@ -478,15 +538,14 @@ class SUAVE:
 
     def _epoch_sums(self) -> np.ndarray:
         """The epoch's (sum reconstruction, sum categorical KL, sum Gaussian KL, rows) over all ranks: one host sync.
-        A non-finite sum is reported once (the reference keeps training on NaNs silently): with the default GEMM
-        arithmetic an activation or scaled gradient beyond fp16's range (65504) is the first thing to rule out."""
+        A non-finite sum is recorded (``fit`` then repeats the schedule on the wide arithmetic, see there; the
+        reference keeps training on NaNs silently)."""
 
         s = self._all_reduce(self._engine.sums).cpu().numpy()
-        if not np.all(np.isfinite(s)) and not getattr(self, "_warned_nonfinite", False):
-            self._warned_nonfinite = True
-            warnings.warn("non-finite ELBO sums during fit; if the data or the activations exceed fp16's range, rerun "
-                          "with SUAVE_GEMM_SPLIT=3 (three bf16 planes: fp32's exponent range, slower matrix products)",
-                          RuntimeWarning, stacklevel=3)
+        if not np.all(np.isfinite(s)):
+            self._nonfinite = True
+            if getattr(self, "_abort_on_nonfinite", False):
+                raise _NonFiniteSums()
         return s
 
     def _posterior_mean(self, table: PackedTable) -> torch.Tensor:

@@ -174,8 +174,9 @@ def load_archive(path) -> Dict[str, Any]:
         try:
             with torch.serialization.safe_globals(safe):
                 return torch.load(path, map_location="cpu", weights_only=True)
-        except Exception:  # noqa: BLE001
-            raise ValueError(f"Unexpected model archive format: {first}") from first
+        except Exception as second:  # noqa: BLE001 - the retry's error is the informative one (model.py:4669-4674 chains it too)
+            raise ValueError(f"Unexpected model archive format: {second} (first attempt, without numpy's array types "
+                             f"allow-listed: {first})") from second
 
 
 def tree(obj, prefix: str = "") -> Dict[str, str]:

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Generate golden vectors from the UNTOUCHED reference (build container only).
 
 Usage (from the repo root, in the container that has /root/reference)::

@@ -122,3 +122,72 @@ def test_device_frame_assembly_matches_the_host_path(n, chunk):
     for c in names:
         assert got[c].dtype == ref[c].dtype, c
     pd.testing.assert_frame_equal(got, ref)
+
+
+def test_device_packer_on_the_reference_tensorise_fixture():
+    """Row f1 against REFERENCE data, not product code: the raw frame of tests/golden/tensorise_mixed8.npz through
+    ``suave_pack_columns`` must give the encoder inputs the reference's standardize -> _apply_training_normalization ->
+    _prepare_training_tensors produced (data.py:133-266, model.py:3116-3213, 2784-2922)."""
+
+    import json
+
+    from oracle import suave_oracle as orc
+    from suave_amd import data as du
+    from suave_amd.types import Schema
+    from tests.helpers import load_golden
+
+    fx = load_golden("tensorise_mixed8")
+    schema = Schema(json.loads(str(fx["schema"])))
+    X = pd.DataFrame({k[len("raw/"):]: fx[k] for k in fx if k.startswith("raw/")})[list(schema.feature_names)]
+    stats = json.loads(str(fx["stats"]))  # the reference's own statistics
+    eng = _engine(schema, stats)
+    for chunk in (1 << 22, 16):
+        xd, cd, md = du.pack_frame_device(X, schema, stats, eng, chunk_rows=chunk)
+        cols = [orc.Column(n, schema[n].type, schema[n].n_classes, schema[n].y_dim, stats[n]) for n in schema.feature_names]
+        om = orc.OracleModel(cols, n_components=2, latent_dim=4, hidden=(8,))
+        x_enc, _, _ = orc.dense_from_packed(om, xd.cpu().numpy(), cd.cpu().numpy(), md.cpu().numpy())
+        np.testing.assert_allclose(x_enc, fx["enc_inputs"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("pre", ["supervised/sample/", "unsupervised/sample/", "cond_sample/"])
+def test_device_frame_assembly_on_the_reference_sample_frames(pre):
+    """Row f2 against REFERENCE data: the frames SUAVE.sample returned in tests/golden/generation_mixed7.npz (values of
+    sampling.decoder_outputs_to_frame, sampling.py:138-179), written back into the decode kernels' output layout and
+    sent through ``suave_unpack_columns`` + FrameAssembler, must come back as the same frames: values, dtypes,
+    category lists and orderedness."""
+
+    import json
+
+    import torch
+    from suave_amd import data as du
+    from suave_amd.types import Schema
+    from tests.helpers import load_golden
+
+    fx = load_golden("generation_mixed7")
+    cols = json.loads(str(fx["columns"]))
+    spec = {c["name"]: {"type": c["type"], **({"n_classes": c["n_classes"]} if c.get("n_classes") else {})} for c in cols}
+    schema = Schema(spec)
+    stats = json.loads(str(fx[("supervised/" if pre == "cond_sample/" else pre.split("/")[0] + "/") + "stats"]))
+    eng = _engine(schema, stats)
+    names = list(schema.feature_names)
+    num = [c for c in names if schema[c].type in ("real", "pos", "count")]
+    disc = [c for c in names if c not in num]
+    n = len(fx[pre + f"frame/{names[0]}"])
+    out_num = np.stack([fx[pre + f"frame/{c}"].astype(np.float32) for c in num], axis=1)
+    out_codes = np.stack([fx[pre + f"frame/{c}"].astype(np.int16) for c in disc], axis=1)
+    for chunk in (n, 17):
+        asm = du.FrameAssembler(schema, stats, eng, n, chunk)
+        on, oc = torch.from_numpy(out_num).to(eng.device), torch.from_numpy(out_codes).to(eng.device)
+        for s0 in range(0, n, chunk):
+            asm.add(s0, on[s0:s0 + chunk].contiguous(), oc[s0:s0 + chunk].contiguous())
+        got = asm.frame()
+        assert list(got.columns) == names
+        for c in names:
+            v, ref = got[c], fx[pre + f"frame/{c}"]
+            assert str(v.dtype) == str(fx[pre + f"dtype/{c}"]), c
+            if c in num:
+                assert np.array_equal(v.to_numpy(), ref), c
+            else:
+                assert np.array_equal(np.asarray(v.cat.codes, np.int64), ref), c
+                assert [str(x) for x in v.cat.categories] == list(fx[pre + f"categories/{c}"]), c
+                assert bool(v.cat.ordered) == bool(fx[pre + f"ordered/{c}"]), c

@@ -126,7 +126,9 @@ def test_supervised_schedule_classifier_and_persistence(refine_mode, tmp_path):
     with pytest.raises(ValueError):
         model.predict_confidence_interval(sub, "sex")
     masked = sub.copy()
-    masked["age"] = 1e6  # the attribute is always decoded as missing: its value must not matter
+    # the attribute is always decoded as missing: its value must not matter (1e6 would be beyond the fp16 planes after
+    # normalisation and switch the arithmetic: test_values_beyond_fp16_switch_the_arithmetic_instead_of_returning_nan)
+    masked["age"] = 1e5
     a = model.predict_confidence_interval(sub, "age", L=32)["point"]
     b = model.predict_confidence_interval(masked, "age", L=32)["point"]
     assert torch.equal(a, b)
@@ -227,3 +229,79 @@ def test_m20_shaped_fit_with_reference_defaults():
     finally:
         sm._ROW_CHUNK = old
     assert pp.shape == (600, 5) and np.allclose(pp.sum(1), 1.0, atol=1e-5)
+
+
+@pytest.fixture
+def restore_arithmetic():
+    import ctypes as C
+
+    from suave_amd import lib as slib
+
+    L = slib.load()
+    before = C.c_int(0)
+    slib.check(L.suave_gemm_arithmetic_get(C.byref(before)), "suave_gemm_arithmetic_get")
+    yield L
+    slib.check(L.suave_gemm_arithmetic_set(before.value), "suave_gemm_arithmetic_set")
+
+
+def test_values_beyond_fp16_switch_the_arithmetic_instead_of_returning_nan(restore_arithmetic):
+    """The default matrix arithmetic splits every operand into two fp16 planes (range 65504).  A cell whose normalised
+    value is beyond that (new data far outside the training range) would come back as NaN where the reference's fp32
+    returns numbers: the packer counts such cells and the model switches the process to the three-bf16-plane
+    arithmetic (fp32's exponent range), once, with a warning."""
+
+    from suave_amd.model import SUAVE
+
+    df, _ = _frame(600, seed=4)
+    model = SUAVE(_schema(), behaviour="unsupervised", latent_dim=8, n_components=3, hidden_dims=(32, 16), batch_size=128,
+                  random_state=0).fit(df, epochs=2)
+    assert SUAVE._arithmetic() == 4
+    far = df.iloc[:50].copy()
+    far.loc[far.index[3], "age"] = 5.0e6   # ~6e5 standard deviations
+    with pytest.warns(RuntimeWarning, match="three bf16 planes"):
+        z = model.encode(far)
+    assert SUAVE._arithmetic() == 3
+    assert np.isfinite(z).all()
+    ref = model.encode(df.iloc[:50])
+    keep = np.arange(50) != 3
+    assert np.allclose(z[keep], ref[keep], rtol=1e-4, atol=1e-5)  # the other rows: same numbers on the other arithmetic
+    imp = model.impute(far)
+    assert imp.isna().sum().sum() == 0
+
+
+def test_nonfinite_epoch_on_the_fp16_planes_reruns_the_schedule_on_the_wide_arithmetic(restore_arithmetic, monkeypatch):
+    """fit: non-finite ELBO sums under the default arithmetic abort the schedule, switch the arithmetic and run it
+    again from the same initial state and seeds -- the result is bit for bit the fit a caller gets who selected that
+    arithmetic up front.  (The overflow itself is simulated: the epoch sums are poisoned while the fp16 planes are on.)"""
+
+    import ctypes as C
+
+    import torch
+    from suave_amd import lib as slib
+    from suave_amd.model import SUAVE
+
+    df, g = _frame(500, seed=5)
+    kw = dict(behaviour="supervised", latent_dim=8, n_components=2, hidden_dims=(32, 16), batch_size=128, random_state=3)
+    fitkw = dict(epochs=2, head_epochs=1, finetune_epochs=1, decoder_refine_epochs=1)
+    orig = SUAVE._all_reduce
+    calls = {"poisoned": 0}
+
+    def poisoned(self, t):
+        out = orig(self, t)
+        if SUAVE._arithmetic() == 4 and t is self._engine.sums:
+            calls["poisoned"] += 1
+            return out * float("nan")
+        return out
+
+    monkeypatch.setattr(SUAVE, "_all_reduce", poisoned)
+    with pytest.warns(RuntimeWarning, match="non-finite ELBO sums: matrix products switched|switched from two fp16"):
+        m1 = SUAVE(_schema(), **kw).fit(df, y=g, **fitkw)
+    assert calls["poisoned"] == 1 and SUAVE._arithmetic() == 3
+    assert all(np.isfinite(list(h.values())).all() for h in m1._train_history)
+    monkeypatch.setattr(SUAVE, "_all_reduce", orig)
+    m2 = SUAVE(_schema(), **kw).fit(df, y=g, **fitkw)  # arithmetic 3 from the start
+    assert torch.equal(m1._engine.params, m2._engine.params)
+    for a, b in zip(m1._classifier.parameters(), m2._classifier.parameters()):
+        assert torch.equal(a, b)
+    slib.check(restore_arithmetic.suave_gemm_arithmetic_set(4), "suave_gemm_arithmetic_set")
+    assert SUAVE._arithmetic() == 4

@@ -88,7 +88,16 @@ def test_static_decode_rejects_oversized_requests_and_accepts_empty():
     s = torch.full((n, 10), 0.1, device=eng.device)
     with pytest.raises(slib.SuaveHipError, match="static buffer holds"):
         eng.decode_sample_static(z, out_num, out_codes, assignments=s)
-    eng.decode_sample_static(z[:14000], out_num, out_codes, assignments=s[:14000])  # within the limit
+    import ctypes as C
+
+    fit = C.c_int64(-1)
+    slib.check(eng.lib.suave_decode_static_max_rows(eng._plan, 1, C.byref(fit)), "suave_decode_static_max_rows")
+    assert 14000 <= fit.value < n  # (include/suave_hip.h: 14 979 for this model)
+    eng.decode_sample_static(z[:fit.value], out_num, out_codes, assignments=s[:fit.value])  # exactly the limit
+    with pytest.raises(slib.SuaveHipError, match=f"\\({fit.value} rows of this model"):
+        eng.decode_sample_static(z[:fit.value + 1], out_num, out_codes, assignments=s[:fit.value + 1])
+    slib.check(eng.lib.suave_decode_static_max_rows(eng._plan, 0, C.byref(fit)), "suave_decode_static_max_rows")
+    assert fit.value >= n
     # component indices take the fused kernel: the buffer only holds the weight images, any row count goes
     eng.decode_sample_static(z, out_num, out_codes, component=comp)
     eng.decode_sample_static(z[:0], out_num, out_codes, component=comp)      # empty request
