@@ -7,8 +7,8 @@ set -e -o pipefail
 R=${1:-r02}
 O=gpurun_out
 export TMPDIR=/tmp
-RAW="$O/${R}_stats $O/${R}_stats_train $O/${R}_fetch $O/${R}_write $O/${R}_fetch_t $O/${R}_write_t $O/${R}_tl_s64 $O/${R}_tl_w"
-trap 'rm -rf $RAW' EXIT  # the raw traces exceed what gpurun copies back
+RAW="$O/${R}_stats $O/${R}_stats_train $O/${R}_fetch $O/${R}_write $O/${R}_fetch_t $O/${R}_write_t $O/${R}_tl_s64 $O/${R}_tl_w $O/${R}_fetch_w $O/${R}_write_w $O/${R}_pmc_sq"
+trap 'echo "exit status $? at line $LINENO"; rm -rf $RAW' EXIT  # the raw traces exceed what gpurun copies back
 rm -rf $O/${R}_stats $O/${R}_stats_train $O/${R}_fetch $O/${R}_write $O/${R}_fetch_t $O/${R}_write_t $O/${R}_tl_s64 $O/${R}_tl_w
 echo "[1/9] kernel stats, default command"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/${R}_stats --output-format csv -o bench -- python bench.py > $O/${R}_bench_stats.log 2>&1

@@ -185,16 +185,22 @@ def phase_record(fx, pre):
 
 def update_close(new, old, ref_new, ref_old, lr, n_steps, what=""):
     """Parameters after a few Adam steps against the reference's.  Adam normalises the gradient, so an entry whose
-    gradient is within the 1e-4 gradient tolerance of zero may move by up to lr per step in either direction; all
-    others must agree closely: at most 2 % of the entries may differ by more than 2 % of the largest update, and
-    none by more than the trust region 2 * lr * n_steps."""
+    gradient is within the 1e-4 gradient tolerance of zero may move by up to lr per step in either direction: at most
+    0.1 % of the entries may differ by more than 0.2 % of the largest update (observed on MI355X: none, largest
+    difference 4e-6 of the largest update), and none by more than the trust region 2 * lr * n_steps.  The typical
+    size of the large updates must be the reference's to 1 % -- a tensor stepped with another group's learning rate
+    (the joint phase has four, model.py:1894-1909) is off by the ratio of the rates."""
 
     d = np.asarray(new, np.float64) - np.asarray(old, np.float64)
     dr = np.asarray(ref_new, np.float64) - np.asarray(ref_old, np.float64)
     err = np.abs(d - dr)
     scale = max(float(np.abs(dr).max()), 1e-12)
     assert float(err.max()) <= 2.0 * lr * n_steps + 1e-7, (what, float(err.max()))
-    assert float((err > 0.02 * scale).mean()) <= 0.02, (what, float((err > 0.02 * scale).mean()))
+    assert float((err > 0.002 * scale + 1e-7).mean()) <= 0.001, (what, float((err > 0.002 * scale).mean()))
+    big = np.abs(dr) > 0.25 * scale
+    if big.any() and scale > 1e-7:
+        ratio = float(np.median(np.abs(d[big]) / np.abs(dr[big])))
+        assert abs(ratio - 1.0) <= 0.01, (what, ratio)
 
 
 # ---------------------------------------------------------------------------

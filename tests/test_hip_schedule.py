@@ -7,8 +7,8 @@ reference ran itself (tests/golden/phases_mixed7.npz, written by tests/golden/ma
 * `_closed_form_prior_update_from_stats` (:2447-2495).
 
 `suave_amd.SUAVE`'s own phase methods run on the HIP step with the recorded permutations and draws
-(`DrawReplay`); the gradient of EVERY optimisation step is compared with the reference's (1e-4 at the first step,
-1e-3 once the parameters have drifted by rounding), then the parameters after the phase.
+(`DrawReplay`); the gradient of EVERY optimisation step is compared with the reference's to 1e-4, then the
+parameters after the phase (helpers.update_close: 0.2 % of the largest update, learning-rate group by group).
 """
 
 import json
@@ -60,7 +60,7 @@ def _check_phase(m, rec, lr_of, n_opt, frozen):
         got = lay.unpack(flat.cpu().numpy())
         ref_g = {k: v for k, v in ref_g.items() if not k.startswith("clf.")}
         gmax = max(float(np.abs(v).max()) for v in ref_g.values())
-        tol = TOL if t == 0 else 10 * TOL
+        tol = TOL  # every step, also after the parameters have drifted (observed on MI355X: <= 2.1e-6 at all steps)
         for k, v in ref_g.items():
             err = float(np.abs(got[k].reshape(v.shape) - v).max())
             assert err <= tol * max(float(np.abs(v).max()), 1e-3 * gmax) + 1e-7, (t, k, err)
