@@ -209,6 +209,58 @@ int suave_elbo_backward_overlap(const suave_plan* plan, const float* params, con
                                 const suave_elbo_out_t* out, float* grads, const float* dlatent,
                                 void* decoder_ready_event);
 
+/* ---- the classifier head of behaviour="supervised" (row f4) -------------------------------------------------
+ * ClassificationHead without hidden layers (suave/modules/heads.py:62-91: dropout on the latent inputs, one
+ * nn.Linear, class-weighted F.cross_entropy) evaluated by the library, so that neither the head phase
+ * (_train_head_phase, model.py:1743-1864) nor the joint step (model.py:1973-1999) leaves the stream for an
+ * autograd framework.  Heads with hidden layers stay with the caller (suave_elbo_backward's dlatent).
+ * C = n_classes in 2..64, D = latent_dim <= 256.  params = linear.weight [C, D] row-major followed by
+ * linear.bias [C].  targets holds the class index of every TABLE row and is addressed by row id (batch row_index /
+ * row_begin + i), like the packed table.  The loss of a call is CE = sum_i w[y_i] ce_i / weight_sum with
+ * weight_sum = sum_i w[y_i] over the call's rows, or *weight_sum when given (data parallelism: the sum over the
+ * GLOBAL batch, so that rank gradients add up to the one-GPU gradient).  Outputs: grads (if not NULL) =
+ * loss_scale * d CE / d params; *loss_sum (if not NULL) += CE * loss_rows (the reference's
+ * `epoch_loss += loss.item() * batch_count`, model.py:1802).  adam_lr > 0 applies torch.optim.Adam's update
+ * (defaults betas (0.9, 0.999), eps 1e-8; adam_step 1-based) to params in the same launch that sums the gradient.
+ * Dropout (training != 0) keeps input d of table row r when hash(r, dropout_key, d) >= dropout -- a stateless
+ * lowbias32 hash, the same on every rank and for every sharding of a batch (suave_amd/supervised.py
+ * RowKeyedDropout is its torch statement).  workspace: suave_head_workspace_bytes(C, D) bytes of device memory. */
+typedef struct {
+  int32_t n_classes;
+  int32_t training;
+  float* params;
+  float* grads;
+  const float* class_weight; /* [C] or NULL (unweighted) */
+  const int32_t* targets;
+  const float* weight_sum;   /* device scalar or NULL */
+  float loss_scale;
+  float loss_rows;
+  double* loss_sum;          /* device scalar or NULL */
+  float dropout;
+  uint64_t dropout_key;
+  float adam_lr;
+  int64_t adam_step;
+  float* adam_m;
+  float* adam_v;
+  void* workspace;
+  size_t workspace_bytes;
+} suave_head_t;
+int suave_head_workspace_bytes(int32_t n_classes, int32_t latent_dim, size_t* bytes);
+
+/* One step of the head phase on cached latents: row i of the batch is table row rid = row_index[i] (or
+ * row_begin + i) and reads latent[rid * ld .. + D) and targets[rid].  logits_out [n, C] optional. */
+int suave_head_step(const suave_head_t* head, int32_t latent_dim, const float* latent, int32_t ld,
+                    const int32_t* row_index, int64_t row_begin, int64_t n, void* stream, float* logits_out);
+
+/* The joint fine-tuning step in one pass (model.py:1973-1999: loss = ELBO loss + weight * CE(classifier(latent)),
+ * one backward): suave_elbo_backward_overlap with the head's cross-entropy evaluated on the step's own `latent`
+ * between the decoder and the encoder backward -- head->loss_scale * d CE / d latent joins the latent gradient,
+ * head->grads receives the head's gradient.  Supervised branch only; decoder_ready_event may be NULL. */
+int suave_elbo_joint_backward(const suave_plan* plan, const float* params, const suave_batch_t* batch,
+                              const suave_noise_t* noise, float beta_scale, float tau, int64_t global_rows,
+                              void* workspace, size_t workspace_bytes, void* stream, const suave_elbo_out_t* out,
+                              float* grads, const suave_head_t* head, void* decoder_ready_event);
+
 /* Decoder.forward's per-column log-likelihoods at a GIVEN latent (decoder.py:333-379 as called by the reference's
  * decode-side code and tests): y_full = trunk(z), then every head scores the batch's cells with the row's
  * component as the assignment one-hot.  log_px / log_px_missing: [n, n_cols], laid out as the fields of that name in the ELBO output struct (either may

@@ -711,7 +711,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
 int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* batch, const suave_noise_t* noise,
               float beta_scale, float tau, int training, int64_t global_rows, void* workspace,
               size_t workspace_bytes, hipStream_t s, const suave_elbo_out_t* out, float* grads, const float* dlatent,
-              hipEvent_t ready_event = nullptr) {
+              hipEvent_t ready_event = nullptr, const suave_head_t* head = nullptr) {
   SUAVE_REQUIRE(p != nullptr && params != nullptr, "plan/params is null");
   if (int rc = check_batch(p, batch)) return rc;
   const suave_model_t& m = p->model;
@@ -719,8 +719,12 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
   SUAVE_REQUIRE(global_rows >= 1, "global_rows must be positive");
   t_grad_scale = grad_scale_for(global_rows);
   GemmSmallScope small_scope;
+  SUAVE_REQUIRE(head == nullptr || (m.behaviour == 0 && grads != nullptr), "the classifier head joins the supervised backward only");
   if (batch->n_rows == 0) {  // an empty shard still owes its gradient (zero) and its event to the all-reduce
     if (grads) SUAVE_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * m.n_params, s));
+    if (head)
+      if (int rc = launch_head_loss(*head, m.latent_dim, nullptr, 0, 0, batch->row_index, batch->row_begin, 0, nullptr, 0, nullptr, s))
+        return rc;
     if (ready_event) SUAVE_CHECK_HIP(hipEventRecord(ready_event, s));
     return 0;
   }
@@ -952,6 +956,10 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
       max_elems = 256;
     }
     // ---- latent backward ----
+    if (head) {  // joint fine-tuning in one pass: CE(classifier(latent)) on the step's own z, its gradient into dz
+      if (int rc = launch_head_loss(*head, D, w.z, p->ldD, 0, batch->row_index, batch->row_begin, B, w.dz, p->ldD, nullptr, s))
+        return rc;
+    }
     if (dlatent) {  // classification loss of joint fine-tuning reaches the encoder through outputs["latent"]
       hipLaunchKernelGGL(k_add_rows, dim3(std::min((B * D + 255) / 256, 2048)), dim3(256), 0, s, w.dz, p->ldD, dlatent, D, B, D);
       SUAVE_CHECK_HIP(hipGetLastError());
@@ -1380,6 +1388,33 @@ int encode_impl(const suave_plan* p, const float* params, const suave_batch_t* b
                                 post_logvar, probs, s, hard_comp, hard_mu);
 }
 }  // namespace
+
+extern "C" int suave_head_workspace_bytes(int32_t n_classes, int32_t latent_dim, size_t* bytes) {
+  SUAVE_REQUIRE(bytes != nullptr, "head_workspace_bytes: null argument");
+  SUAVE_REQUIRE(suave::head_shape_ok(n_classes, latent_dim), "classifier head: n_classes must be 2..64 and latent_dim <= 256 (C * D within LDS)");
+  *bytes = sizeof(float) * suave::head_workspace_floats(n_classes, latent_dim);
+  return 0;
+}
+
+extern "C" int suave_head_step(const suave_head_t* head, int32_t latent_dim, const float* latent, int32_t ld,
+                               const int32_t* row_index, int64_t row_begin, int64_t n, void* stream, float* logits_out) {
+  suave::drop_stale_hip_error();
+  SUAVE_REQUIRE(head != nullptr && n >= 0, "head_step: null head");
+  SUAVE_REQUIRE(n == 0 || latent != nullptr, "head_step: latent is null");
+  SUAVE_REQUIRE(ld >= latent_dim, "head_step: ld < latent_dim");
+  return suave::launch_head_loss(*head, latent_dim, latent, ld, 1, row_index, row_begin, n, nullptr, 0, logits_out,
+                                 static_cast<hipStream_t>(stream));
+}
+
+extern "C" int suave_elbo_joint_backward(const suave_plan* p, const float* params, const suave_batch_t* batch,
+                                         const suave_noise_t* noise, float beta_scale, float tau, int64_t global_rows,
+                                         void* workspace, size_t workspace_bytes, void* stream, const suave_elbo_out_t* out,
+                                         float* grads, const suave_head_t* head, void* decoder_ready_event) {
+  suave::drop_stale_hip_error();
+  SUAVE_REQUIRE(grads != nullptr && head != nullptr, "elbo_joint_backward: grads / head is null");
+  return elbo_impl(p, params, batch, noise, beta_scale, tau, 1, global_rows, workspace, workspace_bytes,
+                   static_cast<hipStream_t>(stream), out, grads, nullptr, static_cast<hipEvent_t>(decoder_ready_event), head);
+}
 
 extern "C" int suave_encode(const suave_plan* p, const float* params, const suave_batch_t* batch,
                             float inv_temperature, void* workspace, size_t workspace_bytes, void* stream,

@@ -7,7 +7,7 @@ OBJ=../../build/obj
 mkdir -p "$OBJ"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $SUAVE_EXTRA_FLAGS"
 pids=()
-for f in gemm decode loss wide embed latent optim sample frame api; do
+for f in gemm decode loss wide embed latent optim sample frame head api; do
   [ -f $f.hip ] || continue
   stale=0  # an object is rebuilt when its source, ANY header here or under include/, or this script is newer
   for dep in $f.hip *.h ../../include/*.h build.sh; do
@@ -23,6 +23,6 @@ for f in gemm decode loss wide embed latent optim sample frame api; do
 done
 for p in "${pids[@]}"; do wait $p; done
 objs=""
-for f in gemm decode loss wide embed latent optim sample frame api; do [ -f $OBJ/$f.o ] && objs="$objs $OBJ/$f.o"; done
+for f in gemm decode loss wide embed latent optim sample frame head api; do [ -f $OBJ/$f.o ] && objs="$objs $OBJ/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $OUT
 echo "built $(realpath $OUT)"

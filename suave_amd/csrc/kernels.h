@@ -287,4 +287,10 @@ struct EmbedBwdArgs {
 int launch_embed_fwd(const EmbedFwdArgs& a, hipStream_t s);
 int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s);
 
+// head.hip: the classifier head (heads.py:62-91) -- loss / gradients / optional Adam of one batch
+bool head_shape_ok(int C, int D);
+size_t head_workspace_floats(int C, int D);
+int launch_head_loss(const suave_head_t& h, int D, const float* latent, int ld, int latent_by_row_id, const int32_t* row_index,
+                     int64_t row_begin, int64_t n, float* dz, int ldz, float* logits_out, hipStream_t s);
+
 }  // namespace suave

@@ -182,12 +182,14 @@ class Engine:
              beta_scale: float, tau: Optional[float] = 1.0, grad: bool = True, training: bool = True,
              global_rows: Optional[int] = None, noise: Optional[Mapping[str, object]] = None, seed: int = 0,
              step: int = 0, want: Sequence[str] = (), accumulate_sums: bool = False,
-             dlatent: Optional[torch.Tensor] = None, ready_event: Optional[torch.cuda.Event] = None
-             ) -> Dict[str, torch.Tensor]:
+             dlatent: Optional[torch.Tensor] = None, ready_event: Optional[torch.cuda.Event] = None,
+             head=None) -> Dict[str, torch.Tensor]:
         """One ELBO forward (+ backward into ``self.grads``).  ``want`` selects
         per-row outputs among reconstruction, categorical_kl, gaussian_kl,
         latent, component, enc_out, and (supervised branch) the per-column log_px / log_px_missing [B, n_cols].  ``ready_event`` (grad only): recorded by the library once the
-        decoder-side gradient bucket is final, before the encoder backward (suave_elbo_backward_overlap)."""
+        decoder-side gradient bucket is final, before the encoder backward (suave_elbo_backward_overlap).  ``head``
+        (grad only; a ``plan.HeadT``): the joint fine-tuning step in one pass -- the classifier head's cross-entropy on
+        this step's latent joins the backward (suave_elbo_joint_backward)."""
 
         B = int(n_rows)
         unsup = self.layout.behaviour != "supervised"
@@ -213,7 +215,13 @@ class Engine:
             out.sums = self.sums.data_ptr()
         base = (ws.data_ptr() + 255) // 256 * 256
         nbytes = ws.numel() - (base - ws.data_ptr())
-        if grad and ready_event is not None:
+        if grad and head is not None:
+            rc = self.lib.suave_elbo_joint_backward(self._plan, self.params.data_ptr(), C.byref(batch), C.byref(nz),
+                                                    float(beta_scale), float(tau), int(global_rows or B), base, nbytes,
+                                                    self._stream(), C.byref(out), self.grads.data_ptr(), C.byref(head),
+                                                    int(ready_event.cuda_event) if ready_event is not None else None)
+            _lib.check(rc, "suave_elbo_joint_backward")
+        elif grad and ready_event is not None:
             rc = self.lib.suave_elbo_backward_overlap(self._plan, self.params.data_ptr(), C.byref(batch), C.byref(nz),
                                                       float(beta_scale), float(tau), int(global_rows or B), base, nbytes,
                                                       self._stream(), C.byref(out), self.grads.data_ptr(), _ptr(dlatent),
@@ -243,6 +251,24 @@ class Engine:
         rc = self.lib.suave_adam_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
                                       self.exp_avg_sq.data_ptr(), gb, lra, 3, self.adam_t, float(betas[0]),
                                       float(betas[1]), float(eps), self._stream())
+        _lib.check(rc, "suave_adam_step")
+
+    def head_step(self, head, latent: torch.Tensor, rows: torch.Tensor, *, logits: Optional[torch.Tensor] = None) -> None:
+        """suave_head_step: one batch of the classifier-head phase on cached latents -- ``rows`` (int32) are row ids into
+        ``latent`` [N, D] and into the head's targets; ``head`` is a ``plan.HeadT``."""
+
+        rc = self.lib.suave_head_step(C.byref(head), int(latent.shape[1]), latent.data_ptr(), int(latent.stride(0)),
+                                      rows.data_ptr(), 0, int(rows.numel()), self._stream(), _ptr(logits))
+        _lib.check(rc, "suave_head_step")
+
+    def adam_flat(self, params: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step_t: int, lr: float,
+                  *, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+        """torch.optim.Adam step on one flat buffer with one learning rate (the classifier head's group)."""
+
+        gb = (C.c_int32 * 2)(0, int(params.numel()))
+        lra = (C.c_float * 1)(float(lr))
+        rc = self.lib.suave_adam_step(params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), gb, lra, 1, int(step_t),
+                                      float(betas[0]), float(betas[1]), float(eps), self._stream())
         _lib.check(rc, "suave_adam_step")
 
     # -- encode ----------------------------------------------------------------

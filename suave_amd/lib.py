@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from .plan import BatchT, ColT, ElboOutT, ModelT, NoiseT
+from .plan import BatchT, ColT, ElboOutT, HeadT, ModelT, NoiseT
 
 # SUAVE_HIP_LIB points at another build of the same library (tuning builds under build/); default: the in-tree one
 _LIB_PATH = os.environ.get("SUAVE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsuave_hip.so")
@@ -24,6 +24,9 @@ EXPORTS = (
     "suave_elbo_backward",
     "suave_elbo_backward_overlap",
     "suave_adam_step",
+    "suave_head_workspace_bytes",
+    "suave_head_step",
+    "suave_elbo_joint_backward",
     "suave_encode",
     "suave_prior_latents",
     "suave_conditional_latents",
@@ -88,6 +91,10 @@ def load():
                                         C.POINTER(ElboOutT), vp, vp]
     lib.suave_elbo_backward_overlap.argtypes = [vp, vp, C.POINTER(BatchT), C.POINTER(NoiseT), f32, f32, i64, vp, sz, vp,
                                                 C.POINTER(ElboOutT), vp, vp, vp]
+    lib.suave_head_workspace_bytes.argtypes = [i32, i32, C.POINTER(sz)]
+    lib.suave_head_step.argtypes = [C.POINTER(HeadT), i32, vp, i32, vp, i64, i64, vp, vp]
+    lib.suave_elbo_joint_backward.argtypes = [vp, vp, C.POINTER(BatchT), C.POINTER(NoiseT), f32, f32, i64, vp, sz, vp,
+                                              C.POINTER(ElboOutT), vp, C.POINTER(HeadT), vp]
     lib.suave_adam_step.argtypes = [vp, vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, i64, f32, f32, f32, vp]
     lib.suave_encode.argtypes = [vp, vp, C.POINTER(BatchT), f32, vp, sz, vp, vp, vp, vp, vp]
     lib.suave_encode_hard.argtypes = [vp, vp, C.POINTER(BatchT), f32, vp, sz, vp, vp, vp]

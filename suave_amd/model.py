@@ -564,9 +564,24 @@ class SUAVE:
             return
         n = latent_mu.shape[0]
         eff = min(bs, n)
-        opt = torch.optim.Adam(self._classifier.parameters(), lr=self.learning_rate)
         self._classifier.train()
         self._head_history = []
+        hd = self._device_head(y_t)
+        if hd is not None:  # the phase in the library: two launches per batch, one host sync per epoch
+            hd.reset_optimizer()
+            latent_mu = latent_mu.contiguous()
+            for _ in range(epochs):
+                hd.loss_sum.zero_()
+                for idx, idx32 in self._epoch_batches(n, eff):
+                    key = self._head_keys(idx).get("key", 0)
+                    self._engine.head_step(hd.struct(training=True, loss_scale=1.0, loss_rows=float(idx.numel()), key=key,
+                                                     adam_lr=self.learning_rate, want_grads=False), latent_mu, idx32)
+                self._head_history.append(float(hd.loss_sum.item()) / n)
+            if self._dp is not None:
+                self._dp.broadcast_module(self._classifier)
+            self._classifier.eval()
+            return
+        opt = torch.optim.Adam(self._classifier.parameters(), lr=self.learning_rate)
         for _ in range(epochs):
             tot = torch.zeros((), device=latent_mu.device, dtype=torch.float64)
             for idx, _ in self._epoch_batches(n, eff):
@@ -579,6 +594,23 @@ class SUAVE:
         if self._dp is not None:  # the phase is replicated (cached latents, same seed); rank 0's bits win
             self._dp.broadcast_module(self._classifier)
         self._classifier.eval()
+
+    def _device_head(self, y_t: torch.Tensor):
+        """The library-side head state (``supervised.DeviceHead``) when the classifier is one the HIP kernels serve --
+        no hidden layers, <= 64 classes -- else None (the torch module computes the head; ``SUAVE_TORCH_HEAD=1`` forces
+        that, for comparisons).  Replayed parity runs with head dropout keep torch's generator, as the reference."""
+
+        import os
+
+        clf = self._classifier
+        if clf is None or os.environ.get("SUAVE_TORCH_HEAD") or not sup.DeviceHead.supports(clf):
+            return None
+        hd = getattr(self, "_dev_head", None)
+        if hd is None or hd.clf is not clf or hd.targets.numel() != y_t.numel():
+            hd = self._dev_head = sup.DeviceHead(clf, y_t)
+        if self._replay is not None and hd.dropout > 0.0:
+            return None
+        return hd
 
     def _validation_scores(self, val: Optional[PackedTable], bs: int, y_val_t: Optional[torch.Tensor],
                            weight: Optional[float]) -> Dict[str, float]:
@@ -639,7 +671,10 @@ class SUAVE:
         eng, clf = self._engine, self._classifier
         weight = float(max(weight, 0.0))
         eng.reset_optimizer()  # the reference builds a fresh Adam per phase (model.py:1909)
-        clf_opt = torch.optim.Adam(clf.parameters(), lr=self.learning_rate)
+        hd = self._device_head(y_t)
+        if hd is not None:
+            hd.reset_optimizer()
+        clf_opt = torch.optim.Adam(clf.parameters(), lr=self.learning_rate) if hd is None else None
         lrs = {"encoder": self.learning_rate, "decoder": self.learning_rate * lr_scale, "prior": self.learning_rate * lr_scale}
         clf.train()
         n = train.n_global
@@ -653,11 +688,26 @@ class SUAVE:
         for _ in range(epochs):
             eng.sums.zero_()
             ce_tot = torch.zeros((), device=eng.device, dtype=torch.float64)
+            if hd is not None:
+                hd.loss_sum.zero_()
             for idx64, loc in self._elbo_batches(train, eff):
                 nb = int(idx64.numel())  # the global batch; `loc` are this rank's rows of it
                 self._step += 1
                 nz = self._noise_for(nb)
                 loc64 = loc.long()
+                if hd is not None:
+                    # one pass (suave_elbo_joint_backward): the head's CE on the step's own latent inside the backward
+                    key = self._head_keys(loc64).get("key", 0)
+                    wsum = None if self._dp is None else hd.batch_weight(idx64)  # the GLOBAL batch's class-weight sum
+                    self._backward(train, loc, beta_scale=self.beta, tau=tau, global_rows=nb, noise=nz,
+                                   head=hd.struct(training=True, loss_scale=weight, loss_rows=float(nb), key=key, weight_sum=wsum))
+                    if self._dp is not None:
+                        self._dp.all_reduce(hd.grads)
+                    self._record_step_gradient()
+                    eng.adam_step(lrs)
+                    hd.t += 1
+                    eng.adam_flat(hd.flat, hd.grads, hd.m, hd.v, hd.t, self.learning_rate)
+                    continue
                 fwd = eng.elbo(train, 0, int(loc.numel()), row_index=loc, beta_scale=self.beta, tau=tau, grad=False,
                                training=True, seed=self.random_state, step=self._step, want=("latent",), noise=nz)
                 latent = fwd["latent"].requires_grad_(True)
@@ -679,6 +729,8 @@ class SUAVE:
             s = self._epoch_sums()
             cnt = max(s[3], 1.0)
             elbo_loss = -(s[0] - self.beta * (s[1] + s[2])) / cnt
+            if hd is not None:
+                ce_tot = hd.loss_sum[0].clone()
             ce = float(self._all_reduce(ce_tot).item()) / cnt
             metrics = self._validation_scores(val, bs, y_val_t, weight)
             self._joint_history.append({"train_elbo_loss": elbo_loss, "train_classification_loss": ce,

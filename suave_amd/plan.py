@@ -66,6 +66,14 @@ class ElboOutT(C.Structure):
                 ("log_px", C.c_void_p), ("log_px_missing", C.c_void_p)]
 
 
+class HeadT(C.Structure):  # suave_head_t
+    _fields_ = [("n_classes", C.c_int32), ("training", C.c_int32), ("params", C.c_void_p), ("grads", C.c_void_p),
+                ("class_weight", C.c_void_p), ("targets", C.c_void_p), ("weight_sum", C.c_void_p),
+                ("loss_scale", C.c_float), ("loss_rows", C.c_float), ("loss_sum", C.c_void_p), ("dropout", C.c_float),
+                ("dropout_key", C.c_uint64), ("adam_lr", C.c_float), ("adam_step", C.c_int64), ("adam_m", C.c_void_p),
+                ("adam_v", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 def _r4(x: int) -> int:
     return (x + 3) // 4 * 4
 

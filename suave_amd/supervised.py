@@ -121,6 +121,81 @@ class ClassificationHead(nn.Module):
         return torch.tensor(float(targets.numel()), device=targets.device)
 
 
+class DeviceHead:
+    """Library-side training state of a ``ClassificationHead`` WITHOUT hidden layers (include/suave_hip.h,
+    ``suave_head_t``): the module's ``linear`` parameters are re-homed as views of one flat device buffer
+    (weight [C, D] then bias [C]) which the HIP kernels read and update in place, so ``state_dict`` / persistence /
+    the eval-mode forward keep working on the module while the head phase (model.py:1743-1864) and the joint step
+    (model.py:1973-1999) run in the library: no autograd, no optimizer object, no host sync per batch."""
+
+    def __init__(self, clf: ClassificationHead, targets: torch.Tensor) -> None:
+        import ctypes as C
+
+        from . import lib as _lib
+
+        if clf.hidden_layers is not None:
+            raise ValueError("DeviceHead serves heads without hidden layers")
+        w, b = clf.linear.weight, clf.linear.bias
+        self.C, self.D = int(w.shape[0]), int(w.shape[1])
+        dev = w.device
+        self.flat = torch.cat([w.detach().reshape(-1), b.detach().reshape(-1)]).to(torch.float32).contiguous()
+        w.data = self.flat[: self.C * self.D].view(self.C, self.D)
+        b.data = self.flat[self.C * self.D:]
+        self.clf = clf
+        self.grads = torch.zeros_like(self.flat)
+        self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.t = 0
+        nbytes = C.c_size_t(0)
+        _lib.check(_lib.load().suave_head_workspace_bytes(self.C, self.D, C.byref(nbytes)), "suave_head_workspace_bytes")
+        self.ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device=dev)
+        self.loss_sum = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.class_weight = clf.class_weight.to(torch.float32).contiguous() if clf._use_weight else None
+        self.targets = targets.to(device=dev, dtype=torch.int32).contiguous()
+        drops = [mod for mod in clf.modules() if isinstance(mod, RowKeyedDropout)]
+        self.dropout = float(drops[0].p) if drops else 0.0
+
+    @staticmethod
+    def supports(clf: ClassificationHead) -> bool:
+        w = clf.linear.weight
+        c, d = int(w.shape[0]), int(w.shape[1])
+        lds = 4 * (2 * (c * d + c) + d * 65 + c * 64 + 2)  # k_head_loss at its smallest tile (64 rows)
+        return clf.hidden_layers is None and 2 <= c <= 64 and 1 <= d <= 256 and lds <= 144 * 1024 and w.is_cuda
+
+    def reset_optimizer(self) -> None:
+        self.m.zero_()
+        self.v.zero_()
+        self.t = 0
+
+    def struct(self, *, training: bool, loss_scale: float, loss_rows: float, key: int = 0,
+               weight_sum: Optional[torch.Tensor] = None, adam_lr: float = 0.0, want_grads: bool = True):
+        """A ``suave_head_t`` for one call.  ``adam_lr`` > 0 advances the head's Adam step counter."""
+
+        from .plan import HeadT
+
+        if adam_lr > 0.0:
+            self.t += 1
+        h = HeadT()
+        h.n_classes, h.training = self.C, int(bool(training))
+        h.params, h.grads = self.flat.data_ptr(), (self.grads.data_ptr() if want_grads else None)
+        h.class_weight = None if self.class_weight is None else self.class_weight.data_ptr()
+        h.targets = self.targets.data_ptr()
+        h.weight_sum = None if weight_sum is None else weight_sum.data_ptr()
+        h.loss_scale, h.loss_rows = float(loss_scale), float(loss_rows)
+        h.loss_sum = self.loss_sum.data_ptr()
+        h.dropout, h.dropout_key = self.dropout, int(key) & 0xFFFFFFFF
+        h.adam_lr, h.adam_step = float(adam_lr), int(self.t)
+        h.adam_m, h.adam_v = self.m.data_ptr(), self.v.data_ptr()
+        h.workspace, h.workspace_bytes = self.ws.data_ptr(), int(self.ws.numel())
+        return h
+
+    def batch_weight(self, rows: torch.Tensor) -> torch.Tensor:
+        """Sum of the class weights over the targets of ``rows`` (the GLOBAL batch of a data-parallel step): a device scalar."""
+
+        if self.class_weight is None:
+            return torch.full((1,), float(rows.numel()), dtype=torch.float32, device=self.flat.device)
+        return self.class_weight[self.targets[rows].long()].sum().reshape(1)
+
+
 class TemperatureScaler:
     """calibrate.py:16-112: one log-temperature fitted by Adam on the cross-entropy of ``logits / T``."""
 

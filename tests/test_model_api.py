@@ -305,3 +305,29 @@ def test_nonfinite_epoch_on_the_fp16_planes_reruns_the_schedule_on_the_wide_arit
         assert torch.equal(a, b)
     slib.check(restore_arithmetic.suave_gemm_arithmetic_set(4), "suave_gemm_arithmetic_set")
     assert SUAVE._arithmetic() == 4
+
+
+def test_device_head_fit_agrees_with_the_torch_head_fit(monkeypatch):
+    """The supervised schedule with the classifier head in the library (head phase: suave_head_step; joint phase:
+    suave_elbo_joint_backward) against the same schedule with the torch module computing the head
+    (SUAVE_TORCH_HEAD=1: forward, autograd, torch.optim.Adam, suave_elbo_backward(dlatent)) -- same seeds, same
+    row-keyed dropout masks, so the two fits differ by fp32 summation order only."""
+
+    import torch
+    from suave_amd.model import SUAVE
+
+    df, g = _frame(900, seed=6)
+    kw = dict(behaviour="supervised", latent_dim=8, n_components=2, hidden_dims=(32, 16), batch_size=128, random_state=1,
+              dropout=0.1, learning_rate=2e-3)
+    fitkw = dict(epochs=3, head_epochs=3, finetune_epochs=3, decoder_refine_epochs=1)
+    m_dev = SUAVE(_schema(), **kw).fit(df, y=g, **fitkw)
+    assert getattr(m_dev, "_dev_head", None) is not None and m_dev._dev_head.t > 0
+    monkeypatch.setenv("SUAVE_TORCH_HEAD", "1")
+    m_ref = SUAVE(_schema(), **kw).fit(df, y=g, **fitkw)
+    assert getattr(m_ref, "_dev_head", None) is None
+    assert np.allclose(m_dev._head_history, m_ref._head_history, rtol=1e-4)
+    for a, b in zip(m_dev._joint_history, m_ref._joint_history):
+        assert abs(a["train_classification_loss"] - b["train_classification_loss"]) < 2e-3 * abs(b["train_classification_loss"])
+        assert abs(a["train_elbo_loss"] - b["train_elbo_loss"]) < 2e-3 * abs(b["train_elbo_loss"])
+    pa, pb = m_dev.predict_proba(df.iloc[:200]), m_ref.predict_proba(df.iloc[:200])
+    assert np.abs(np.asarray(pa) - np.asarray(pb)).max() < 5e-3
