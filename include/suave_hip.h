@@ -200,8 +200,9 @@ int suave_elbo_backward(const suave_plan* plan, const float* params, const suave
  * y_projection, likelihood heads, prior: one contiguous range) as soon as the decoder backward has produced it
  * and records `decoder_ready_event` (a hipEvent_t) on the stream at that point; the encoder backward and its
  * reduction follow.  A caller makes its communication stream wait for the event and all-reduces that bucket while
- * the encoder backward runs, then all-reduces the encoder bucket once the call's stream work is done.  (The
- * unsupervised branch records the event at the end: its prior gradient is produced last.)  An empty batch writes
+ * the encoder backward runs, then all-reduces the encoder bucket once the call's stream work is done.  Both
+ * branches: in the unsupervised one the bucket is decoder + heads + PriorMean, whose gradient (column sums of the
+ * mixture finalisation) only needs the decoder backward.  An empty batch writes
  * a zero gradient and records the event. */
 int suave_elbo_backward_overlap(const suave_plan* plan, const float* params, const suave_batch_t* batch,
                                 const suave_noise_t* noise, float beta_scale, float tau,

@@ -534,7 +534,8 @@ __global__ void k_add_rows(float* dst, int ld_dst, const float* src, int ld_src,
 
 int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_t* batch, const suave_noise_t* noise,
                     float beta_scale, float tau, int training, int64_t global_rows, void* workspace,
-                    size_t workspace_bytes, hipStream_t s, const suave_elbo_out_t* out, float* grads) {
+                    size_t workspace_bytes, hipStream_t s, const suave_elbo_out_t* out, float* grads,
+                    hipEvent_t ready_event = nullptr) {
   const suave_model_t& m = p->model;
   const bool grad = grads != nullptr;
   const int B = batch->n_rows, K = m.n_components, D = m.latent_dim;
@@ -650,25 +651,6 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
   red.sums_out = out ? out->sums : nullptr;
   red.n_rows = (double)B;
   if (grad) {
-    const float* helast = nh ? w.he[nh - 1] : w.x;
-    const int ldhe = nh ? p->ldH[nh - 1] : p->ldI;
-    if (int rc = bwd_weight(p, m.enc_head, w.dencout, p->ldE, helast, ldhe, B, w.slab, &slab_off, &red, &max_elems, s))
-      return rc;
-    const float* dcur = w.dencout;
-    int lddcur = p->ldE;
-    const suave_layer_t* lcur = &m.enc_head;
-    for (int i = nh - 1; i >= 0; --i) {
-      if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dhe[i], p->ldH[i], B, w.he[i], drop_p, s, w.wT[layer_index(p, lcur)])) return rc;
-      const float* ain = i > 0 ? w.he[i - 1] : w.x;
-      const int ldain = i > 0 ? p->ldH[i - 1] : p->ldI;
-      if (int rc = bwd_weight(p, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, B, w.slab, &slab_off, &red, &max_elems, s))
-        return rc;
-      dcur = w.dhe[i];
-      lddcur = p->ldH[i];
-      lcur = &m.enc[i];
-    }
-    if (nh > 0)
-      if (int rc = encoder_embed_backward(p, w, B, grads, s)) return rc;
     // PriorMean gradients: column sums of prior_terms -> linear.weight[d,k] and linear.bias[d]
     {
       const int ncol = K * D + D;
@@ -689,6 +671,35 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     sh.src_ld = m.head_len; sh.dst_off = m.head_off; sh.dst_si = 0; sh.dst_sj = 1;
     red.segs[red.n_segs++] = sh;
     max_elems = std::max(max_elems, m.head_len);
+    // The decoder-side bucket (decoder, likelihood heads, PriorMean: one contiguous range of the flat gradient) is
+    // complete here: with an event to signal, reduce it now and record the event, so that a data-parallel caller
+    // all-reduces it while the encoder backward below is still running (as the supervised branch does).
+    if (ready_event) {
+      if (int rc = launch_reduce(red, max_elems, s)) return rc;
+      SUAVE_CHECK_HIP(hipEventRecord(ready_event, s));
+      red.n_segs = 0;
+      red.sums_slab = nullptr; red.n_sum_slabs = 0; red.sums_out = nullptr;  // the epoch sums went with the first launch
+      max_elems = 256;
+    }
+    const float* helast = nh ? w.he[nh - 1] : w.x;
+    const int ldhe = nh ? p->ldH[nh - 1] : p->ldI;
+    if (int rc = bwd_weight(p, m.enc_head, w.dencout, p->ldE, helast, ldhe, B, w.slab, &slab_off, &red, &max_elems, s))
+      return rc;
+    const float* dcur = w.dencout;
+    int lddcur = p->ldE;
+    const suave_layer_t* lcur = &m.enc_head;
+    for (int i = nh - 1; i >= 0; --i) {
+      if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dhe[i], p->ldH[i], B, w.he[i], drop_p, s, w.wT[layer_index(p, lcur)])) return rc;
+      const float* ain = i > 0 ? w.he[i - 1] : w.x;
+      const int ldain = i > 0 ? p->ldH[i - 1] : p->ldI;
+      if (int rc = bwd_weight(p, m.enc[i], w.dhe[i], p->ldH[i], ain, ldain, B, w.slab, &slab_off, &red, &max_elems, s))
+        return rc;
+      dcur = w.dhe[i];
+      lddcur = p->ldH[i];
+      lcur = &m.enc[i];
+    }
+    if (nh > 0)
+      if (int rc = encoder_embed_backward(p, w, B, grads, s)) return rc;
     SUAVE_REQUIRE(slab_off <= w.slab_floats, "internal: slab overflow");
   }
   if (grad || red.sums_out) {
@@ -732,12 +743,12 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
                 "per-column log_px / log_px_missing are outputs of the supervised branch (the unsupervised one scores "
                 "every column once per component)");
   if (m.behaviour == 1) {
+    // (the PriorMean gradient comes out of the mixture finalisation, which only needs the decoder backward: the
+    // decoder-side bucket is reduced and the event recorded before the encoder backward, as in the supervised branch)
     if (int rc = elbo_unsup_impl(p, params, batch, noise, beta_scale, tau, training, global_rows, workspace, workspace_bytes,
-                                 s, out, grads))
+                                 s, out, grads, grads ? ready_event : nullptr))
       return rc;
-    // (the PriorMean gradient comes out of the mixture finalisation, after the decoder backward: the unsupervised
-    // branch has one bucket, ready when everything is)
-    if (ready_event) SUAVE_CHECK_HIP(hipEventRecord(ready_event, s));
+    if (!grads && ready_event) SUAVE_CHECK_HIP(hipEventRecord(ready_event, s));
     return 0;
   }
   const bool grad = grads != nullptr;

@@ -201,6 +201,46 @@ def test_overlap_entry_point_matches_and_its_event_marks_a_final_decoder_bucket(
         assert torch.equal(early, ref[lo:hi])
 
 
+def test_overlap_entry_point_in_the_unsupervised_branch():
+    """The same for behaviour="unsupervised": the decoder + heads + PriorMean range is final at the event (the PriorMean
+    gradient comes out of the mixture finalisation, before the encoder backward), and the gradient bits are those of
+    suave_elbo_backward."""
+
+    import torch
+    from suave_amd.engine import Engine, PackedTable
+    from tests.helpers import layout_from_columns, s64_columns, synth_packed
+
+    cols = s64_columns(64, real_variant="scaled")
+    layout = layout_from_columns(cols, K=4, D=32, hidden=(256, 128), dropout=0.1, behaviour="unsupervised")
+    eng = Engine(layout, "cuda:0")
+    from oracle import suave_oracle as orc
+    eng.load_state(orc.OracleModel(cols, n_components=4, latent_dim=32, hidden=(256, 128), dropout=0.1,
+                                   behaviour="unsupervised").init_params(seed=2))
+    n, B = 40000, 16384
+    xnum, codes, mask = synth_packed(cols, n, 0.1, seed=9)
+    table = PackedTable(xnum, codes, mask, eng.device)
+    idx = torch.randperm(n, device=eng.device, generator=torch.Generator(eng.device).manual_seed(3))[:B].to(torch.int32)
+    eng.grads.zero_()
+    eng.elbo(table, 0, B, row_index=idx, beta_scale=0.7, tau=0.9, grad=True, seed=5, step=9, global_rows=2 * B)
+    ref = eng.grads.clone()
+    assert float(ref.abs().max()) > 0
+    lo, hi = layout.group_ranges["decoder"][0], layout.group_ranges["prior"][1]
+    side = torch.cuda.Stream(eng.device)
+    ev = torch.cuda.Event()
+    ev.record()
+    early = torch.empty(hi - lo, device=eng.device)
+    for _ in range(3):
+        eng.grads.zero_()
+        eng.elbo(table, 0, B, row_index=idx, beta_scale=0.7, tau=0.9, grad=True, seed=5, step=9, global_rows=2 * B,
+                 ready_event=ev)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            early.copy_(eng.grads[lo:hi])
+        torch.cuda.synchronize()
+        assert torch.equal(eng.grads, ref)
+        assert torch.equal(early, ref[lo:hi])
+
+
 def test_posterior_draws_lane_group_kernel_equals_the_scalar_kernel(s64):
     """suave_posterior_draws has two kernels with the same generator keys and arithmetic: eight lanes per row
     (D % 4 == 0, K <= 32, 16-byte aligned z) and one thread per draw.  Same bits out of both (the scalar one is
