@@ -141,6 +141,89 @@ def test_generation_is_invariant_to_row_sharding_and_in_range(s64):
     assert np.abs(freq - p).max() < 5e-3
 
 
+def test_conditional_generation_full_size_properties(s64):
+    """sample(conditional=True) at 1M rows (suave_conditional_latents -> the fused decode): the rows do not depend on
+    the chunking; every draw of label c comes from the cached posteriors of class c's training rows -- the mean of z
+    over a class's draws is the mixture mean of that class (sum_rows sum_k p_k mu_k / n_c) within 6 standard errors --
+    and the component frequencies per class are the class's mean responsibilities."""
+
+    import torch
+
+    eng, _, layout = s64
+    K, D = layout.n_components, layout.latent_dim
+    g = torch.Generator(device=eng.device).manual_seed(31)
+    n_train, n_cls = 50_000, 3
+    y_train = torch.randint(0, n_cls, (n_train,), device=eng.device, generator=g)
+    probs = torch.softmax(2.0 * torch.randn((n_train, K), device=eng.device, generator=g), dim=1)
+    mu = torch.randn((n_train, K, D), device=eng.device, generator=g) + y_train.view(-1, 1, 1).float()
+    logvar = 0.3 * torch.randn((n_train, K, D), device=eng.device, generator=g) - 1.0
+    order = torch.argsort(y_train, stable=True)
+    class_rows = order.to(torch.int64)
+    counts = torch.bincount(y_train, minlength=n_cls)
+    class_offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=eng.device), counts.cumsum(0)]).to(torch.int64)
+    labels = torch.randint(0, n_cls, (ROWS,), device=eng.device, generator=g).to(torch.int32)
+
+    def run(chunk):
+        zs, ks, nums, codes = [], [], [], []
+        for s0 in range(0, ROWS, chunk):
+            nb = min(chunk, ROWS - s0)
+            z, k = eng.conditional_latents(labels[s0:s0 + nb].contiguous(), class_offsets, class_rows, probs, mu, logvar,
+                                           seed=41, row_offset=s0)
+            onum, ocodes = eng.decode_sample(z, component=k, seed=42, row_offset=s0)
+            zs.append(z.clone()); ks.append(k.clone()); nums.append(onum.clone()); codes.append(ocodes.clone())
+        return torch.cat(zs), torch.cat(ks), torch.cat(nums), torch.cat(codes)
+
+    z1, k1, n1, c1 = run(1 << 18)
+    z2, k2, n2, c2 = run(333_333)
+    assert torch.equal(k1, k2) and torch.equal(z1, z2) and torch.equal(c1, c2) and torch.equal(n1, n2)
+    assert bool(torch.isfinite(z1).all()) and bool(torch.isfinite(n1).all())
+    for c in range(n_cls):
+        rows_c = y_train == c
+        sel = labels == c
+        m = int(sel.sum())
+        want_mean = (probs[rows_c].unsqueeze(-1) * mu[rows_c]).sum(dim=1).mean(dim=0)
+        got_mean = z1[sel].mean(dim=0)
+        sd = z1[sel].std(dim=0)
+        assert bool(((got_mean - want_mean).abs() <= 6.0 * sd / m ** 0.5 + 1e-3).all()), c
+        freq = torch.bincount(k1[sel].long(), minlength=K).float() / m
+        assert float((freq - probs[rows_c].mean(dim=0)).abs().max()) < 6.0 * (0.25 / m) ** 0.5 + 1e-3, c
+
+
+def test_mc32_posterior_predictive_full_size_properties(s64):
+    """impute_mc's device path at the bench size (32 768 table rows x 32 draws = 1M decoded rows): encode ->
+    suave_posterior_draws (row-major, keyed by (table row, draw)) -> the fused decode.  The decoded rows do not depend
+    on how the table rows are chunked; the mean of a row's 32 z draws is its moment-matched posterior mean within 6
+    standard errors (pooled over rows); the component frequencies follow the responsibilities."""
+
+    import torch
+
+    eng, table, layout = s64
+    K, D, L, n = layout.n_components, layout.latent_dim, 32, 32768
+
+    def run(chunk):
+        zs, ks, nums, codes = [], [], [], []
+        for s0 in range(0, n, chunk):
+            nb = min(chunk, n - s0)
+            enc = eng.encode(table, s0, nb)
+            z, k = eng.posterior_draws(enc["enc_out"], L, seed=51, row_offset=s0, row_major=True)
+            onum, ocodes = eng.decode_sample(z, component=k, seed=52, row_offset=s0 * L)
+            zs.append(z.clone()); ks.append(k.clone()); nums.append(onum.clone()); codes.append(ocodes.clone())
+        return torch.cat(zs), torch.cat(ks), torch.cat(nums), torch.cat(codes)
+
+    z1, k1, n1, c1 = run(n)
+    z2, k2, n2, c2 = run(5000)
+    assert torch.equal(k1, k2) and torch.equal(z1, z2) and torch.equal(c1, c2) and torch.equal(n1, n2)
+    assert bool(torch.isfinite(n1).all())
+    enc = eng.encode(table, 0, n)
+    zbar = z1.view(n, L, D).mean(dim=1)
+    # per-coordinate standard error of a row's mean from the moment-matched variance of the mixture
+    se = (enc["logvar"].exp() / L).sqrt()
+    dev = ((zbar - enc["mean"]) / se)
+    assert abs(float(dev.mean())) < 0.02 and abs(float(dev.std()) - 1.0) < 0.05  # standardised deviations ~ N(0, 1)
+    freq = torch.zeros((n, K), device=eng.device).scatter_add_(1, k1.view(n, L).long(), torch.ones((n, L), device=eng.device)) / L
+    assert float((freq.mean(dim=0) - enc["probs"].mean(dim=0)).abs().max()) < 2e-3
+
+
 def test_empty_inputs_are_accepted(s64):
     """Zero-row batches: every entry point returns success and launches no model kernel (reference: batch == 0
     guards, model.py:3361-3362, 3398-3399, 4238); the backward's gradient of nothing is zero."""
