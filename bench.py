@@ -266,12 +266,28 @@ def generation_rates(eng, table, rows, gen_rows, device, rank, world, dist, fenc
 
     ms, cnt = timed(run_sample, gen_rows, "sample_conditional")
     if prof and cnt[6] > 0:
-        # k_sample_heads against HBM: reads y_full (4 B x Y) and writes the packed columnar output
         L = eng.layout
-        bytes_row = 4 * L.total_y + 4 * L.n_num + 2 * L.n_disc
-        gbs = bytes_row * gen_rows / (ms[6] * 1e-3) / 1e9
-        res["roofline_sample_heads"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                        "frac": gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_row": bytes_row}
+        if ms[0] == 0.0 and len(L.hidden) == 2:
+            # the fused decode kernel (decode.hip: decoder trunk -> y_projection -> head maps -> sample draw in one
+            # launch, nothing but z / component in and the packed cells out): priced against the matrix pipe for the
+            # trunk's algorithmic FLOPs (the head maps' extra MFMA layer and the sampler's VALU work are not counted)
+            # and against HBM for its necessary bytes
+            h1, h2 = L.hidden
+            flops_row = 2 * (L.latent_dim * h1 + h1 * h2 + h2 * L.total_y)
+            bytes_row = 4 * L.latent_dim + 4 + 4 * L.n_num + 2 * L.n_disc
+            tf = flops_row * gen_rows / (ms[6] * 1e-3) / 1e12
+            gbs = bytes_row * gen_rows / (ms[6] * 1e-3) / 1e9
+            res["roofline_decode_fused"] = {"bound": "mfma", "kernel": "k_decode_fused", "achieved": tf,
+                                            "peak": PEAK_BF16_MFMA_TFLOPS / 3, "unit": "TFLOP/s", "frac": tf / (PEAK_BF16_MFMA_TFLOPS / 3),
+                                            "algorithmic_flops_per_row": flops_row, "hbm_GBps": gbs,
+                                            "hbm_frac": gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_row": bytes_row,
+                                            "kernel_ms": ms[6]}
+        else:
+            # k_sample_heads against HBM: reads y_full (4 B x Y) and writes the packed columnar output
+            bytes_row = 4 * L.total_y + 4 * L.n_num + 2 * L.n_disc
+            gbs = bytes_row * gen_rows / (ms[6] * 1e-3) / 1e9
+            res["roofline_sample_heads"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                            "frac": gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_row": bytes_row}
     n_imp = min(rows, n_imp_max)
 
     def run_impute():  # reference-exact single pass at the posterior-mean latent, hard assignment (model.py:3627-3651)
@@ -650,7 +666,8 @@ def main():
         if gen is not None:
             line["generation"] = gen
         pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in
-                                (("r02_pmc_traffic_w1024.json",) if wide else ("r02_pmc_traffic.json", "r01_pmc_traffic.json")))
+                                (("r03_pmc_traffic_w1024.json", "r02_pmc_traffic_w1024.json") if wide else
+                                 ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")))
                     if os.path.exists(f)), "")
         if "roofline" in line and pmc and B == (32768 if wide else 65536):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
             with open(pmc) as fh:

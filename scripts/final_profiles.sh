@@ -13,19 +13,19 @@ rm -rf $O/${R}_stats $O/${R}_stats_train $O/${R}_fetch $O/${R}_write $O/${R}_fet
 echo "[1/9] kernel stats, default command"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/${R}_stats --output-format csv -o bench -- python bench.py > $O/${R}_bench_stats.log 2>&1
 echo "[2/9] kernel stats, training only"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/${R}_stats_train --output-format csv -o bench -- python bench.py --gen-rows 0 --no-cpu-baseline > $O/${R}_bench_stats_train.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/${R}_stats_train --output-format csv -o bench -- python bench.py --gen-rows 0 --no-cpu-baseline --no-subrecords > $O/${R}_bench_stats_train.log 2>&1
 echo "[3/9] PMC FETCH_SIZE, training only"
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/${R}_fetch_t --output-format csv -o pmc -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --gen-rows 0 > $O/${R}_fetch_t.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/${R}_fetch_t --output-format csv -o pmc -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-subrecords --no-profile --gen-rows 0 > $O/${R}_fetch_t.log 2>&1
 echo "[4/9] PMC WRITE_SIZE, training only"
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/${R}_write_t --output-format csv -o pmc -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --gen-rows 0 > $O/${R}_write_t.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/${R}_write_t --output-format csv -o pmc -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-subrecords --no-profile --gen-rows 0 > $O/${R}_write_t.log 2>&1
 echo "[5/9] PMC FETCH_SIZE, with generation"
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/${R}_fetch --output-format csv -o pmc -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile > $O/${R}_fetch.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/${R}_fetch --output-format csv -o pmc -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-subrecords --no-profile > $O/${R}_fetch.log 2>&1
 echo "[6/9] PMC WRITE_SIZE, with generation"
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/${R}_write --output-format csv -o pmc -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile > $O/${R}_write.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/${R}_write --output-format csv -o pmc -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-subrecords --no-profile > $O/${R}_write.log 2>&1
 echo "[7/9] timeline S64"
-timeout -k 10 120 rocprofv3 --kernel-trace -d $O/${R}_tl_s64 --output-format csv -o tl -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --gen-rows 0 > $O/${R}_tl_s64.log 2>&1
+timeout -k 10 120 rocprofv3 --kernel-trace -d $O/${R}_tl_s64 --output-format csv -o tl -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-subrecords --no-profile --gen-rows 0 > $O/${R}_tl_s64.log 2>&1
 echo "[8/9] timeline W1024"
-timeout -k 10 200 rocprofv3 --kernel-trace -d $O/${R}_tl_w --output-format csv -o tl -- python bench.py --config w1024 --steps 3 --warmup 2 --no-cpu-baseline --no-profile --gen-rows 0 > $O/${R}_tl_w.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace -d $O/${R}_tl_w --output-format csv -o tl -- python bench.py --config w1024 --steps 3 --warmup 2 --no-cpu-baseline --no-subrecords --no-profile --gen-rows 0 > $O/${R}_tl_w.log 2>&1
 echo "[summaries]"
 mkdir -p $O/${R}_out
 python scripts/trim_prof.py $(find $O/${R}_stats -name '*kernel_stats.csv' | tail -1) $O/${R}_out/${R}_bench_kernel_stats.csv > /dev/null
@@ -38,8 +38,8 @@ grep -h "^{\"metric\"" $O/${R}_bench_stats.log | tail -1 > $O/${R}_out/${R}_benc
 rm -rf $O/${R}_stats $O/${R}_stats_train $O/${R}_fetch $O/${R}_write $O/${R}_fetch_t $O/${R}_write_t $O/${R}_tl_s64 $O/${R}_tl_w
 echo "[8b] PMC FETCH_SIZE / WRITE_SIZE, W1024 training only"
 rm -rf $O/${R}_fetch_w $O/${R}_write_w
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/${R}_fetch_w --output-format csv -o pmc -- python bench.py --config w1024 --steps 3 --warmup 1 --no-cpu-baseline --no-profile --gen-rows 0 > $O/${R}_fetch_w.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/${R}_write_w --output-format csv -o pmc -- python bench.py --config w1024 --steps 3 --warmup 1 --no-cpu-baseline --no-profile --gen-rows 0 > $O/${R}_write_w.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/${R}_fetch_w --output-format csv -o pmc -- python bench.py --config w1024 --steps 3 --warmup 1 --no-cpu-baseline --no-subrecords --no-profile --gen-rows 0 > $O/${R}_fetch_w.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/${R}_write_w --output-format csv -o pmc -- python bench.py --config w1024 --steps 3 --warmup 1 --no-cpu-baseline --no-subrecords --no-profile --gen-rows 0 > $O/${R}_write_w.log 2>&1
 python scripts/pmc_traffic.py $O/${R}_fetch_w $O/${R}_write_w 4 > $O/${R}_out/${R}_pmc_traffic_w1024.json
 rm -rf $O/${R}_fetch_w $O/${R}_write_w
 echo "[8c] SQ counter passes (VALU / LDS / MFMA / waits per kernel), S64 training step"

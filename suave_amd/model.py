@@ -410,6 +410,9 @@ class SUAVE:
         val = self._table(X_val, row_base=int(va_b), n_global=n_val) if n_val else None
         self._dp = parallel.DataParallel.from_environment(self._layout, eng.device)
         if self._dp is not None:
+            # one arithmetic on every rank: a rank whose block of a sharded table left fp16's range switched by itself
+            if any(int(m) != 4 for m in parallel.all_gather_objects(self._arithmetic())):
+                self._use_wide_arithmetic("another rank's rows exceed fp16's range")
             if self._replay is not None:
                 raise RuntimeError("recorded draws (parity tests) are per batch row and cannot be replayed on sharded batches")
             if not self._sharded:
