@@ -570,7 +570,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     a.encout = w.encout; a.ldE = p->ldE; a.K = K; a.D = D; a.ldK = p->ldK; a.ldD = p->ldD; a.n_rows = B;
     a.row_index = batch->row_index; a.row_begin = batch->row_begin; a.exp_noise = nz->exp_noise; a.eps_in = nz->eps;
     a.seed = nz->seed; a.step = nz->step; a.tau = tau_c; a.w = w.ysoft; a.wflat = wflat; a.z_all = w.z;
-    a.eps_buf = w.eps; a.latent_out = out ? out->latent : nullptr;
+    a.eps_buf = w.eps; a.latent_out = out ? out->latent : nullptr; a.rb = mix_rows_per_block(B);
     if (int rc = launch_mix_fwd(a, s)) return rc;
   }
   act = w.z;
@@ -635,7 +635,8 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     }
     if (int rc = bwd_data(p, params, *lcur, dcur, lddcur, w.dz, p->ldD, V, nullptr, 0.f, s, w.wT[layer_index(p, lcur)])) return rc;
   }
-  const int fgrid = std::max(1, std::min((B + 63) / 64, 2 * p->n_cu));
+  const int mix_rb = mix_rows_per_block(B);
+  const int fgrid = std::max(1, std::min((B + mix_rb - 1) / mix_rb, 2 * p->n_cu));
   {
     MixFinArgs a{};
     a.encout = w.encout; a.ldE = p->ldE; a.K = K; a.D = D; a.ldK = p->ldK; a.ldD = p->ldD; a.n_rows = B;
@@ -643,7 +644,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     a.w = w.ysoft; a.eps_buf = w.eps; a.recon_part = w.recon_part; a.dz_all = w.dz; a.tau = tau_c;
     a.c_up = -1.0f / (float)global_rows; a.bk = beta_scale / (float)global_rows;
     a.recon = w.recon; a.catkl = w.catkl; a.gausskl = w.gausskl; a.dencout = w.dencout; a.prior_terms = w.prior_terms;
-    a.sums_slab = w.sums_slab;
+    a.sums_slab = w.sums_slab; a.rb = mix_rb;
     if (int rc = launch_mix_finalize(a, grad, fgrid, s)) return rc;
   }
   red.sums_slab = w.sums_slab;
@@ -654,7 +655,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     // PriorMean gradients: column sums of prior_terms -> linear.weight[d,k] and linear.bias[d]
     {
       const int ncol = K * D + D;
-      const int nb = std::max(1, std::min(lgrid, (B + 255) / 256));
+      const int nb = std::max(1, std::min(lgrid, (B + 31) / 32));  // (the slab holds loss_workers >= lgrid of them)
       if (int rc = launch_colsum(w.prior_terms, ldT, B, ncol, w.slab + slab_off, nb, s)) return rc;
       SUAVE_REQUIRE(red.n_segs + 3 <= kMaxReduceSegs, "too many reduction segments");
       ReduceSeg sw{};

@@ -215,8 +215,10 @@ __global__ __launch_bounds__(256) void k_head_weight_sum(const int32_t* targets,
 }  // namespace
 
 // rows per tile / LDS bytes of k_head_loss for a head of C classes on D inputs; 0 rows: outside the kernel's shapes
-static int head_tile_rows(int C, int D, size_t* lds_bytes) {
+// (small batches take 64-row tiles whatever fits: a 256-row batch is then four blocks of short loops instead of one)
+static int head_tile_rows(int C, int D, size_t* lds_bytes, int64_t n = int64_t(1) << 40) {
   for (int R : {256, 128, 64}) {
+    if (n <= 8192 && R > 64) continue;
     const size_t b = sizeof(float) * (2 * (size_t)(C * D + C) + (size_t)D * (R + 1) + (size_t)C * R + 2 * (R / 64));
     if (b <= 144 * 1024) { *lds_bytes = b; return R; }
   }
@@ -240,7 +242,7 @@ int launch_head_loss(const suave_head_t& h, int D, const float* latent, int ld, 
   SUAVE_REQUIRE(h.dropout >= 0.f && h.dropout < 1.f, "classifier head: dropout must be in [0, 1)");
   const int C = h.n_classes;
   size_t lds = 0;
-  const int R = head_tile_rows(C, D, &lds);
+  const int R = head_tile_rows(C, D, &lds, n);
   float* wsp = static_cast<float*>(h.workspace);
   float* wsum_cell = wsp + (size_t)kHeadMaxBlocks * (C * D + C + 2);
   const float* wsum = h.weight_sum;

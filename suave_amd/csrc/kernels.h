@@ -158,11 +158,13 @@ struct MixFwdArgs {
   float* z_all;            // [B*K, ldD]
   float* eps_buf;          // [B*K, ldD]
   float* latent_out;       // [B, D] or null: sum_k w_k z_k
+  int rb;                  // table rows per block (<= 64): 8 for small batches, so that a few hundred rows still fill CUs
 };
 
 struct MixFinArgs {
   const float* encout;
   int ldE, K, D, ldK, ldD, n_rows, n_chunks, ldT;
+  int rb;                  // table rows per block (<= 64), as in MixFwdArgs
   const float* params;
   int pm_w_off, pm_b_off;
   const float* w;          // [B, ldK]
@@ -212,6 +214,7 @@ int launch_unpack_columns(const suave_unpack_col_t* cols_dev, int n_cols, int64_
                           const int16_t* out_codes, int ld_disc, float* f32_block, int64_t* i64_block, int16_t* i16_block,
                           int8_t* i8_block, int64_t ld_rows, hipStream_t s);
 
+int mix_rows_per_block(int n_rows);
 int launch_mix_fwd(const MixFwdArgs& a, hipStream_t s);
 int launch_mix_finalize(const MixFinArgs& a, bool grad, int grid, hipStream_t s);
 int launch_colsum(const float* src, int ld, int n_rows, int n_cols, float* slab, int n_blocks, hipStream_t s);

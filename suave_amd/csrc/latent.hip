@@ -773,9 +773,9 @@ __global__ __launch_bounds__(256) void k_mix_fwd(MixFwdArgs a) {
   __shared__ float w_s[64 * SUAVE_MAX_COMPONENTS];
   const int tid = threadIdx.x;
   const Philox rng(a.seed);
-  const int K = a.K, D = a.D;
-  for (int r0 = blockIdx.x * 64; r0 < a.n_rows; r0 += gridDim.x * 64) {
-    const int nrows = min(64, a.n_rows - r0);
+  const int K = a.K, D = a.D, RB = a.rb;
+  for (int r0 = blockIdx.x * RB; r0 < a.n_rows; r0 += gridDim.x * RB) {
+    const int nrows = min(RB, a.n_rows - r0);
     __syncthreads();
     if (tid < nrows) {
       const int r = r0 + tid;
@@ -858,10 +858,10 @@ __global__ __launch_bounds__(256) void k_mix_finalize(MixFinArgs a) {
   __shared__ float kl_s[64 * SUAVE_MAX_COMPONENTS];
   __shared__ float red_s[3 * 64];
   const int tid = threadIdx.x;
-  const int K = a.K, D = a.D;
+  const int K = a.K, D = a.D, RB = a.rb;
   double s_rec = 0.0, s_cat = 0.0, s_gau = 0.0;
-  for (int r0 = blockIdx.x * 64; r0 < a.n_rows; r0 += gridDim.x * 64) {
-    const int nrows = min(64, a.n_rows - r0);
+  for (int r0 = blockIdx.x * RB; r0 < a.n_rows; r0 += gridDim.x * RB) {
+    const int nrows = min(RB, a.n_rows - r0);
     __syncthreads();
     for (int idx = tid; idx < nrows * K; idx += 256) {
       const int lr = idx / K, k = idx % K;
@@ -869,16 +869,19 @@ __global__ __launch_bounds__(256) void k_mix_finalize(MixFinArgs a) {
       kl_s[lr * SUAVE_MAX_COMPONENTS + k] = 0.f;
     }
     __syncthreads();
-    // per (row, component, latent dim): KL term and gradients of mu / logvar; KL summed over d per (row, k)
-    for (int idx = tid; idx < nrows * K; idx += 256) {
-      const int lr = idx / K, k = idx % K;
+    // per (row, component, latent dim): KL term and gradients of mu / logvar; KL summed over d per (row, k).
+    // Eight lanes per (row, component): lane g takes d = g, g + 8, ... (32-byte runs of every array per group and
+    // instruction) and the eight partial KL sums meet by a fixed butterfly of shuffles -- the same order every run.
+    for (int idx = tid; idx < nrows * K * 8; idx += 256) {
+      const int pk = idx >> 3, g = idx & 7;
+      const int lr = pk / K, k = pk % K;
       const int r = r0 + lr;
       const float* mu = a.encout + (size_t)r * a.ldE + K + k * D;
       const float* lv = mu + K * D;
       const float wk = w_s[lr * SUAVE_MAX_COMPONENTS + k];
       const size_t v = (size_t)r * K + k;
       float kl = 0.f;
-      for (int d = 0; d < D; ++d) {
+      for (int d = g; d < D; d += 8) {
         const float pm = a.params[a.pm_w_off + d * K + k] + a.params[a.pm_b_off + d];  // prior.py:31-39
         const float raw = lv[d];
         const float lvc = fminf(fmaxf(raw, kLogvarMin), kLogvarMax);
@@ -896,7 +899,10 @@ __global__ __launch_bounds__(256) void k_mix_finalize(MixFinArgs a) {
           a.prior_terms[(size_t)r * a.ldT + k * D + d] = -gm;
         }
       }
-      kl_s[lr * SUAVE_MAX_COMPONENTS + k] = kl;
+      kl += __shfl_xor(kl, 1, 64);
+      kl += __shfl_xor(kl, 2, 64);
+      kl += __shfl_xor(kl, 4, 64);
+      if (g == 0) kl_s[lr * SUAVE_MAX_COMPONENTS + k] = kl;
     }
     __syncthreads();
     if (tid < nrows) {
@@ -1056,13 +1062,19 @@ int launch_prior_colsum(const float* terms, int ldT, const int32_t* kidx, int n_
 int launch_mix_fwd(const MixFwdArgs& a, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
   ProfScope prof_scope(kProfLatent, s);
-  hipLaunchKernelGGL(k_mix_fwd, dim3(std::min((a.n_rows + 63) / 64, 2048)), dim3(256), 0, s, a);
+  SUAVE_REQUIRE(a.rb >= 1 && a.rb <= 64, "mix_fwd: rows per block must be 1..64");
+  hipLaunchKernelGGL(k_mix_fwd, dim3(std::min((a.n_rows + a.rb - 1) / a.rb, 2048)), dim3(256), 0, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
+// table rows per block of the two mixture kernels: 64 at training batch sizes; 8 below 16 384 rows, where 64-row blocks
+// leave the chip empty and every thread walks 80+ dependent elements (a 256-row M20 step: 130 us -> see DESIGN.md)
+int mix_rows_per_block(int n_rows) { return n_rows >= 16384 ? 64 : 8; }
+
 int launch_mix_finalize(const MixFinArgs& a, bool grad, int grid, hipStream_t s) {
   if (a.n_rows <= 0) return 0;
+  SUAVE_REQUIRE(a.rb >= 1 && a.rb <= 64 && grid >= 1, "mix_finalize: rows per block must be 1..64");
   ProfScope prof_scope(kProfLatent, s);
   if (grad) hipLaunchKernelGGL((k_mix_finalize<true>), dim3(grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((k_mix_finalize<false>), dim3(grid), dim3(256), 0, s, a);
