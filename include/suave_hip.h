@@ -374,6 +374,13 @@ int suave_decode_static_max_rows(const suave_plan* plan, int32_t dense_assignmen
 int suave_posterior_draws(const suave_plan* plan, const float* enc_out, int64_t n_rows, int32_t n_draws,
                           const float* e, const float* eps, uint64_t seed, int64_t row_offset, void* stream,
                           float* z, int32_t* component);
+/* The same draws (same keys, same bits) laid out by TABLE ROW: draw l of row b is output row b * L + l, so a
+ * row's draws are contiguous and a decode of them with row_offset * L keys every decoded row by (global table
+ * row, draw) whatever the chunking or the sharding (impute_mc / predict_* of the Python host).  Injected e / eps
+ * keep the reference's draw-major layout [L, n_rows, .]. */
+int suave_posterior_draws_by_row(const suave_plan* plan, const float* enc_out, int64_t n_rows, int32_t n_draws,
+                                 const float* e, const float* eps, uint64_t seed, int64_t row_offset, void* stream,
+                                 float* z, int32_t* component);
 
 /* Decoder pass + parameters of ONE head: the `params` of
  * SUAVE._posterior_predictive_params (model.py:3349-3386; head outputs

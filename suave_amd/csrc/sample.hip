@@ -392,6 +392,7 @@ struct PostDrawArgs {
   int B, L, K, D;
   float* z;              // [L*B, D]
   int32_t* comp;         // [L*B]
+  int row_major;         // output row of (row b, draw l): l * B + b (the reference's order), or b * L + l
 };
 
 __global__ __launch_bounds__(256) void k_posterior_draws(PostDrawArgs a) {
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(256) void k_posterior_draws(PostDrawArgs a) {
   const int E = a.K + 2 * a.K * a.D;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
     const int b = (int)(v % a.B);
+    const int64_t vo = a.row_major ? (int64_t)b * a.L + v / a.B : v;  // (injected draws are always draw-major: v)
     // generator key of (table row row_offset + b, draw l): independent of how the rows are chunked or sharded
     const uint64_t gid = (uint64_t)(a.row_offset + b) * (uint64_t)a.L + (uint64_t)(v / a.B);
     const float* row = a.enc_out + (size_t)b * E;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(256) void k_posterior_draws(PostDrawArgs a) {
       const float sc = detm::sub(row[j], detm::log(e));
       if (sc > best) { best = sc; kb = j; }
     }
-    a.comp[v] = kb;
+    a.comp[vo] = kb;
     const float* mu = row + a.K + kb * a.D;
     const float* lv = mu + a.K * a.D;
     for (int d = 0; d < a.D; d += 2) {
@@ -429,8 +431,8 @@ __global__ __launch_bounds__(256) void k_posterior_draws(PostDrawArgs a) {
         const float2 n2 = normal2(w.x, w.y);
         e0 = n2.x; e1 = n2.y;
       }
-      a.z[(size_t)v * a.D + d] = mu[d] + e0 * __expf(0.5f * lv[d]);
-      if (d + 1 < a.D) a.z[(size_t)v * a.D + d + 1] = mu[d + 1] + e1 * __expf(0.5f * lv[d + 1]);
+      a.z[(size_t)vo * a.D + d] = mu[d] + e0 * __expf(0.5f * lv[d]);
+      if (d + 1 < a.D) a.z[(size_t)vo * a.D + d + 1] = mu[d + 1] + e1 * __expf(0.5f * lv[d + 1]);
     }
   }
 }
@@ -454,6 +456,7 @@ __global__ __launch_bounds__(256) void k_posterior_draws8(PostDrawArgs a) {
     for (int u = 0; u < 4; ++u) lg[u] = 4 * l8 + u < K ? row[4 * l8 + u] : 0.f;
     for (int l = 0; l < a.L; ++l) {
       const int64_t v = (int64_t)l * a.B + b;
+      const int64_t vo = a.row_major ? b * a.L + l : v;
       const uint64_t gid = (uint64_t)(a.row_offset + b) * (uint64_t)a.L + (uint64_t)l;
       const uint32_t glo = (uint32_t)gid, ghi = (uint32_t)(gid >> 32);
       float best = -INFINITY;
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(256) void k_posterior_draws8(PostDrawArgs a) {
         const int ok = __shfl_xor(kb, off, 64);
         if (ob > best || (ob == best && ok < kb)) { best = ob; kb = ok; }
       }
-      if (l8 == 0) a.comp[v] = kb;
+      if (l8 == 0) a.comp[vo] = kb;
       const float* mu = row + K + kb * D;
       const float* lv = mu + K * D;
       for (int q = l8; q < dq; q += 8) {
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(256) void k_posterior_draws8(PostDrawArgs a) {
         float zz[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) zz[u] = mu[4 * q + u] + ev[u] * __expf(0.5f * lv[4 * q + u]);
-        *reinterpret_cast<float4*>(a.z + (size_t)v * D + 4 * q) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        *reinterpret_cast<float4*>(a.z + (size_t)vo * D + 4 * q) = make_float4(zz[0], zz[1], zz[2], zz[3]);
       }
     }
   }
@@ -673,9 +676,9 @@ extern "C" int suave_conditional_latents(const suave_plan* p, const int64_t* cla
   return 0;
 }
 
-extern "C" int suave_posterior_draws(const suave_plan* p, const float* enc_out, int64_t n_rows, int32_t n_draws,
-                                     const float* e, const float* eps, uint64_t seed, int64_t row_offset, void* stream,
-                                     float* z, int32_t* component) {
+static int posterior_draws_impl(const suave_plan* p, const float* enc_out, int64_t n_rows, int32_t n_draws, const float* e,
+                                const float* eps, uint64_t seed, int64_t row_offset, void* stream, float* z,
+                                int32_t* component, int row_major) {
   suave::drop_stale_hip_error();
   SUAVE_REQUIRE(p, "posterior_draws: null plan");
   SUAVE_REQUIRE(n_draws >= 1, "posterior_draws: L must be a positive integer");  // model.py:3313-3314
@@ -684,7 +687,7 @@ extern "C" int suave_posterior_draws(const suave_plan* p, const float* enc_out, 
   SUAVE_REQUIRE(enc_out && z && component, "posterior_draws: null argument");
   PostDrawArgs a{};
   a.enc_out = enc_out; a.e = e; a.eps = eps; a.seed = seed; a.row_offset = row_offset; a.B = (int)n_rows; a.L = n_draws;
-  a.K = p->model.n_components; a.D = p->model.latent_dim; a.z = z; a.comp = component;
+  a.K = p->model.n_components; a.D = p->model.latent_dim; a.z = z; a.comp = component; a.row_major = row_major;
   const int64_t total = n_rows * n_draws;
   const bool aligned = (reinterpret_cast<uintptr_t>(z) & 15) == 0 && (!eps || (reinterpret_cast<uintptr_t>(eps) & 15) == 0);
   if (a.D % 4 == 0 && a.K <= 32 && aligned)
@@ -695,4 +698,16 @@ extern "C" int suave_posterior_draws(const suave_plan* p, const float* enc_out, 
                        static_cast<hipStream_t>(stream), a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int suave_posterior_draws(const suave_plan* p, const float* enc_out, int64_t n_rows, int32_t n_draws,
+                                     const float* e, const float* eps, uint64_t seed, int64_t row_offset, void* stream,
+                                     float* z, int32_t* component) {
+  return posterior_draws_impl(p, enc_out, n_rows, n_draws, e, eps, seed, row_offset, stream, z, component, 0);
+}
+
+extern "C" int suave_posterior_draws_by_row(const suave_plan* p, const float* enc_out, int64_t n_rows, int32_t n_draws,
+                                            const float* e, const float* eps, uint64_t seed, int64_t row_offset,
+                                            void* stream, float* z, int32_t* component) {
+  return posterior_draws_impl(p, enc_out, n_rows, n_draws, e, eps, seed, row_offset, stream, z, component, 1);
 }

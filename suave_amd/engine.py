@@ -382,14 +382,10 @@ class Engine:
         D = self.layout.latent_dim
         z = torch.empty((L * B, D), dtype=torch.float32, device=self.device)
         comp = torch.empty((L * B,), dtype=torch.int32, device=self.device)
-        rc = self.lib.suave_posterior_draws(self._plan, enc_out.data_ptr(), B, int(L), _ptr(e), _ptr(eps), int(seed),
-                                            int(row_offset), self._stream(), z.data_ptr(), comp.data_ptr())
+        fn = self.lib.suave_posterior_draws_by_row if row_major else self.lib.suave_posterior_draws
+        rc = fn(self._plan, enc_out.data_ptr(), B, int(L), _ptr(e), _ptr(eps), int(seed), int(row_offset), self._stream(),
+                z.data_ptr(), comp.data_ptr())
         _lib.check(rc, "suave_posterior_draws")
-        if row_major and L > 1 and B > 0:
-            # row b's draws become rows b L .. b L + L - 1: a decode of them with row_offset = (first table row) * L
-            # keys (row, draw) by (global row) * L + draw, whatever the chunking or the sharding
-            z = z.view(L, B, D).transpose(0, 1).reshape(B * L, D).contiguous()
-            comp = comp.view(L, B).transpose(0, 1).reshape(-1).contiguous()
         return z, comp
 
     def decode_log_px(self, z: torch.Tensor, component: torch.Tensor, table: PackedTable, row_begin: int = 0, *,

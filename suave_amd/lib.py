@@ -33,6 +33,7 @@ EXPORTS = (
     "suave_decode_sample",
     "suave_decode_sample_static",
     "suave_posterior_draws",
+    "suave_posterior_draws_by_row",
     "suave_encode_hard",
     "suave_rng_draws",
     "suave_decode_static_max_rows",
@@ -105,6 +106,7 @@ def load():
     lib.suave_decode_sample.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, u64, i64, vp, sz, vp, vp, i32, vp, i32, vp]
     lib.suave_decode_sample_static.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, u64, i64, vp, vp, i32, vp, i32, vp]
     lib.suave_posterior_draws.argtypes = [vp, vp, i64, i32, vp, vp, u64, i64, vp, vp, vp]
+    lib.suave_posterior_draws_by_row.argtypes = [vp, vp, i64, i32, vp, vp, u64, i64, vp, vp, vp]
     lib.suave_head_params_width.argtypes = [vp, i32, C.POINTER(i32)]
     lib.suave_decode_params.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, sz, vp, vp]
     lib.suave_decode_log_px.argtypes = [vp, vp, vp, vp, C.POINTER(BatchT), vp, sz, vp, vp, vp]

@@ -350,3 +350,24 @@ def test_posterior_draws_lane_group_kernel_equals_the_scalar_kernel(s64):
     assert torch.equal(k_a, k_b)
     assert torch.equal(z_a.reshape(-1), z_b)
     assert int(k_a.min()) >= 0 and int(k_a.max()) < layout.n_components
+
+
+def test_posterior_draws_by_row_is_the_transposed_draw_major_output(s64):
+    """suave_posterior_draws_by_row: same keys and bits as suave_posterior_draws, output row b * L + l."""
+
+    import torch
+
+    eng, table, layout = s64
+    K, D, L, n = layout.n_components, layout.latent_dim, 7, 3001
+    enc = eng.encode(table, 500, n)["enc_out"]
+    z0, k0 = eng.posterior_draws(enc, L, seed=13, row_offset=500)
+    z1, k1 = eng.posterior_draws(enc, L, seed=13, row_offset=500, row_major=True)
+    assert torch.equal(z1, z0.view(L, n, D).transpose(0, 1).reshape(n * L, D))
+    assert torch.equal(k1, k0.view(L, n).transpose(0, 1).reshape(-1))
+    g = torch.Generator(device=eng.device).manual_seed(2)
+    e = torch.empty((L, n, K), device=eng.device).exponential_(generator=g)
+    eps = torch.randn((L, n, D), device=eng.device, generator=g)
+    z2, k2 = eng.posterior_draws(enc, L, e=e, eps=eps)
+    z3, k3 = eng.posterior_draws(enc, L, e=e, eps=eps, row_major=True)  # injected draws stay draw-major
+    assert torch.equal(z3, z2.view(L, n, D).transpose(0, 1).reshape(n * L, D))
+    assert torch.equal(k3, k2.view(L, n).transpose(0, 1).reshape(-1))
