@@ -179,15 +179,22 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bid, cons
 
   // XCD-aware tile order: blocks id, id+8, ... run on one XCD and share its L2,
   // so give them the column tiles of the same row tile (they re-read one A tile).
+  // Many column tiles (tiles_n >= 16: the 1 024-column schema's y_projection, 133 of them): an XCD walks the column
+  // tiles of TWO of its row tiles together, row tile fastest, so each B (weight) tile comes out of HBM once per two
+  // row tiles (W1024 y_projection forward: 1.39 -> 1.32 ms; four or eight row tiles together were slower, 1.40 /
+  // 1.58 ms: the kernel is at its compute rate, 218 TFLOP/s, and the wider write footprint costs more than the
+  // weight re-reads save).
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   int id = bid, tile_m, tile_n;
   {
-    const int full = (tiles_m / 8) * 8;
+    const int G = tiles_n >= 16 ? 2 : 1;                 // row tiles of one XCD walked together
+    const int full = (tiles_m / (8 * G)) * (8 * G);
     const int n_full = full * tiles_n;
     if (id < n_full) {
       const int xcd = id & 7, w = id >> 3;
-      tile_m = (w / tiles_n) * 8 + xcd;
-      tile_n = w % tiles_n;
+      const int grp = w / (G * tiles_n), wi = w - grp * (G * tiles_n);
+      tile_m = (grp * G + wi % G) * 8 + xcd;
+      tile_n = wi / G;
     } else {
       const int r = id - n_full;
       tile_m = full + r / tiles_n;
