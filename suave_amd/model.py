@@ -632,16 +632,16 @@ class SUAVE:
             return m
         was_training = self._classifier.training
         self._classifier.eval()
-        with torch.no_grad():
-            logits = self._classifier(self._posterior_mean(val))
-            m["classification_loss"] = float(self._classifier.loss(logits, y_val_t).item())
-            probs = torch.softmax(logits, dim=-1).cpu().numpy()
-        t = y_val_t.cpu().numpy()
-        for key, fn in (("brier", sup.compute_brier), ("ece", sup.compute_ece), ("auroc", sup.compute_auroc)):
-            try:
-                m[key] = float(fn(probs, t))
-            except ValueError:
-                m[key] = float("nan")
+        with torch.no_grad():  # logits, weighted CE and the three metrics stay on the device: one sync for all four
+            hd = getattr(self, "_dev_head", None)
+            if hd is not None and hd.clf is self._classifier and self._device_head(hd.targets) is not None:
+                logits, ce = hd.evaluate(self._engine, self._posterior_mean(val), y_val_t)
+            else:
+                logits = self._classifier(self._posterior_mean(val))
+                ce = self._classifier.loss(logits, y_val_t).to(torch.float64).reshape(1)
+            vals = torch.cat([ce, sup.device_classification_metrics(torch.softmax(logits, dim=-1), y_val_t)]).cpu().numpy()
+        for key, v in zip(("classification_loss", "brier", "ece", "auroc"), vals):
+            m[key] = float(v)
         if weight is not None:
             ok = math.isfinite(m["classification_loss"]) and math.isfinite(m["nll"])
             m["joint_objective"] = m["nll"] + float(weight) * m["classification_loss"] if ok else float("nan")

@@ -167,8 +167,10 @@ class DeviceHead:
         self.t = 0
 
     def struct(self, *, training: bool, loss_scale: float, loss_rows: float, key: int = 0,
-               weight_sum: Optional[torch.Tensor] = None, adam_lr: float = 0.0, want_grads: bool = True):
-        """A ``suave_head_t`` for one call.  ``adam_lr`` > 0 advances the head's Adam step counter."""
+               weight_sum: Optional[torch.Tensor] = None, adam_lr: float = 0.0, want_grads: bool = True,
+               targets: Optional[torch.Tensor] = None):
+        """A ``suave_head_t`` for one call.  ``adam_lr`` > 0 advances the head's Adam step counter.  ``targets``
+        (int32, device) replaces the training targets (validation rows)."""
 
         from .plan import HeadT
 
@@ -178,7 +180,7 @@ class DeviceHead:
         h.n_classes, h.training = self.C, int(bool(training))
         h.params, h.grads = self.flat.data_ptr(), (self.grads.data_ptr() if want_grads else None)
         h.class_weight = None if self.class_weight is None else self.class_weight.data_ptr()
-        h.targets = self.targets.data_ptr()
+        h.targets = (self.targets if targets is None else targets).data_ptr()
         h.weight_sum = None if weight_sum is None else weight_sum.data_ptr()
         h.loss_scale, h.loss_rows = float(loss_scale), float(loss_rows)
         h.loss_sum = self.loss_sum.data_ptr()
@@ -187,6 +189,23 @@ class DeviceHead:
         h.adam_m, h.adam_v = self.m.data_ptr(), self.v.data_ptr()
         h.workspace, h.workspace_bytes = self.ws.data_ptr(), int(self.ws.numel())
         return h
+
+    def evaluate(self, engine, latent: torch.Tensor, targets: torch.Tensor):
+        """Eval-mode logits [n, C] and the class-weighted cross-entropy (a device scalar, float64) of ``latent`` [n, D]
+        against ``targets`` [n] -- the library's head kernel instead of a torch linear (no BLAS handle, one launch pair)."""
+
+        n = int(latent.shape[0])
+        latent = latent.contiguous()
+        t32 = targets.to(torch.int32).contiguous()
+        rows = torch.arange(n, dtype=torch.int32, device=latent.device)
+        logits = torch.empty((n, self.C), dtype=torch.float32, device=latent.device)
+        keep = self.loss_sum.clone()
+        self.loss_sum.zero_()
+        engine.head_step(self.struct(training=False, loss_scale=1.0, loss_rows=1.0, want_grads=False, targets=t32), latent, rows,
+                         logits=logits)
+        ce = self.loss_sum.clone()
+        self.loss_sum.copy_(keep)
+        return logits, ce
 
     def batch_weight(self, rows: torch.Tensor) -> torch.Tensor:
         """Sum of the class weights over the targets of ``rows`` (the GLOBAL batch of a data-parallel step): a device scalar."""
@@ -307,6 +326,56 @@ def compute_ece(probabilities: np.ndarray, targets: np.ndarray, n_bins: int = 10
         if sel.any():
             ece += sel.mean() * abs(correct[sel].mean() - conf[sel].mean())
     return float(ece)
+
+
+def device_classification_metrics(probabilities: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    """``[brier, ece, auroc]`` (float64, on the tensors' device) of ``compute_brier`` / ``compute_ece`` /
+    ``compute_auroc`` above -- the validation metrics of model.py:2609-2622 (evaluate.py:88-297) without moving the
+    probabilities to the host: squared errors and calibration bins are reductions, AUROC is the rank statistic with
+    average ranks over ties (one sort per class; ``unique_consecutive`` gives the tie groups).  An undefined AUROC
+    (one class only) is NaN, where the host function raises.  One small tensor: one sync for the caller."""
+
+    p = probabilities.detach().to(torch.float64)
+    t = targets.reshape(-1).to(torch.int64)
+    n, C = int(p.shape[0]), int(p.shape[1])
+    nan = torch.full((), float("nan"), dtype=torch.float64, device=p.device)
+    if n == 0:
+        return torch.stack([nan, nan, nan])
+    binary = C == 2
+    if binary:
+        brier = ((p[:, 1] - t.to(torch.float64)) ** 2).mean()
+        conf, correct = p[:, 1], (t == 1).to(torch.float64)
+    else:
+        brier = ((p - F.one_hot(t, C).to(torch.float64)) ** 2).sum(dim=1).mean()
+        conf, arg = p.max(dim=1)
+        correct = (arg == t).to(torch.float64)
+    # bins (lo, hi] (the first one closed at 0): bucketize against the nine inner edges of np.linspace(0, 1, 11)
+    inner = torch.from_numpy(np.linspace(0.0, 1.0, 11)[1:-1].copy()).to(p.device)
+    idx = torch.bucketize(conf.contiguous(), inner, right=False)
+    cnt = torch.bincount(idx, minlength=10).to(torch.float64)
+    s_conf = torch.bincount(idx, weights=conf, minlength=10)
+    s_corr = torch.bincount(idx, weights=correct, minlength=10)
+    safe = cnt.clamp_min(1.0)
+    ece = torch.where(cnt > 0, (cnt / n) * (s_corr / safe - s_conf / safe).abs(), torch.zeros_like(cnt)).sum()
+
+    def auc(score: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        pos = y.sum().to(torch.float64)
+        neg = float(n) - pos
+        srt, order = torch.sort(score)
+        _, inv, counts = torch.unique_consecutive(srt, return_inverse=True, return_counts=True)
+        cd = counts.to(torch.float64)
+        avg_rank = cd.cumsum(0) - (cd - 1.0) * 0.5           # 1-based ranks, averaged over a tie group
+        rsum = (avg_rank[inv] * y[order].to(torch.float64)).sum()
+        val = (rsum - pos * (pos + 1.0) * 0.5) / (pos * neg).clamp_min(1.0)
+        return torch.where((pos > 0) & (neg > 0), val, nan)
+
+    if binary:
+        auroc = auc(p[:, 1], t == 1)
+    else:
+        vals = torch.stack([auc(p[:, c], t == c) for c in range(C)])
+        ok = ~torch.isnan(vals)
+        auroc = torch.where(ok.any(), torch.where(ok, vals, torch.zeros_like(vals)).sum() / ok.sum().clamp_min(1), nan)
+    return torch.stack([brier, ece, auroc])
 
 
 def is_better_metrics(candidate: Dict[str, float], best: Dict[str, float]) -> bool:

@@ -234,3 +234,33 @@ def test_row_sharded_host_logic():
                     assert abs(part[col][key] - v) <= 1e-12 * max(1.0, abs(v)), (col, key)
                 else:
                     assert part[col][key] == v, (col, key)
+
+
+def test_device_classification_metrics_match_the_host_functions():
+    """supervised.device_classification_metrics (torch reductions / sorts, run on the device inside fit) against the
+    numpy statements of evaluate.py's Brier / ECE / AUROC it replaces on the validation path, ties included."""
+
+    import numpy as np
+    import torch
+
+    from suave_amd import supervised as sup
+
+    rng = np.random.default_rng(0)
+    for C, n in ((2, 1000), (3, 777), (5, 64)):
+        logits = rng.normal(size=(n, C)).astype(np.float32) * 2
+        logits[::7] = logits[0]            # exact ties in every score column
+        logits = np.round(logits, 1)       # and many more
+        p = torch.softmax(torch.from_numpy(logits), dim=-1)
+        t = rng.integers(0, C, n)
+        got = sup.device_classification_metrics(p, torch.from_numpy(t)).numpy()
+        pn = p.numpy()
+        want = [sup.compute_brier(pn, t), sup.compute_ece(pn, t), sup.compute_auroc(pn, t)]
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-14), (C, got, want)
+    # probabilities on bin edges, one class only (AUROC undefined -> NaN), empty input
+    p = torch.tensor([[0.9, 0.1], [0.8, 0.2], [0.0, 1.0], [1.0, 0.0], [0.5, 0.5]], dtype=torch.float32)
+    t = np.array([0, 0, 1, 0, 1])
+    got = sup.device_classification_metrics(p, torch.from_numpy(t)).numpy()
+    assert np.allclose(got, [sup.compute_brier(p.numpy(), t), sup.compute_ece(p.numpy(), t), sup.compute_auroc(p.numpy(), t)])
+    one = sup.device_classification_metrics(p, torch.zeros(5, dtype=torch.int64)).numpy()
+    assert np.isfinite(one[0]) and np.isfinite(one[1]) and np.isnan(one[2])
+    assert np.isnan(sup.device_classification_metrics(p[:0], torch.zeros(0, dtype=torch.int64)).numpy()).all()
