@@ -7,7 +7,7 @@ set -e -o pipefail
 R=${1:-r02}
 O=gpurun_out
 export TMPDIR=/tmp
-RAW="$O/${R}_stats $O/${R}_stats_train $O/${R}_fetch $O/${R}_write $O/${R}_fetch_t $O/${R}_write_t $O/${R}_tl_s64 $O/${R}_tl_w $O/${R}_fetch_w $O/${R}_write_w $O/${R}_pmc_sq"
+RAW="$O/${R}_stats $O/${R}_stats_train $O/${R}_fetch $O/${R}_write $O/${R}_fetch_t $O/${R}_write_t $O/${R}_tl_s64 $O/${R}_tl_w $O/${R}_fetch_w $O/${R}_write_w $O/${R}_pmc_sq/p1 $O/${R}_pmc_sq/p2 $O/${R}_pmc_sq/p3"
 trap 'echo "exit status $? at line $LINENO"; rm -rf $RAW' EXIT  # the raw traces exceed what gpurun copies back
 rm -rf $O/${R}_stats $O/${R}_stats_train $O/${R}_fetch $O/${R}_write $O/${R}_fetch_t $O/${R}_write_t $O/${R}_tl_s64 $O/${R}_tl_w
 echo "[1/9] kernel stats, default command"
@@ -43,8 +43,7 @@ timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/${R}_write_w --output-forma
 python scripts/pmc_traffic.py $O/${R}_fetch_w $O/${R}_write_w 4 > $O/${R}_out/${R}_pmc_traffic_w1024.json
 rm -rf $O/${R}_fetch_w $O/${R}_write_w
 echo "[8c] SQ counter passes (VALU / LDS / MFMA / waits per kernel), S64 training step"
-bash scripts/pmc_kernels.sh ${R}_pmc_sq
-cp $O/${R}_pmc_sq_summary.txt $O/${R}_out/${R}_pmc_sq_summary.txt
+if bash scripts/pmc_kernels.sh ${R}_pmc_sq; then cp $O/${R}_pmc_sq_summary.txt $O/${R}_out/${R}_pmc_sq_summary.txt; else echo "SQ passes failed: see $O/${R}_pmc_sq/*.log (rerun scripts/pmc_kernels.sh on its own)"; fi
 echo "[9/9] W1024 bench line"
 timeout -k 10 600 python bench.py --config w1024 > $O/${R}_bench_w1024.json 2> $O/${R}_bench_w1024.err
 echo done
