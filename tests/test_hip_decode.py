@@ -577,3 +577,20 @@ def test_golden_per_column_log_px(name):
     assert rel_err(lp2.astype(np.float64).sum(axis=1), rec) < 1e-5
     mask = fx["mask"].astype(bool)
     assert not lp2[~mask].any() and not res["log_px_missing"].cpu().numpy()[mask].any()
+
+
+def test_fused_decode_agrees_with_the_per_layer_path_on_random_shapes(monkeypatch):
+    """scripts/decode_fuzz.py, twelve random (schema, K, D, hidden, n) cases: the same rows through component indices
+    (k_decode_fused where the shape allows) and through one-hot dense assignments (per-layer GEMMs + k_sample_heads)
+    with the same generator keys -- discrete cells and counts bit for bit, numeric values to 2e-4, y_full to 1e-4."""
+
+    import importlib.util
+    import os
+    import sys
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "decode_fuzz.py")
+    spec = importlib.util.spec_from_file_location("decode_fuzz", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["decode_fuzz.py", "12", "3"])
+    assert mod.main() == 0
