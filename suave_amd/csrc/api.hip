@@ -236,7 +236,7 @@ void carve(const suave_plan* p, int64_t rows, void* base, Workspace* w) {
     const int Mt = 2 * m.latent_dim + m.n_components, Nt = m.n_components;
     slab += (size_t)std::max(prior_colsum_blocks((int)rows), reparam_grid((int)rows)) * Mt * round_up(Nt + 1, 4);
   }
-  if (m.behaviour == 1) slab += (size_t)lg * (m.n_components * m.latent_dim + m.latent_dim);
+  if (m.behaviour == 1) slab += (size_t)lg * (m.n_components * m.latent_dim + m.latent_dim) + 4;
   if (any_wide) slab += (size_t)wide_splits(p, rows) * p->wide_len + 4;
   w->slab_floats = slab;
   w->slab = c.take<float>(slab);
@@ -665,7 +665,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
       ReduceSeg sb = sw;
       sb.src_off += (int64_t)K * D; sb.rows = 1; sb.cols = D; sb.dst_off = m.pm_b_off; sb.dst_si = 0; sb.dst_sj = 1;
       red.segs[red.n_segs++] = sb;
-      slab_off += (size_t)nb * ncol;
+      slab_off += ((size_t)nb * ncol + 3) & ~size_t(3);  // the encoder's GEMM slabs follow: 16-byte aligned
     }
     ReduceSeg sh{};
     sh.src_off = 0; sh.slab_stride = m.head_len; sh.n_slabs = lworkers / loss_workers_per_block(); sh.rows = 1; sh.cols = m.head_len;  // one row per block

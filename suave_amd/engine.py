@@ -128,11 +128,22 @@ class Engine:
 
     # -- workspace -------------------------------------------------------------
     def workspace(self, rows: int) -> torch.Tensor:
-        if self._ws is None or rows > self._ws_rows:
+        """The caller-owned scratch of the step / decode entry points, grown on demand.  Its size depends on the
+        process-wide GEMM arithmetic and small-batch settings (include/suave_hip.h: "size workspaces after changing
+        it"), so a change of either -- the automatic switch to the wide arithmetic included -- re-sizes it."""
+
+        mode, small = C.c_int(0), C.c_int(0)
+        self.lib.suave_gemm_arithmetic_get(C.byref(mode))
+        self.lib.suave_small_batch_rows_get(C.byref(small))
+        stamp = (mode.value, small.value)
+        if self._ws is None or rows > self._ws_rows or stamp != getattr(self, "_ws_stamp", None):
+            rows = max(int(rows), int(self._ws_rows or 0))
             nbytes = C.c_size_t()
             _lib.check(self.lib.suave_workspace_bytes(self._plan, int(rows), C.byref(nbytes)), "suave_workspace_bytes")
-            self._ws = torch.empty(int(nbytes.value) + 256, dtype=torch.uint8, device=self.device)
+            if self._ws is None or int(nbytes.value) + 256 > self._ws.numel():
+                self._ws = torch.empty(int(nbytes.value) + 256, dtype=torch.uint8, device=self.device)
             self._ws_rows = rows
+            self._ws_stamp = stamp
         return self._ws
 
     # -- data formats either side of the path (f1 / f2) -----------------------------
