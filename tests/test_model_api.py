@@ -331,3 +331,22 @@ def test_device_head_fit_agrees_with_the_torch_head_fit(monkeypatch):
         assert abs(a["train_elbo_loss"] - b["train_elbo_loss"]) < 2e-3 * abs(b["train_elbo_loss"])
     pa, pb = m_dev.predict_proba(df.iloc[:200]), m_ref.predict_proba(df.iloc[:200])
     assert np.abs(np.asarray(pa) - np.asarray(pb)).max() < 5e-3
+
+
+@pytest.mark.gpu
+def test_the_class_survives_random_schemas_and_settings(monkeypatch):
+    """scripts/api_fuzz.py, sixteen random (schema, missingness, behaviour, K, D, hidden, batch, dropout, val_split)
+    cases: fit -> finite history; encode; sample (chunking invariance, dtypes, ranges; conditional); impute under the
+    three assignment strategies (no NaN left, observed numeric cells kept); impute_mc; predict_proba (label and
+    attribute); calibrate; save -> load -> bit-identical encode."""
+
+    import importlib.util
+    import os
+    import sys
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "api_fuzz.py")
+    spec = importlib.util.spec_from_file_location("api_fuzz", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["api_fuzz.py", "16", "4"])
+    assert mod.main() == 0
