@@ -7,7 +7,7 @@ from suave_amd import lib as _lib
 if os.environ.get("SUAVE_LIB"):
     _lib._LIB_PATH = os.environ["SUAVE_LIB"]
 L = _lib.load()
-sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-profile"]
+sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-subrecords", "--gen-rows", "0"]
 out = (ctypes.c_ulonglong * 16)()
 L.suave_debug_loss_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
 L.suave_debug_loss_timing(out, 1)
@@ -23,4 +23,3 @@ for t, nm in enumerate(["real", "pos", "count", "cat", "ordinal"]):
 print(f"outputs+writeback  {v[6] / tiles:10.0f} cycles per wave-tile")
 print(f"whole wave         {v[7] / max(v[14], 1):10.0f} cycles per wave")
 print(f"  recon/sum part   {v[15] / tiles:10.0f} cycles per wave-tile")
-print(f"  + ds_part stores {v[12] / tiles:10.0f} cycles per wave-tile (cumulative)")

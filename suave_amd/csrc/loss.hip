@@ -13,11 +13,14 @@
 // loads; then each of the 4 wavefronts walks its share of the chunk's columns
 // with LANE = ROW, so the column's type, class count, normalisation statistics
 // and head weights are wave-uniform (scalar loads, no divergence between
-// lanes).  dY overwrites y in LDS and is written back coalesced.  Per-row
-// terms are reduced across the 4 waves through LDS; head-weight gradients are
-// reduced across the 64 rows with DPP wavefront reductions, accumulated per
-// block in LDS over the block's tiles, and flushed once to a slab that a
-// fixed-order reduction sums (deterministic, no float atomics).
+// lanes).  dY overwrites y in LDS and is written back coalesced.  Head-weight
+// gradients are reduced across the 64 rows inside the wavefront -- the y part
+// with DPP wavefront reductions, the per-component part with a segmented DPP
+// scan over lanes ordered by component (see seg_add) -- accumulated per wave
+// in LDS over its tiles, and flushed once per block to a slab that a
+// fixed-order reduction sums (deterministic, no float atomics in global
+// memory; the LDS adds of one instruction hit distinct addresses, two lanes
+// at most on one).
 #include <type_traits>
 
 #include "kernels.h"
@@ -26,6 +29,17 @@ namespace suave {
 
 
 namespace {
+
+// Timing-only ablation bits (scripts/loss_ablate.py builds one library per value; results are wrong by construction;
+// 0 in every product build, where the guarded code folds away).  1: no dY write-back; 2 / 4: no per-component / no
+// y-part accumulator adds; 8: no ds_part stores; 16: no wavefront sums; 32: no column loop; 64: y-part adds as plain
+// stores; 512: y-part adds one lane at a time; 1024 / 2048 / 4096 / 8192: skip real+pos / count / categorical /
+// ordinal columns; 16384: non-temporal dY and ds_part stores; 32768: dY read from LDS but not stored; 65536: no
+// ragged-edge dY stores; 131072: dY stored fully coalesced (wrong place).
+#ifndef SUAVE_LOSS_ABL
+#define SUAVE_LOSS_ABL 0
+#endif
+constexpr int kAbl = SUAVE_LOSS_ABL;
 
 constexpr int kMissing = kCellMissing;
 // Every wavefront is an independent worker on (64-row tile, column chunk) tasks with private LDS: no block
@@ -36,6 +50,7 @@ constexpr int kWeightPad = 32;  // readable floats past a chunk's weight image: 
 
 // Sum over the 64 lanes with DPP row operations; result is wave-uniform.
 __device__ __forceinline__ float wave_sum_dpp(float v) {
+  if (kAbl & 16) return v;
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
@@ -45,17 +60,47 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// v of the lane a DPP control selects (lanes the control leaves out, and rows outside row_mask, read 0)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_get_or_minus1(int v) {
+  return __builtin_amdgcn_update_dpp(-1, v, CTRL, ROW_MASK, 0xF, false);
+}
+
+// v_rcp_f32 (1 ulp) in place of the IEEE division sequence (ten instructions): the likelihood terms and their
+// gradients are checked to 1e-4, every divisor here is >= kEps or >= 1
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoid_fast(float x) { return rcp_fast(1.0f + __expf(-x)); }
+__device__ __forceinline__ float softplus_grad_fast(float x) { return x > 20.0f ? 1.0f : sigmoid_fast(x); }
+
 // Fire-and-forget LDS add (ds_add_f32, no return value to wait for).  Every index is only ever
 // touched by one wavefront, in program order, so the sum order is fixed (deterministic).
 __device__ __forceinline__ void acc_add(float* hw, int idx, float v, int lane) {
+  if (kAbl & 4) return;
+  if (kAbl & 64) { if (lane == 0) hw[idx] = v; return; }
   if (lane == 0) (void)__hip_atomic_fetch_add(hw + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Per-lane LDS add: lane r adds its value at the slot of its own component.  Lanes that share a
-// component collide on one address and are serialised by the LDS unit in a fixed order, and no other
-// wavefront ever touches these slots, so the result is reproducible run to run.
-__device__ __forceinline__ void acc_add_lanes(float* slot, float v) {
-  (void)__hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// The same for up to YB consecutive accumulators at once: lane i takes the wave-uniform t[i] (v_writelane) and lanes
+// 0 .. n-1 add with ONE DS instruction at distinct addresses, instead of n single-lane adds.
+template <int YB>
+__device__ __forceinline__ void acc_add_vec(float* hw, const float (&t)[YB], int n, int lane) {
+  if (kAbl & 4) return;
+  if (kAbl & 512) {
+#pragma unroll
+    for (int i = 0; i < YB; ++i)
+      if (i < n) acc_add(hw, i, t[i], lane);
+    return;
+  }
+  int packed = 0;
+#pragma unroll
+  for (int i = 0; i < YB; ++i)  // (no clang builtin for v_writelane_b32 in this toolchain; immediate lane select: no hazard)
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(packed) : "s"(__builtin_bit_cast(int, t[i])), "n"(i));
+  if (lane < n)
+    (void)__hip_atomic_fetch_add(hw + lane, __builtin_bit_cast(float, packed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 }  // namespace
@@ -147,12 +192,45 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
     float* dst = a.y + (size_t)(r0 + lr) * a.ldY + ybase + q * 4;
     const int c0 = q * 4 - lead;
     if (c0 >= 0 && c0 + 3 < ch.y_len) {
-      *reinterpret_cast<float4*>(dst) = make_float4(src[c0], src[c0 + 1], src[c0 + 2], src[c0 + 3]);
-    } else {
+      const float4 v4 = make_float4(src[c0], src[c0 + 1], src[c0 + 2], src[c0 + 3]);
+      if (kAbl & 32768) { asm volatile("" ::"v"(v4.x), "v"(v4.y), "v"(v4.z), "v"(v4.w)); return; }
+      if (kAbl & 131072) {  // same bytes, fully coalesced (timing only)
+        float* d2 = a.y + ((size_t)(r0 / 64) * gridDim.y + blockIdx.y) * (64 * ch.y_len) + (size_t)(lr * nq + q) * 4;
+        *reinterpret_cast<float4*>(d2 - ((size_t)d2 & 15) / 4) = v4;
+        return;
+      }
+      if (kAbl & 16384) {
+        __builtin_nontemporal_store(v4.x, dst); __builtin_nontemporal_store(v4.y, dst + 1);
+        __builtin_nontemporal_store(v4.z, dst + 2); __builtin_nontemporal_store(v4.w, dst + 3);
+        return;
+      }
+      *reinterpret_cast<float4*>(dst) = v4;
+    } else if (!(kAbl & 65536)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (c0 + e >= 0 && c0 + e < ch.y_len) dst[e] = src[c0 + e];
     }
+  };
+  // Component part of a head-weight gradient: slot_base[k] += sum of g over the tile's rows assigned to component k.
+  // The lanes of each half wavefront work on their 32 tile rows in component order (set up per tile below), so a
+  // component's rows are a run of neighbouring lanes: a segmented scan over DPP row shifts (four steps inside a row of
+  // 16 lanes, one row_bcast:15 step across the two rows of a half) leaves the run's sum in its last lane, and those
+  // lanes -- at most one per component and half -- add it to the accumulator.  (One ds_add_f32 from all 64 lanes at
+  // slot_base[k] was applied lane after lane by the LDS unit where lanes shared a component, 6.4 of them on average
+  // at K = 10: a fifth of the kernel's time.)  Fixed order: every slot is touched by this wavefront only, DS
+  // operations of a wavefront execute in program order, and the two halves' lanes of one instruction hit a slot in
+  // lane order.
+  bool sg1 = false, sg2 = false, sg4 = false, sg8 = false, sgb = false, sg_end = false;
+  int seg_k = 0;
+  auto seg_add = [&](float* slot_base, float g) {
+    if (kAbl & 2) return;
+    float v = g, t;
+    t = v + dpp_get<0x111>(v); v = sg1 ? t : v;        // row_shr:1
+    t = v + dpp_get<0x112>(v); v = sg2 ? t : v;        // row_shr:2
+    t = v + dpp_get<0x114>(v); v = sg4 ? t : v;        // row_shr:4
+    t = v + dpp_get<0x118>(v); v = sg8 ? t : v;        // row_shr:8
+    t = v + dpp_get<0x142, 0xA>(v); v = sgb ? t : v;   // row_bcast:15 into rows 1 and 3
+    if (sg_end) (void)__hip_atomic_fetch_add(slot_base + seg_k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   // Register-blocked discrete heads (y_dim = classes <= YB): the column's y slice and, class by class, its weight
   // row are read from LDS in one batch (clamped, branch-free), and the YB wavefront reductions of a class's weight
@@ -207,15 +285,13 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
         float t[YB];
 #pragma unroll
         for (int i = 0; i < YB; ++i) t[i] = wave_sum_dpp(g * yv[i]);
+        acc_add_vec<YB>(hr, t, yd, lane);
 #pragma unroll
-        for (int i = 0; i < YB; ++i) {
-          if (i < yd) acc_add(hr, i, t[i], lane);
-          dy[i] += g * wv[i];
-        }
+        for (int i = 0; i < YB; ++i) dy[i] += g * wv[i];
 #pragma unroll
         for (int j = 0; j < KMAX; ++j)
           if (j < K) ds[j] += g * wk[j];
-        acc_add_lanes(hr + yd + k, g);
+        seg_add(hr + yd, g);
       }
 #pragma unroll
       for (int i = 0; i < YB; ++i)
@@ -248,7 +324,7 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
     for (int j = 0; j < YB; ++j) {
       if (j < C - 1) {
         thr += softplus_f(raw[j]) + kEps;
-        const float sgj = sigmoid_f(thr - mo);
+        const float sgj = sigmoid_fast(thr - mo);
         if (j == t) sg_t = sgj;
         if (j == t - 1) sg_tm1 = sgj;
       }
@@ -258,24 +334,21 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
     lp_out = __logf(p);
     recon += obs ? lp_out : 0.f;
     if (GRAD) {
-      const float gp = (obs && p_raw >= kEps && p_raw <= 1.0f) ? u / p : 0.f;
+      const float gp = (obs && p_raw >= kEps && p_raw <= 1.0f) ? u * rcp_fast(p) : 0.f;
       const float du_t = (gp != 0.f && t < C - 1) ? gp * sg_t * (1.0f - sg_t) : 0.f;
       const float du_tm1 = (gp != 0.f && t > 0) ? -gp * sg_tm1 * (1.0f - sg_tm1) : 0.f;
       const float gmean = -(du_t + du_tm1);
       float s[YB];
 #pragma unroll
       for (int i = 0; i < YB; ++i) s[i] = wave_sum_dpp(gmean * yv[i]);
+      acc_add_vec<YB>(hwm, s, yd, lane);
 #pragma unroll
-      for (int i = 0; i < YB; ++i) {
-        if (i < yd) {
-          acc_add(hwm, i, s[i], lane);
-          yb[i] = gmean * wmv[i];
-        }
-      }
+      for (int i = 0; i < YB; ++i)
+        if (i < yd) yb[i] = gmean * wmv[i];
 #pragma unroll
       for (int j = 0; j < KMAX; ++j)
         if (j < K) ds[j] += gmean * wmk[j];
-      acc_add_lanes(hwm + yd + k, gmean);
+      seg_add(hwm + yd, gmean);
 #pragma unroll
       for (int jj = 0; jj < YB; ++jj) {
         if (jj < C - 1) {
@@ -283,11 +356,11 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
 #pragma unroll
           for (int j = 0; j < KMAX; ++j) wk[j] = wl[jj * K + j];
           const float dsp = (jj <= t - 1 ? du_tm1 : 0.f) + (jj <= t ? du_t : 0.f);
-          const float gpart = dsp * softplus_grad_f(raw[jj]);
+          const float gpart = dsp * softplus_grad_fast(raw[jj]);
 #pragma unroll
           for (int j = 0; j < KMAX; ++j)
             if (j < K) ds[j] += gpart * wk[j];
-          acc_add_lanes(hw + jj * K + k, gpart);
+          seg_add(hw + jj * K, gpart);
         }
       }
     }
@@ -314,14 +387,49 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
       if (lr < nrows) v = *reinterpret_cast<const float4*>(a.y + (size_t)(r0 + lr) * a.ldY + ybase + q * 4);
       put_y(lr, q, v);
     }
-    const int k = k_pre;
-    const float up = up_pre;
+    const int k_nat = k_pre;  // (lane = tile row order)
+    const float up_nat = up_pre;
     if (tile + n_workers < n_tiles) prefetch(tile + n_workers);
 
-    // ---- column phase: lane = row, wave-uniform column ----
-    const bool valid = lane < nrows;
+    // ---- lane order of the column phase: each half wavefront takes its 32 tile rows sorted by (component, row) ----
+    // (rows 0..31 stay in lanes 0..31, so the y reads at row * ldy keep their conflict-free bank pattern; the cell
+    // loads and per-row stores move inside one 256-byte segment)
+    int rank = 0;
+    {
+      int base_lo = 0, base_hi = 0;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        if (j < K) {
+          const unsigned long long m = __ballot(k_nat == j);
+          const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+          const int below = lane >= 32 ? 32 + base_hi + (int)__builtin_amdgcn_mbcnt_hi(hi, 0u)
+                                       : base_lo + (int)__builtin_amdgcn_mbcnt_lo(lo, 0u);
+          if (k_nat == j) rank = below;
+          base_lo += __popc(lo);
+          base_hi += __popc(hi);
+        }
+      }
+    }
+    int* order_s = reinterpret_cast<int*>(gsw - lane);  // 64 words of the categorical scratch (free between columns)
+    order_s[rank] = lane;
+    const int my_row = order_s[lane];
+    const int k = __builtin_amdgcn_ds_bpermute(my_row << 2, k_nat);
+    const float up = __int_as_float(__builtin_amdgcn_ds_bpermute(my_row << 2, __float_as_int(up_nat)));
+    seg_k = k;
+    sg1 = dpp_get_or_minus1<0x111>(k) == k;
+    sg2 = dpp_get_or_minus1<0x112>(k) == k;
+    sg4 = dpp_get_or_minus1<0x114>(k) == k;
+    sg8 = dpp_get_or_minus1<0x118>(k) == k;
+    sgb = dpp_get_or_minus1<0x142, 0xA>(k) == k;
+    // (read by every lane before the test: a short-circuited || would switch lanes 31 and 63 off, and lanes 30
+    // and 62 would read an inactive lane's zero)
+    const int k_next = __builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, k);
+    sg_end = ((lane & 31) == 31) | (k_next != k);
+
+    // ---- column phase: lane = one tile row (my_row), wave-uniform column ----
+    const bool valid = my_row < nrows;
     // packed cells in tile-transposed layout [row / 64][column][row % 64]: one coalesced load per column
-    const int drow = a.vdiv == 1 ? r0 + lane : (r0 + lane) / a.vdiv;
+    const int drow = a.vdiv == 1 ? r0 + my_row : (r0 + my_row) / a.vdiv;
     const int32_t* cell_ptr = a.cells + ((size_t)(drow >> 6) * a.n_cols) * 64 + (drow & 63);
     float recon = 0.f;
     float ds[KMAX];
@@ -329,13 +437,13 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
 #pragma unroll
       for (int j = 0; j < KMAX; ++j) ds[j] = 0.f;
     }
-    float* yrow = ytile + lane * a.ldy;
+    float* yrow = ytile + my_row * a.ldy;
     int cell_next = valid ? cell_ptr[(size_t)ch.col_begin * 64] : kMissing;
     suave_col_t col_next = a.cols[ch.col_begin];  // descriptor and cell of the next column are fetched a column ahead
 
     LOSS_T(t1);
     LOSS_ACC(0, t1 - t0);
-    for (int c = ch.col_begin; c < ch.col_end; ++c) {
+    for (int c = ch.col_begin; c < ((kAbl & 32) ? ch.col_begin : ch.col_end); ++c) {
       LOSS_T(tc0);
       const suave_col_t col = col_next;
       const int cell = cell_next;
@@ -353,7 +461,10 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
       const float* w = wl;
       float* hw = hw_acc + (col.w_off - hw_begin);
       float lp_cell = 0.f;  // the column's log-likelihood of this row's cell value (placeholder value when masked)
-      if ((col.type == SUAVE_TYPE_REAL || col.type == SUAVE_TYPE_POS) && yd == 1) {
+      if (((kAbl & 1024) && (col.type == SUAVE_TYPE_REAL || col.type == SUAVE_TYPE_POS)) ||
+          ((kAbl & 2048) && col.type == SUAVE_TYPE_COUNT) || ((kAbl & 4096) && col.type == SUAVE_TYPE_CAT) ||
+          ((kAbl & 8192) && col.type == SUAVE_TYPE_ORDINAL)) {
+      } else if ((col.type == SUAVE_TYPE_REAL || col.type == SUAVE_TYPE_POS) && yd == 1) {
         // y_dim == 1 (the default; decoder.py:87-99): every LDS operand of the column is read before the arithmetic starts, the
         // K assignment weights unconditionally up to KMAX (the weight image is padded), so one wait covers them all
         const float* wvl = wsm + (col.w2_off - hw_begin);
@@ -371,15 +482,16 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
         const float xr = x * col.scale + col.shift;
         const float cc = fmaxf(vs, kEps);
         const float rr = xr - mean;
-        float nll = 0.5f * (kLog2Pi + __logf(cc) + rr * rr / cc);
+        const float icc = rcp_fast(cc), rri = rr * icc;
+        float nll = 0.5f * (kLog2Pi + __logf(cc) + rr * rri);
         if (col.type == SUAVE_TYPE_POS) nll += xr;
         lp_cell = -nll;
         recon += obs ? lp_cell : 0.f;
         if (GRAD) {
           // masked / out-of-tile lanes get an exact zero (select, not 0 * x: x may be inf or NaN there)
-          const float ga = obs ? u * (rr / cc) * col.scale : 0.f;
-          const float gb = (obs && vs >= kEps) ? u * (-0.5f) * (1.0f / cc - rr * rr / (cc * cc)) *
-                                                      (col.scale * col.scale) * softplus_grad_f(bv)
+          const float ga = obs ? u * rri * col.scale : 0.f;
+          const float gb = (obs && vs >= kEps) ? u * (-0.5f) * (icc - rri * rri) *
+                                                      (col.scale * col.scale) * softplus_grad_fast(bv)
                                                 : 0.f;
           const float t = wave_sum_dpp(ga * y0);
           yb[0] = ga * w0;
@@ -387,8 +499,8 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
           for (int j = 0; j < KMAX; ++j)
             if (j < K) ds[j] += ga * wk[j] + gb * wvk[j];
           acc_add(hw, 0, t, lane);
-          acc_add_lanes(hw + 1 + k, ga);
-          acc_add_lanes(hwv + k, gb);
+          seg_add(hw + 1, ga);
+          seg_add(hwv, gb);
         }
       } else if (col.type == SUAVE_TYPE_COUNT && yd == 1) {
         const float y0 = yb[0], w0 = wl[0];
@@ -404,14 +516,14 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
         lp_cell = lp;
         recon += obs ? lp : 0.f;
         if (GRAD) {
-          const float gr = obs ? u * (cnt / rc - 1.0f) * softplus_grad_f(rho) : 0.f;
+          const float gr = obs ? u * (cnt * rcp_fast(rc) - 1.0f) * softplus_grad_fast(rho) : 0.f;
           const float t = wave_sum_dpp(gr * y0);
           yb[0] = gr * w0;
 #pragma unroll
           for (int j = 0; j < KMAX; ++j)
             if (j < K) ds[j] += gr * wk[j];
           acc_add(hw, 0, t, lane);
-          acc_add_lanes(hw + 1 + k, gr);
+          seg_add(hw + 1, gr);
         }
       } else if (col.type == SUAVE_TYPE_REAL || col.type == SUAVE_TYPE_POS) {  // y_dim > 1 (Schema y_dimensions override)
         const float* wvl = wsm + (col.w2_off - hw_begin);
@@ -427,15 +539,16 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
         const float xr = x * col.scale + col.shift;
         const float cc = fmaxf(vs, kEps);
         const float rr = xr - mean;
-        float nll = 0.5f * (kLog2Pi + __logf(cc) + rr * rr / cc);
+        const float icc = rcp_fast(cc), rri = rr * icc;
+        float nll = 0.5f * (kLog2Pi + __logf(cc) + rr * rri);
         if (col.type == SUAVE_TYPE_POS) nll += xr;
         lp_cell = -nll;
         recon += obs ? lp_cell : 0.f;
         if (GRAD) {
           // masked / out-of-tile lanes get an exact zero (select, not 0 * x: x may be inf or NaN there)
-          const float ga = obs ? u * (rr / cc) * col.scale : 0.f;
-          const float gb = (obs && vs >= kEps) ? u * (-0.5f) * (1.0f / cc - rr * rr / (cc * cc)) *
-                                                      (col.scale * col.scale) * softplus_grad_f(bv)
+          const float ga = obs ? u * rri * col.scale : 0.f;
+          const float gb = (obs && vs >= kEps) ? u * (-0.5f) * (icc - rri * rri) *
+                                                      (col.scale * col.scale) * softplus_grad_fast(bv)
                                                 : 0.f;
           for (int i = 0; i < yd; ++i) {
             const float t = wave_sum_dpp(ga * yb[i]);
@@ -448,8 +561,8 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
               ds[j] += ga * w[yd + j] + gb * wv[j];
             }
           }
-          acc_add_lanes(hw + yd + k, ga);
-          acc_add_lanes(hwv + k, gb);
+          seg_add(hw + yd, ga);
+          seg_add(hwv, gb);
         }
       } else if (col.type == SUAVE_TYPE_COUNT) {
         float rho = wl[yd + k];
@@ -462,7 +575,7 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
         lp_cell = lp;
         recon += obs ? lp : 0.f;
         if (GRAD) {
-          const float gr = obs ? u * (cnt / rc - 1.0f) * softplus_grad_f(rho) : 0.f;
+          const float gr = obs ? u * (cnt * rcp_fast(rc) - 1.0f) * softplus_grad_fast(rho) : 0.f;
           for (int i = 0; i < yd; ++i) {
             const float t = wave_sum_dpp(gr * yb[i]);
             acc_add(hw, i, t, lane);
@@ -474,7 +587,7 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
               ds[j] += gr * w[yd + j];
             }
           }
-          acc_add_lanes(hw + yd + k, gr);
+          seg_add(hw + yd, gr);
         }
       } else if (col.type == SUAVE_TYPE_CAT) {
         if (yd <= 2) cat_col(std::integral_constant<int, 2>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
@@ -518,7 +631,7 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
                   ds[j] += g * wr[yd + j];
                 }
               }
-              acc_add_lanes(hr + yd + k, g);
+              seg_add(hr + yd, g);
             }
             // sweep 3: dY
             for (int i = 0; i < yd; ++i) {
@@ -544,7 +657,7 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
           float thr = 0.f, sg_t = 1.0f, sg_tm1 = 0.f;
           for (int j = 0; j < C - 1; ++j) {
             thr += softplus_f(wl[j * K + k]) + kEps;
-            const float sgj = sigmoid_f(thr - mo);
+            const float sgj = sigmoid_fast(thr - mo);
             if (j == t) sg_t = sgj;
             if (j == t - 1) sg_tm1 = sgj;
           }
@@ -553,7 +666,7 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
           lp_cell = __logf(p);
           recon += obs ? lp_cell : 0.f;
           if (GRAD) {
-            const float gp = (obs && p_raw >= kEps && p_raw <= 1.0f) ? u / p : 0.f;
+            const float gp = (obs && p_raw >= kEps && p_raw <= 1.0f) ? u * rcp_fast(p) : 0.f;
             const float du_t = (gp != 0.f && t < C - 1) ? gp * sg_t * (1.0f - sg_t) : 0.f;
             const float du_tm1 = (gp != 0.f && t > 0) ? -gp * sg_tm1 * (1.0f - sg_tm1) : 0.f;
             const float gmean = -(du_t + du_tm1);
@@ -568,23 +681,23 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
                 ds[j] += gmean * wm[yd + j];
               }
             }
-            acc_add_lanes(hwm + yd + k, gmean);
+            seg_add(hwm + yd, gmean);
             for (int jj = 0; jj < C - 1; ++jj) {
               const float dsp = (jj <= t - 1 ? du_tm1 : 0.f) + (jj <= t ? du_t : 0.f);
-              const float gpart = dsp * softplus_grad_f(wl[jj * K + k]);
+              const float gpart = dsp * softplus_grad_fast(wl[jj * K + k]);
 #pragma unroll
               for (int j = 0; j < KMAX; ++j) {
                 if (j < K) {
                   ds[j] += gpart * w[jj * K + j];
                 }
               }
-              acc_add_lanes(hw + jj * K + k, gpart);
+              seg_add(hw + jj * K, gpart);
             }
           }
         }
       }
-      if (a.log_px && valid) a.log_px[(size_t)(r0 + lane) * a.n_cols + c] = obs ? lp_cell : 0.f;
-      if (a.log_px_missing && valid) a.log_px_missing[(size_t)(r0 + lane) * a.n_cols + c] = obs ? 0.f : lp_cell;
+      if (a.log_px && valid) a.log_px[(size_t)(r0 + my_row) * a.n_cols + c] = obs ? lp_cell : 0.f;
+      if (a.log_px_missing && valid) a.log_px_missing[(size_t)(r0 + my_row) * a.n_cols + c] = obs ? 0.f : lp_cell;
       LOSS_T(tc1);
       LOSS_ACC(1 + col.type, tc1 - tc0);
       LOSS_ACC(8 + col.type, 1);
@@ -592,7 +705,7 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
     LOSS_T(t2);
 
     // ---- per-row outputs straight from the registers (lane = row) ----
-    if (valid) a.recon_part[(size_t)chunk_id * a.n_rows + r0 + lane] = recon;
+    if (valid) a.recon_part[(size_t)chunk_id * a.n_rows + r0 + my_row] = recon;
     {
       const float tot = wave_sum_dpp(valid ? recon : 0.f);
       sum_recon += (double)tot;
@@ -601,20 +714,19 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
     LOSS_T(t2a);
     LOSS_ACC(15, t2a - t2);
 #endif
-    if (GRAD && a.ds_part && valid) {
+    if (GRAD && a.ds_part && valid && !(kAbl & 8)) {
       // plane-major [chunk][j][row]: lane = row, so every store instruction writes 256 contiguous bytes (the
       // row-major layout scattered 64 x 4 bytes at a 48-byte stride, 15 % of the kernel's time)
-      float* dst = a.ds_part + (size_t)chunk_id * a.ldK * a.n_rows + r0 + lane;
+      float* dst = a.ds_part + (size_t)chunk_id * a.ldK * a.n_rows + r0 + my_row;
 #pragma unroll
       for (int j = 0; j < KMAX; ++j)
-        if (j < K) dst[(size_t)j * a.n_rows] = ds[j];
+        if (j < K) {
+          if (kAbl & 16384) __builtin_nontemporal_store(ds[j], dst + (size_t)j * a.n_rows);
+          else dst[(size_t)j * a.n_rows] = ds[j];
+        }
     }
-#ifdef SUAVE_LOSS_TIMING
-    LOSS_T(t2b);
-    LOSS_ACC(12, t2b - t2);
-#endif
     // ---- write dY back ----
-    if (GRAD) {
+    if (GRAD && !(kAbl & 1)) {
       int lr = y_lr0, q = y_q0;
 #pragma unroll
       for (int u = 0; u < kPre; ++u) {
