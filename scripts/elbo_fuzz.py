@@ -102,6 +102,16 @@ def main():
                      for k, r in ref["grads"].items() if r.size)
             if g0 < tol:
                 status = "ok (relu boundary: exact arithmetic %.1e)" % g0
+        if not status.startswith("ok") and max(errs.values()) < tol and np.isfinite(gerr) and gerr < 3e-2:
+            # ... or the pre-activation is zero to fp32 rounding itself (|pre| < 1e-5 against O(1) terms): then exact
+            # fp32 on the GPU and the oracle's float64 may disagree on relu' too (seed 31, case 277)
+            h, i, margin = x_enc.astype(np.float64), 0, np.inf
+            while f"encoder.backbone.{i}.weight" in P:
+                pre = h @ P[f"encoder.backbone.{i}.weight"].astype(np.float64).T + P[f"encoder.backbone.{i}.bias"]
+                margin = min(margin, float(np.abs(pre).min()))
+                h, i = np.maximum(pre, 0.0), i + 2
+            if margin < 1e-5 and gwhere.startswith("encoder.backbone"):
+                status = "ok (relu boundary: |pre-activation| %.1e)" % margin
         bad += not status.startswith("ok")
         print(f"case {case}: {behaviour[:5]} cols={n_cols} K={K} D={D} hidden={hidden} B={B} tau={tau} small={small} "
               f"terms={max(errs.values()):.1e} grad={gerr:.1e} ({gwhere}) {status}", flush=True)
