@@ -363,7 +363,11 @@ __global__ __launch_bounds__(256) void k_group_scatter(GroupArgs a) {
 
 // supervised, step 2 (4 lanes per row): z = mu_k + eps * exp(lv_k / 2) from the selected component's head
 // outputs, and both KL terms with their gradients -- everything that only needs the compact head row.
+#ifndef SUAVE_REPARAM_ABL
+#define SUAVE_REPARAM_ABL 0  // timing-only ablation bits (1: no prior column sums, 2: no categorical KL, 4: no generator); 0 in product builds
+#endif
 __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
+  constexpr int kAblR = SUAVE_REPARAM_ABL;
   extern __shared__ float prior_s[];  // [K*D] prior mu | [K*D] prior logvar | [K*D] +-1 / max(exp(logvar), 1e-6)
   __shared__ float red_s[8];
   // Prior gradients without the [B, 2D + K] round trip through HBM: the 64 rows' terms go to an LDS tile; thread
@@ -371,6 +375,7 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
   // component (a thread owns its accumulators: no atomics, fixed order); the row groups are combined in order into
   // the block's slab, and the per-block slabs are summed by the fixed-order reduction, as k_prior_colsum's were.
   __shared__ int kk_s[64];
+  __shared__ float lp_s[SUAVE_MAX_COMPONENTS], ep_s[SUAVE_MAX_COMPONENTS];  // log-softmax of the prior logits, and its exp
   const bool colsum = a.grad && a.prior_slab != nullptr;
   const int n_terms = 2 * a.D + a.K;
   const int kTS = n_terms | 1;                     // odd row stride of the tile
@@ -394,6 +399,14 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
     plv_s[i] = l;
     const float vp_raw = __expf(l);  // sign of the stored reciprocal: negative when the 1e-6 floor is active
     ivp_s[i] = vp_raw >= 1e-6f ? 1.0f / vp_raw : -1e6f;
+  }
+  if (tid < K) {
+    const float* pl = a.params + a.prior_logits_off;
+    float mp = -INFINITY, sp = 0.f;
+    for (int j = 0; j < K; ++j) mp = fmaxf(mp, pl[j]);
+    for (int j = 0; j < K; ++j) sp += __expf(pl[j] - mp);
+    lp_s[tid] = pl[tid] - (mp + __logf(sp));
+    ep_s[tid] = __expf(lp_s[tid]);
   }
   __syncthreads();
   const bool vec = (D & 3) == 0;
@@ -422,7 +435,9 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
           lv_nx = *reinterpret_cast<const float4*>(lv + (q + 4) * 4);
         }
         float ev[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.eps_in == nullptr) {
+        if (kAblR & 4) {
+          ev[0] = ev[1] = ev[2] = ev[3] = 0.5f;
+        } else if (a.eps_in == nullptr) {
           const uint4 w = rng(rid, (uint32_t)q, kStreamEps, (uint32_t)a.step);
           const float2 n0 = normal2(w.x, w.y), n1 = normal2(w.z, w.w);
           ev[0] = n0.x; ev[1] = n0.y; ev[2] = n1.x; ev[3] = n1.y;
@@ -488,28 +503,54 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
     }
     gk += __shfl_xor(gk, 1, 64);
     gk += __shfl_xor(gk, 2, 64);
+    // categorical KL of the row and its gradients: the row's four lanes take every fourth component each (the prior's
+    // log-softmax comes from LDS, once per block)
     float ck = 0.f;
-    if (v4 && qd == 0) {
+    if (!(kAblR & 2)) {
       const float* lg = a.sel + (size_t)r * a.ldS;
-      const float* pl = a.params + a.prior_logits_off;
-      float mq = -INFINITY, mp = -INFINITY;
-      for (int j = 0; j < K; ++j) { mq = fmaxf(mq, lg[j]); mp = fmaxf(mp, pl[j]); }
-      float sq = 0.f, sp = 0.f;
-      for (int j = 0; j < K; ++j) { sq += __expf(lg[j] - mq); sp += __expf(pl[j] - mp); }
-      const float lq = mq + __logf(sq), lp = mp + __logf(sp);
-      for (int j = 0; j < K; ++j) {
-        const float logq = lg[j] - lq, logp = pl[j] - lp;
-        ck += __expf(logq) * (logq - logp);
+      constexpr int kPer = SUAVE_MAX_COMPONENTS / 4;
+      float lgv[kPer];
+      float mq = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) {
+        const int j = qd + 4 * i;
+        lgv[i] = j < K ? lg[j] : -INFINITY;
+        mq = fmaxf(mq, lgv[i]);
       }
-      if (a.grad) {
-        for (int j = 0; j < K; ++j) {
-          const float logq = lg[j] - lq, logp = pl[j] - lp;
-          const float q = __expf(logq);
-          a.gkl_logit[(size_t)r * a.ldK + j] = a.bk * q * ((logq - logp) - ck);
-          if (colsum) terms_s[lr * kTS + 2 * D + j] = a.bk * (__expf(logp) - q);
-          else a.prior_terms[(size_t)r * a.ldT + 2 * D + j] = a.bk * (__expf(logp) - q);
+      mq = fmaxf(mq, __shfl_xor(mq, 1, 64));
+      mq = fmaxf(mq, __shfl_xor(mq, 2, 64));
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < kPer; ++i)
+        if (qd + 4 * i < K) sq += __expf(lgv[i] - mq);
+      sq += __shfl_xor(sq, 1, 64);
+      sq += __shfl_xor(sq, 2, 64);
+      const float lq = mq + __logf(sq);
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) {
+        const int j = qd + 4 * i;
+        if (j < K) {
+          const float logq = lgv[i] - lq;
+          ck += __expf(logq) * (logq - lp_s[j]);
         }
       }
+      ck += __shfl_xor(ck, 1, 64);
+      ck += __shfl_xor(ck, 2, 64);
+      if (a.grad && v4) {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+          const int j = qd + 4 * i;
+          if (j < K) {
+            const float logq = lgv[i] - lq, logp = lp_s[j];
+            const float q = __expf(logq);
+            a.gkl_logit[(size_t)r * a.ldK + j] = a.bk * q * ((logq - logp) - ck);
+            if (colsum) terms_s[lr * kTS + 2 * D + j] = a.bk * (ep_s[j] - q);
+            else a.prior_terms[(size_t)r * a.ldT + 2 * D + j] = a.bk * (ep_s[j] - q);
+          }
+        }
+      }
+    }
+    if (v4 && qd == 0) {
       a.catkl[r] = ck;
       a.gausskl[r] = gk;
     }
@@ -518,7 +559,7 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
     if (colsum && qd == 0) kk_s[lr] = v4 ? kk : -1;
     __syncthreads();
     if (lane == 0) { red_s[wave * 2] = t_c; red_s[wave * 2 + 1] = t_g; }
-    if (colsum) {
+    if (colsum && !(kAblR & 1)) {
       const int g = tid / n_terms;
       if (g < RG) {
         for (int c = tid - g * n_terms; c < n_terms; c += 256) {  // (more than 256 term columns: RG = 1, several per thread)
@@ -531,7 +572,7 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
       }
     }
     __syncthreads();
-    if (colsum) {  // row groups in order -> slab[c][k] (c < 2 D: per component; the K logits terms: all rows, column K)
+    if (colsum && !(kAblR & 1)) {  // row groups in order -> slab[c][k] (c < 2 D: per component; the K logits terms: all rows, column K)
       const bool first = r0 == (int)blockIdx.x * 64;  // later tiles of the block add to its slab (same thread, same address)
       for (int o = tid; o < 2 * D * K + K; o += 256) {
         const bool per_comp = o < 2 * D * K;
