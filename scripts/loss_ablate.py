@@ -7,7 +7,7 @@ import bench
 from suave_amd import lib as _lib
 if os.environ.get("SUAVE_LIB"):
     _lib._LIB_PATH = os.environ["SUAVE_LIB"]
-sys.argv = ["bench.py", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-subrecords", "--gen-rows", "0"]
+sys.argv = ["bench.py", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-subrecords", "--gen-rows", "0"] + sys.argv[1:]
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
     bench.main()

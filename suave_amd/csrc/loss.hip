@@ -115,7 +115,10 @@ __device__ unsigned long long g_loss_dbg[16];
 #endif
 
 template <bool GRAD, int KMAX>
-__global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS admits three blocks per CU)
+#ifndef SUAVE_LOSS_MINBLOCKS  // tuning knob: 4 (128 registers, no prefetch slots) with 16-float chunks is within 3 % either way
+#define SUAVE_LOSS_MINBLOCKS 3
+#endif
+__global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(LossArgs a) {  // (LDS admits three blocks per CU)
 #ifdef SUAVE_LOSS_TIMING
   unsigned long long dbg_acc[16] = {0};
   LOSS_T(tk0);
@@ -147,7 +150,13 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
   // registers before the column phase of the current one and stored to LDS after it, so the HBM round trip
   // hides behind the arithmetic.  Each lane owns up to kPre float4 of the 64 x y_len slice (fixed (row,
   // float4) coordinates for the whole kernel); wider chunks stage the rest directly.
-  constexpr int kPre = 6;
+  // (Two slots: six -- the whole 24-column slice in registers -- cost 20 registers, 40 bytes of scratch per lane and
+  // 5 us at 65 536 rows, where a wave has one tile and nothing to prefetch; at 262 144 rows two beat none by 2 %.)
+#ifdef SUAVE_LOSS_KPRE  // tuning knob
+  constexpr int kPre = SUAVE_LOSS_KPRE;
+#else
+  constexpr int kPre = 2;
+#endif
   const int ybase = ch.y_begin & ~3;  // aligned start column
   const int lead = ch.y_begin - ybase;
   const int nq = (lead + ch.y_len + 3) / 4;
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(kLossThreads, 3) void k_loss(LossArgs a) {  // (LDS
   // kept, the others follow by adding (64 / nq, 64 % nq) with carry (wave-uniform increments)
   const int y_lr0 = lane / nq, y_q0 = lane - y_lr0 * nq;
   const int step_lr = 64 / nq, step_q = 64 - step_lr * nq;
-  float4 y_pre[kPre];
+  float4 y_pre[kPre > 0 ? kPre : 1];
   int k_pre = 0;
   float up_pre = 0.f;
   auto prefetch = [&](int tile) {
