@@ -37,7 +37,7 @@ def main():
     for case in range(n_cases):
         behaviour = str(rng.choice(["supervised", "unsupervised"]))
         n_cols = int(rng.integers(1, 30))
-        K = int(rng.integers(1, 11))
+        K = int(rng.integers(1, 11)) if rng.random() < 0.8 else int(rng.integers(11, 33))  # (k_loss: KMAX 8 / 12 / 16 / 32)
         D = int(rng.choice([2, 3, 8, 16, 32, 33]))
         hidden = tuple(int(rng.choice([8, 24, 32, 64, 100])) for _ in range(int(rng.integers(1, 3))))
         B = int(rng.choice([1, 63, 64, 65, 256, 300, 777]))
@@ -105,13 +105,21 @@ def main():
         if not status.startswith("ok") and max(errs.values()) < tol and np.isfinite(gerr) and gerr < 3e-2:
             # ... or the pre-activation is zero to fp32 rounding itself (|pre| < 1e-5 against O(1) terms): then exact
             # fp32 on the GPU and the oracle's float64 may disagree on relu' too (seed 31, case 277)
-            h, i, margin = x_enc.astype(np.float64), 0, np.inf
-            while f"encoder.backbone.{i}.weight" in P:
-                pre = h @ P[f"encoder.backbone.{i}.weight"].astype(np.float64).T + P[f"encoder.backbone.{i}.bias"]
-                margin = min(margin, float(np.abs(pre).min()))
-                h, i = np.maximum(pre, 0.0), i + 2
-            if margin < 1e-5 and gwhere.startswith("encoder.backbone"):
-                status = "ok (relu boundary: |pre-activation| %.1e)" % margin
+            def margin_of(prefix, h):
+                i, m = 0, np.inf
+                while f"{prefix}.{i}.weight" in P:
+                    pre = h @ P[f"{prefix}.{i}.weight"].astype(np.float64).T + P[f"{prefix}.{i}.bias"]
+                    m = min(m, float(np.abs(pre).min()))
+                    h, i = np.maximum(pre, 0.0), i + 2
+                return m
+            if behaviour == "supervised":
+                z = ref["latent"].astype(np.float64)
+            else:  # every component's latent goes through the decoder
+                z = (ref["component_mu"] + noise["eps"] * np.exp(0.5 * ref["component_logvar"])).reshape(B * K, D).astype(np.float64)
+            m_enc, m_dec = margin_of("encoder.backbone", x_enc.astype(np.float64)), margin_of("decoder.backbone", z)
+            # (a flipped decoder unit changes dz and with it every encoder gradient; a flipped encoder unit only those)
+            if m_dec < 1e-5 or (m_enc < 1e-5 and gwhere.startswith("encoder.backbone")):
+                status = "ok (relu boundary: |pre-activation| encoder %.1e decoder %.1e)" % (m_enc, m_dec)
         bad += not status.startswith("ok")
         print(f"case {case}: {behaviour[:5]} cols={n_cols} K={K} D={D} hidden={hidden} B={B} tau={tau} small={small} "
               f"terms={max(errs.values()):.1e} grad={gerr:.1e} ({gwhere}) {status}", flush=True)

@@ -19,8 +19,8 @@
 // scan over lanes ordered by component (see seg_add) -- accumulated per wave
 // in LDS over its tiles, and flushed once per block to a slab that a
 // fixed-order reduction sums (deterministic, no float atomics in global
-// memory; the LDS adds of one instruction hit distinct addresses, two lanes
-// at most on one).
+// memory; the lanes of an LDS add instruction always hit distinct addresses,
+// so the order of the additions is program order).
 #include <type_traits>
 
 #include "kernels.h"
@@ -227,8 +227,7 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
   // lanes -- at most one per component and half -- add it to the accumulator.  (One ds_add_f32 from all 64 lanes at
   // slot_base[k] was applied lane after lane by the LDS unit where lanes shared a component, 6.4 of them on average
   // at K = 10: a fifth of the kernel's time.)  Fixed order: every slot is touched by this wavefront only, DS
-  // operations of a wavefront execute in program order, and the two halves' lanes of one instruction hit a slot in
-  // lane order.
+  // operations of a wavefront execute in program order, and the two halves add in two instructions.
   bool sg1 = false, sg2 = false, sg4 = false, sg8 = false, sgb = false, sg_end = false;
   int seg_k = 0;
   auto seg_add = [&](float* slot_base, float g) {
@@ -239,7 +238,14 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
     t = v + dpp_get<0x114>(v); v = sg4 ? t : v;        // row_shr:4
     t = v + dpp_get<0x118>(v); v = sg8 ? t : v;        // row_shr:8
     t = v + dpp_get<0x142, 0xA>(v); v = sgb ? t : v;   // row_bcast:15 into rows 1 and 3
+#ifdef SUAVE_LOSS_ONE_ADD  // timing knob: both halves in one instruction (two lanes may then share a slot)
     if (sg_end) (void)__hip_atomic_fetch_add(slot_base + seg_k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    // one instruction per half: no two lanes of a DS instruction ever add at the same address, so the order of the
+    // additions is program order and nothing rests on how the LDS unit serialises same-address lanes
+    if (sg_end && lane < 32) (void)__hip_atomic_fetch_add(slot_base + seg_k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (sg_end && lane >= 32) (void)__hip_atomic_fetch_add(slot_base + seg_k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
   };
   // Register-blocked discrete heads (y_dim = classes <= YB): the column's y slice and, class by class, its weight
   // row are read from LDS in one batch (clamped, branch-free), and the YB wavefront reductions of a class's weight
