@@ -35,7 +35,8 @@ namespace {
 // y-part accumulator adds; 8: no ds_part stores; 16: no wavefront sums; 32: no column loop; 64: y-part adds as plain
 // stores; 512: y-part adds one lane at a time; 1024 / 2048 / 4096 / 8192: skip real+pos / count / categorical /
 // ordinal columns; 16384: non-temporal dY and ds_part stores; 32768: dY read from LDS but not stored; 65536: no
-// ragged-edge dY stores; 131072: dY stored fully coalesced (wrong place).
+// ragged-edge dY stores; 131072: dY stored fully coalesced (wrong place); 262144: 9..16-wide discrete heads on the
+// operand-at-a-time path (results stay right).
 #ifndef SUAVE_LOSS_ABL
 #define SUAVE_LOSS_ABL 0
 #endif
@@ -608,6 +609,7 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
         if (yd <= 2) cat_col(std::integral_constant<int, 2>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
         else if (yd <= 4) cat_col(std::integral_constant<int, 4>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
         else if (yd <= 8) cat_col(std::integral_constant<int, 8>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
+        else if (yd <= 16 && !(kAbl & 262144)) cat_col(std::integral_constant<int, 16>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
         else {  // more classes than the register-blocked paths take: one LDS round trip per operand
   const int C = col.n_classes;
           const int ldw = yd + K;
@@ -660,6 +662,7 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
         const int need = max(yd, col.n_classes - 1);  // y features and thresholds both live in YB registers
         if (need <= 4) ord_col(std::integral_constant<int, 4>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
         else if (need <= 8) ord_col(std::integral_constant<int, 8>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
+        else if (need <= 16 && !(kAbl & 262144)) ord_col(std::integral_constant<int, 16>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
         else {
   const int C = col.n_classes;
           const float* wml = wsm + (col.w2_off - hw_begin);  // mean_layer [yd + K]
