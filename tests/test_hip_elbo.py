@@ -136,6 +136,46 @@ def test_s64_step_matches_oracle(B, dropout):
     _grad_check(eng.grad_state(), ref["grads"])
 
 
+@pytest.mark.parametrize("K,B", [(1, 64), (2, 31), (7, 65), (12, 200), (13, 64), (16, 129), (17, 1), (32, 257)])
+def test_component_sums_of_the_likelihood_kernel(K, B):
+    """The per-component part of the head-weight gradients is a segmented scan over lanes ordered by component
+    (loss.hip seg_add): every register variant of the kernel (K <= 8 / 12 / 16 / 32), full, ragged and one-row tiles,
+    components with no row in a half wavefront; discrete heads of 2 .. 16 classes (the 2- / 4- / 8- / 16-wide register
+    blocks) against the CPU oracle."""
+
+    import torch
+    from suave_amd.engine import PackedTable
+
+    cols = [orc.Column("r", "real", stats={"mean": 0.3, "std": 1.7}), orc.Column("p", "pos", stats={"mean_log": 0.1, "std_log": 0.6}),
+            orc.Column("n", "count", stats={"offset": 1.0})]
+    cols += [orc.Column(f"c{c}", "cat", n_classes=c) for c in (2, 3, 5, 9, 16)]
+    cols += [orc.Column(f"o{c}", "ordinal", n_classes=c) for c in (3, 6, 10, 16)]
+    om = orc.OracleModel(cols, n_components=K, latent_dim=4, hidden=(16,), dropout=0.0)
+    P = om.init_params(seed=K)
+    rng = np.random.default_rng(100 + K)
+    for k in P:
+        if ".heads." in k:
+            P[k] = (0.3 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    xnum, codes, mask = synth_packed(cols, B, 0.15, seed=K * 1000 + B)
+    x_enc, data, masks = orc.dense_from_packed(om, xnum, codes, mask)
+    noise = {"exp": rng.exponential(size=(B, K)).astype(np.float32), "eps": rng.standard_normal((B, 4)).astype(np.float32)}
+    ref = orc.elbo_supervised(om, P, x_enc, data, masks, noise, beta_scale=1.0, tau=1.0, training=True)
+    eng = _engine(om, P)
+    table = PackedTable(xnum, codes, mask, eng.device)
+    res = eng.elbo(table, 0, B, beta_scale=1.0, tau=1.0, grad=True, noise=torch_noise(noise, eng.device),
+                   want=("reconstruction", "component"))
+    torch.cuda.synchronize()
+    assert np.array_equal(res["component"].cpu().numpy().astype(np.int64), ref["component_indices"])
+    assert rel_err(res["reconstruction"].cpu().numpy(), ref["reconstruction"]) < TOL
+    # (one-row batches: the Gumbel-softmax Jacobian cancels O(100) terms in fp32, see scripts/elbo_fuzz.py)
+    _grad_check(eng.grad_state(), ref["grads"], tol=TOL if B >= 32 else 2e-3)
+    first = {k: np.asarray(v).copy() for k, v in eng.grad_state().items()}
+    eng.elbo(table, 0, B, beta_scale=1.0, tau=1.0, grad=True, noise=torch_noise(noise, eng.device))
+    torch.cuda.synchronize()
+    again = eng.grad_state()
+    assert all(np.array_equal(first[k], np.asarray(again[k])) for k in first)  # bit-reproducible
+
+
 @pytest.mark.parametrize("behaviour", ["supervised", "unsupervised"])
 def test_w1024_miniature_step_matches_oracle(behaviour):
     """BASELINE config #4 in miniature (64 columns, categoricals up to 256 classes: the GEMM head path next to
