@@ -3,8 +3,12 @@ import collections, glob, sqlite3, sys
 paths = sys.argv[1:] or sorted(glob.glob("gpurun_out/**/*_results.db", recursive=True))[-1:]
 for path in paths:
     c = sqlite3.connect(path)
-    tabs = {r[0].rsplit("_00000000", 1)[0]: r[0] for r in c.execute("select name from sqlite_master where type='table'")}
-    t = lambda n: tabs[n]
+    names = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    # tables carry a per-run suffix (rocpd_kernel_dispatch_<guid>): the shortest name that starts with the wanted one
+    t = lambda n: min((x for x in names if x == n or x.startswith(n + "_")), key=len)
+    if not any(x.startswith("rocpd_info_kernel_symbol") for x in names):
+        print("==", path, "(no kernel tables: skipped)")
+        continue
     sym = dict(c.execute(f"select id, kernel_name from {t('rocpd_info_kernel_symbol')}"))
     disp = {}
     dur = collections.defaultdict(list)
