@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Headline benchmark: ELBO train rows/sec (BASELINE.json), S64 schema.
 
 A "step" is one pass of the hot path over one batch: packed-batch gather ->
