@@ -462,6 +462,11 @@ __global__ __launch_bounds__(256, 2) void k_decode_fused(DecodeFusedArgs a) {
           for (int q = 0; q < (int)(sizeof(suave_col_t) / 4); ++q) raw[q] = cp[q];
           __builtin_memcpy(&col, raw, sizeof(col));
         }
+#if DEC_ABL >= 5 && DEC_ABL <= 8  // timing only: one column type skipped (5 real + pos, 6 count, 7 categorical, 8 ordinal)
+        if ((DEC_ABL == 5 && col.type <= SUAVE_TYPE_POS) || (DEC_ABL == 6 && col.type == SUAVE_TYPE_COUNT) ||
+            (DEC_ABL == 7 && col.type == SUAVE_TYPE_CAT) || (DEC_ABL == 8 && col.type == SUAVE_TYPE_ORDINAL))
+          continue;
+#endif
         const int y_off = col.y_off;
         const int u_off = ((const __attribute__((address_space(4))) int32_t*)(uintptr_t)a.u_off)[cidx];
         const float* w = w_s + (col.w_off - sa.head_off);

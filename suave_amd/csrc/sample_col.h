@@ -81,6 +81,16 @@ __device__ inline float poisson_from_noise(float rate, float u, float n) {
   return small ? k : big;
 }
 
+// 1 / i, correctly rounded, for the first-stage Poisson walk: the loop index is wave-uniform, so the entry is a scalar
+// load (same value as __frcp_rn(i), which is the ten-instruction IEEE division in these translation units)
+struct InvIntTable { float v[513]; };
+constexpr InvIntTable make_inv_int_table() {
+  InvIntTable t{};
+  for (int i = 1; i <= 512; ++i) t.v[i] = 1.0f / (float)i;
+  return t;
+}
+static __constant__ InvIntTable kInvInt = make_inv_int_table();
+
 struct SampleArgs {
   const suave_col_t* cols;
   const int32_t* cls_off;  // [n_cols] offset of the column's classes in noise_exp
@@ -187,7 +197,7 @@ __device__ __forceinline__ void sample_cell(const SampleArgs& a, const suave_col
         bool go = sure && (uni > cdf);
         for (int i = 1; i <= 512 && go; ++i) {
           const float fi = (float)i;
-          p = p * rate_f * __frcp_rn(fi);
+          p = p * rate_f * kInvInt.v[i];
           cdf += p;
           k = fi;
           gap = fminf(gap, fabsf(uni - cdf));
