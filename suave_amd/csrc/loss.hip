@@ -454,7 +454,14 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
       for (int j = 0; j < KMAX; ++j) ds[j] = 0.f;
     }
     float* yrow = ytile + my_row * a.ldy;
-    int cell_next = valid ? cell_ptr[(size_t)ch.col_begin * 64] : kMissing;
+#ifndef SUAVE_LOSS_CELL_AHEAD  // tuning knob: columns whose cell is in flight ahead of the one being worked on (2 .. 4: within 2 % on S64 and W1024)
+#define SUAVE_LOSS_CELL_AHEAD 1
+#endif
+    constexpr int kAhead = SUAVE_LOSS_CELL_AHEAD;
+    int cell_q[kAhead];  // at the top of the column loop: the cells of columns c .. c + kAhead - 1
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u)
+      cell_q[u] = (valid && ch.col_begin + u < ch.col_end) ? cell_ptr[(size_t)(ch.col_begin + u) * 64] : kMissing;
     suave_col_t col_next = a.cols[ch.col_begin];  // descriptor and cell of the next column are fetched a column ahead
 
     LOSS_T(t1);
@@ -462,9 +469,11 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
     for (int c = ch.col_begin; c < ((kAbl & 32) ? ch.col_begin : ch.col_end); ++c) {
       LOSS_T(tc0);
       const suave_col_t col = col_next;
-      const int cell = cell_next;
+      const int cell = cell_q[0];
       if (c + 1 < ch.col_end) {
-        cell_next = valid ? cell_ptr[(size_t)(c + 1) * 64] : kMissing;
+#pragma unroll
+        for (int u = 0; u + 1 < kAhead; ++u) cell_q[u] = cell_q[u + 1];
+        cell_q[kAhead - 1] = (valid && c + kAhead < ch.col_end) ? cell_ptr[(size_t)(c + kAhead) * 64] : kMissing;
         col_next = a.cols[c + 1];
       }
       const bool obs = cell != kMissing;
