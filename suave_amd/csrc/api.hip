@@ -603,7 +603,7 @@ int elbo_unsup_impl(const suave_plan* p, const float* params, const suave_batch_
     a.head_off = m.head_off; a.head_len = m.head_len; a.hw_max = p->hw_max;
     a.xsrc = p->xsrc_dev; a.ldx = p->loss_ldx; a.ldm = p->loss_ldm; a.cells = w.cells; a.n_cols = m.n_cols;
     if (n_chunks > 0)
-      if (int rc = launch_loss(a, grad, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
+      if (int rc = launch_loss(a, grad, p->kmax, p->loss_wide16 != 0, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
   }
   const int n_wide = (int)p->wide_host.size();
   const int n_parts = n_chunks + (n_wide ? 1 : 0);
@@ -876,7 +876,7 @@ int elbo_impl(const suave_plan* p, const float* params, const suave_batch_t* bat
     a.xsrc = p->xsrc_dev; a.ldx = p->loss_ldx; a.ldm = p->loss_ldm; a.cells = w.cells; a.n_cols = m.n_cols;
     a.log_px = w.log_px; a.log_px_missing = w.log_px_missing;
     if (n_chunks > 0)
-      if (int rc = launch_loss(a, grad, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
+      if (int rc = launch_loss(a, grad, p->kmax, p->loss_wide16 != 0, lgrid, n_chunks, p->loss_lds_bytes, s)) return rc;
   }
   const int n_wide = (int)p->wide_host.size();
   const int n_parts = n_chunks + (n_wide ? 1 : 0);
@@ -1133,7 +1133,12 @@ extern "C" int suave_plan_create(const suave_model_t* model, const suave_col_t* 
     }
     if (len2 ? col.w2_off != hw + len1 : col.w2_off != -1) return fail("plan_create: second head tensor misplaced");
     hw += len1 + len2;
-    if (col.type == SUAVE_TYPE_CAT) max_classes = std::max(max_classes, col.n_classes);
+    // per-class LDS scratch of the likelihood kernel: only its operand-at-a-time categorical path (y_dim > 16: a
+    // Schema y_dimensions override) parks logits there; the register-blocked heads recompute them
+    if (col.type == SUAVE_TYPE_CAT && col.y_dim > 16) max_classes = std::max(max_classes, col.n_classes);
+    // (loss.hip: y_dim for a categorical head, max(y_dim, classes - 1) for an ordinal one, 9 .. 16)
+    const int blk = col.type == SUAVE_TYPE_CAT ? col.y_dim : col.type == SUAVE_TYPE_ORDINAL ? std::max(col.y_dim, col.n_classes - 1) : 0;
+    if (blk > 8 && blk <= 16) p->loss_wide16 = 1;
     ++p->n_narrow;
   }
   if (sum_y != m.total_y) return fail("plan_create: total_y mismatch");
@@ -1692,7 +1697,7 @@ extern "C" int suave_decode_log_px(const suave_plan* p, const float* params, con
   a.xsrc = p->xsrc_dev; a.ldx = p->loss_ldx; a.ldm = p->loss_ldm; a.cells = w.cells; a.n_cols = m.n_cols;
   a.log_px = log_px; a.log_px_missing = log_px_missing;
   if (n_chunks > 0)
-    if (int rc = launch_loss(a, false, p->kmax, lgrid, n_chunks, p->loss_lds_bytes, st)) return rc;
+    if (int rc = launch_loss(a, false, p->kmax, p->loss_wide16 != 0, lgrid, n_chunks, p->loss_lds_bytes, st)) return rc;
   if (!p->wide_host.empty())
     return wide_forward(p, params, w, B, 1, component, nullptr, nullptr, 0.f, false, w.recon_part + (size_t)n_chunks * B,
                         w.sums_slab + (size_t)lworkers * n_chunks * 4, st);

@@ -106,6 +106,7 @@ struct suave_plan {
   int hw_max;         // widest per-chunk range of likelihood-head weights
   int loss_blocks;    // grid.x of the loss kernel
   size_t loss_lds_bytes;
+  int loss_wide16;    // a narrow categorical / ordinal column needs the 16-wide register blocks of the likelihood kernel
   // wide categorical columns
   std::vector<suave::WideCol> wide_host;
   suave::WideCol* wide_dev = nullptr;

@@ -227,7 +227,7 @@ int launch_prior_colsum(const float* terms, int ldT, const int32_t* kidx, int n_
 size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes, int ldx, int ldm);
 int loss_set_lds_limit(size_t lds_bytes);
 int loss_workers_per_block();
-int launch_loss(const LossArgs& a, bool grad, int kmax, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s);
+int launch_loss(const LossArgs& a, bool grad, int kmax, bool wide16, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s);
 // Row-major copies W^T [n_in, ldT] of the layer weights W [n_out, ld]: with them the data-gradient GEMM
 // dA = dC * W reads both operands k-contiguous, i.e. it is a forward-type product the split kernels handle.
 // The copies are written by extra blocks of the step's first launch (k_expand): as a launch of its own the

@@ -35,8 +35,7 @@ namespace {
 // y-part accumulator adds; 8: no ds_part stores; 16: no wavefront sums; 32: no column loop; 64: y-part adds as plain
 // stores; 512: y-part adds one lane at a time; 1024 / 2048 / 4096 / 8192: skip real+pos / count / categorical /
 // ordinal columns; 16384: non-temporal dY and ds_part stores; 32768: dY read from LDS but not stored; 65536: no
-// ragged-edge dY stores; 131072: dY stored fully coalesced (wrong place); 262144: 9..16-wide discrete heads on the
-// operand-at-a-time path (results stay right).
+// ragged-edge dY stores; 131072: dY stored fully coalesced (wrong place).
 #ifndef SUAVE_LOSS_ABL
 #define SUAVE_LOSS_ABL 0
 #endif
@@ -115,11 +114,12 @@ __device__ unsigned long long g_loss_dbg[16];
 #define LOSS_ACC(i, v)
 #endif
 
-template <bool GRAD, int KMAX>
-#ifndef SUAVE_LOSS_MINBLOCKS  // tuning knob: 4 (128 registers, no prefetch slots) with 16-float chunks is within 3 % either way
-#define SUAVE_LOSS_MINBLOCKS 3
-#endif
-__global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(LossArgs a) {  // (LDS admits three blocks per CU)
+// WIDE16: the plan has narrow discrete heads of 9 .. 16 classes, which take the 16-wide register blocks (168 registers,
+// three waves per SIMD).  Without them the kernel fits 128 registers with no prefetch slots and no scratch: four waves
+// per SIMD, 97 -> 89 us on S64 at 65 536 rows (same box) now that the per-wave LDS admits four blocks per CU.
+template <bool GRAD, int KMAX, bool WIDE16>
+__global__ __launch_bounds__(kLossThreads, WIDE16 ? 3 : 4) void k_loss(LossArgs a) {
+  constexpr bool kWide16 = WIDE16;
 #ifdef SUAVE_LOSS_TIMING
   unsigned long long dbg_acc[16] = {0};
   LOSS_T(tk0);
@@ -129,11 +129,14 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_floats = 64 * a.ldy + 2 * a.hw_max + kWeightPad + a.max_classes * 64;
-  float* ytile = lds + (size_t)wave * wave_floats;  // [64][ldy]  this wave's y slice, overwritten with dY
-  float* hw_acc = ytile + 64 * a.ldy;               // [hw_max]   head-weight gradients of this chunk
-  float* wsm = hw_acc + a.hw_max;                   // [hw_max]   this chunk's head weights
-  float* gsw = wsm + a.hw_max + kWeightPad + lane;  // [max_classes][64] per-class scratch of the categorical head
+  // LDS: [hw_max + pad] the chunk's head weights, shared by the block's waves (they work on the same chunk) | per wave:
+  // [64][ldy] y slice, overwritten with dY | [hw_max] head-weight gradients | [max_classes][64] scratch (the lane order
+  // of a tile; the logits of the operand-at-a-time categorical path)
+  const int wave_floats = 64 * a.ldy + a.hw_max + a.max_classes * 64;
+  float* wsm = lds;
+  float* ytile = lds + a.hw_max + kWeightPad + (size_t)wave * wave_floats;
+  float* hw_acc = ytile + 64 * a.ldy;
+  float* gsw = hw_acc + a.hw_max + lane;
   const int chunk_id = blockIdx.y;
   const ColChunk ch = a.chunks[chunk_id];
   const int hw_begin = a.cols[ch.col_begin].w_off;
@@ -143,9 +146,10 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
   const int hw_next = (chunk_id + 1 < (int)gridDim.y) ? a.cols[a.chunks[chunk_id + 1].col_begin].w_off
                                                       : a.head_off + a.head_len;
   const int hw_len = min(a.hw_max, hw_next - hw_begin);
-  for (int i = lane; i < a.hw_max + kWeightPad; i += 64) wsm[i] = i < hw_len ? a.params[hw_begin + i] : 0.f;
+  for (int i = tid; i < a.hw_max + kWeightPad; i += kLossThreads) wsm[i] = i < hw_len ? a.params[hw_begin + i] : 0.f;
   if (GRAD)
     for (int i = lane; i < a.hw_max; i += 64) hw_acc[i] = 0.f;
+  __syncthreads();  // the shared weight image is complete (the kernel's only other barrier is the one before the flush)
 
   // Tile staging is software-pipelined: the y slice and the per-row scalars of the NEXT tile are loaded into
   // registers before the column phase of the current one and stored to LDS after it, so the HBM round trip
@@ -153,10 +157,11 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
   // float4) coordinates for the whole kernel); wider chunks stage the rest directly.
   // (Two slots: six -- the whole 24-column slice in registers -- cost 20 registers, 40 bytes of scratch per lane and
   // 5 us at 65 536 rows, where a wave has one tile and nothing to prefetch; at 262 144 rows two beat none by 2 %.)
+  // The four-wave variant has none (they are what it gives up for its 128 registers).
 #ifdef SUAVE_LOSS_KPRE  // tuning knob
   constexpr int kPre = SUAVE_LOSS_KPRE;
 #else
-  constexpr int kPre = 2;
+  constexpr int kPre = WIDE16 ? 2 : 0;
 #endif
   const int ybase = ch.y_begin & ~3;  // aligned start column
   const int lead = ch.y_begin - ybase;
@@ -273,7 +278,6 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
       float L = wr[yd + k];
 #pragma unroll
       for (int i = 0; i < YB; ++i) L += wv[i] * yv[i];
-      gsw[cl * 64] = L;
       if (L > mx) { se = se * __expf(mx - L) + 1.0f; mx = L; }
       else se += __expf(L - mx);
       if (cl == code) lcode = L;
@@ -296,7 +300,10 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
         for (int i = 0; i < YB; ++i) wv[i] = wr[min(i, yd - 1)];
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) wk[j] = wr[yd + j];  // (reads past K stay inside the padded weight image)
-        const float p = __expf(gsw[cl * 64] - lse);
+        float L = wr[yd + k];  // the class's logit again (YB multiply-adds) instead of 256 bytes of LDS per class and wave
+#pragma unroll
+        for (int i = 0; i < YB; ++i) L += wv[i] * yv[i];
+        const float p = __expf(L - lse);
         const float g = live ? u * ((cl == code ? 1.0f : 0.f) - p) : 0.f;
         float t[YB];
 #pragma unroll
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
         if (yd <= 2) cat_col(std::integral_constant<int, 2>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
         else if (yd <= 4) cat_col(std::integral_constant<int, 4>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
         else if (yd <= 8) cat_col(std::integral_constant<int, 8>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
-        else if (yd <= 16 && !(kAbl & 262144)) cat_col(std::integral_constant<int, 16>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
+        else if (yd <= 16 && kWide16) cat_col(std::integral_constant<int, 16>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
         else {  // more classes than the register-blocked paths take: one LDS round trip per operand
   const int C = col.n_classes;
           const int ldw = yd + K;
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
         const int need = max(yd, col.n_classes - 1);  // y features and thresholds both live in YB registers
         if (need <= 4) ord_col(std::integral_constant<int, 4>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
         else if (need <= 8) ord_col(std::integral_constant<int, 8>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
-        else if (need <= 16 && !(kAbl & 262144)) ord_col(std::integral_constant<int, 16>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
+        else if (need <= 16 && kWide16) ord_col(std::integral_constant<int, 16>{}, col, cell, obs, u, yb, wl, hw, k, recon, ds, lp_cell);
         else {
   const int C = col.n_classes;
           const float* wml = wsm + (col.w2_off - hw_begin);  // mean_layer [yd + K]
@@ -784,7 +791,7 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
     // barrier of the kernel, after every wave has left its tile loop).  A row per worker made the slab reduction
     // four times deeper -- it was that launch's critical path.
     __syncthreads();
-    const float* h0 = lds + 64 * a.ldy;
+    const float* h0 = lds + a.hw_max + kWeightPad + 64 * a.ldy;
     float* dst = a.head_slab + (size_t)blockIdx.x * a.head_len + (hw_begin - a.head_off);
     for (int i = tid; i < hw_len; i += kLossThreads)
       dst[i] = ((h0[i] + h0[(size_t)wave_floats + i]) + h0[2 * (size_t)wave_floats + i]) + h0[3 * (size_t)wave_floats + i];
@@ -800,33 +807,43 @@ __global__ __launch_bounds__(kLossThreads, SUAVE_LOSS_MINBLOCKS) void k_loss(Los
 
 size_t loss_lds_bytes(int ldy, int K, int hw_max, int max_classes, int ldx, int ldm) {
   (void)K; (void)ldx; (void)ldm;
-  return (size_t)kLossWaves * ((size_t)64 * ldy + 2 * (size_t)hw_max + kWeightPad + (size_t)max_classes * 64) * sizeof(float);
+  return ((size_t)hw_max + kWeightPad + (size_t)kLossWaves * ((size_t)64 * ldy + (size_t)hw_max + (size_t)max_classes * 64)) * sizeof(float);
 }
 
 int loss_workers_per_block() { return kLossWaves; }
 
-template <int KMAX>
+template <int KMAX, bool WIDE16>
 static int launch_loss_k(const LossArgs& a, bool grad, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s) {
   if (grad)
-    hipLaunchKernelGGL((k_loss<true, KMAX>), dim3(grid_x, n_chunks), dim3(kLossThreads), lds_bytes, s, a);
+    hipLaunchKernelGGL((k_loss<true, KMAX, WIDE16>), dim3(grid_x, n_chunks), dim3(kLossThreads), lds_bytes, s, a);
   else
-    hipLaunchKernelGGL((k_loss<false, KMAX>), dim3(grid_x, n_chunks), dim3(kLossThreads), lds_bytes, s, a);
+    hipLaunchKernelGGL((k_loss<false, KMAX, WIDE16>), dim3(grid_x, n_chunks), dim3(kLossThreads), lds_bytes, s, a);
   SUAVE_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_loss(const LossArgs& a, bool grad, int kmax, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s) {
+template <bool WIDE16>
+static int launch_loss_w(const LossArgs& a, bool grad, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s) {
+  if (a.K <= 8) return launch_loss_k<8, WIDE16>(a, grad, grid_x, n_chunks, lds_bytes, s);
+  if (a.K <= 12) return launch_loss_k<12, WIDE16>(a, grad, grid_x, n_chunks, lds_bytes, s);
+  if (a.K <= 16) return launch_loss_k<16, WIDE16>(a, grad, grid_x, n_chunks, lds_bytes, s);
+  return launch_loss_k<32, WIDE16>(a, grad, grid_x, n_chunks, lds_bytes, s);
+}
+
+// wide16: the plan's loss_wide16 (a narrow discrete head of 9 .. 16 classes exists: the three-wave variant)
+int launch_loss(const LossArgs& a, bool grad, int kmax, bool wide16, int grid_x, int n_chunks, size_t lds_bytes, hipStream_t s) {
+  (void)kmax;
   if (a.n_rows <= 0) return 0;
   ProfScope prof_scope(kProfLoss, s);
-  if (a.K <= 8) return launch_loss_k<8>(a, grad, grid_x, n_chunks, lds_bytes, s);
-  if (a.K <= 12) return launch_loss_k<12>(a, grad, grid_x, n_chunks, lds_bytes, s);
-  if (a.K <= 16) return launch_loss_k<16>(a, grad, grid_x, n_chunks, lds_bytes, s);
-  return launch_loss_k<32>(a, grad, grid_x, n_chunks, lds_bytes, s);
+  return wide16 ? launch_loss_w<true>(a, grad, grid_x, n_chunks, lds_bytes, s)
+                : launch_loss_w<false>(a, grad, grid_x, n_chunks, lds_bytes, s);
 }
 
 template <bool GRAD, int KMAX>
 static int set_lds_one(size_t lds_bytes) {
-  SUAVE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loss<GRAD, KMAX>),
+  SUAVE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loss<GRAD, KMAX, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  SUAVE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loss<GRAD, KMAX, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   return 0;
 }
