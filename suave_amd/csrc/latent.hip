@@ -41,7 +41,13 @@ __device__ __forceinline__ void transpose_tiles(const TransArgs& a, int m, int f
 
 // Blocks [0, n_expand) expand the batch; blocks behind them write the transposed weight copies of `trans`
 // (independent work riding in the step's first launch).
-__global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_map, const int32_t* __restrict__ xsrc,
+#ifndef SUAVE_EXPAND_MINBLOCKS  // tuning knob
+#define SUAVE_EXPAND_MINBLOCKS 1
+#endif
+#ifndef SUAVE_EXPAND_STAGE  // tuning knob
+#define SUAVE_EXPAND_STAGE 4
+#endif
+__global__ __launch_bounds__(256, SUAVE_EXPAND_MINBLOCKS) void k_expand(const int32_t* __restrict__ enc_map, const int32_t* __restrict__ xsrc,
                                                 suave_batch_t b, int n_num, int n_disc, int n_cols, int ldI,
                                                 int rows_per_block, float* __restrict__ x, int32_t* __restrict__ cells,
                                                 int n_expand, TransArgs trans) {
@@ -69,7 +75,10 @@ __global__ __launch_bounds__(256) void k_expand(const int32_t* __restrict__ enc_
     int64_t my_tr = -1;
     if (lane < rows_w && lw0 + lane < nrows) my_tr = b.row_index ? (int64_t)b.row_index[r0 + lw0 + lane] : b.row_begin + r0 + lw0 + lane;
     const int n_max = max(n_num, max(n_disc, n_cols));
-    constexpr int kStage = 8;  // rows of cell loads in flight per wave (16 per round was slower: 0.049 -> 0.080 ms)
+    // Rows of cell loads in flight per wave.  The row ids (64-bit) and the staged values of kStage rows are what sets the
+    // kernel's register count: 8 rows -> 168 registers, three blocks per CU and 2 552 blocks in 3.3 rounds; 4 rows -> 96
+    // registers, five blocks per CU: 47 -> 38 us at 65 536 rows, W1024 0.57 -> 0.47 ms (2 rows: 60 registers, 40 us).
+    constexpr int kStage = SUAVE_EXPAND_STAGE;
     for (int j0 = 0; j0 < rows_w; j0 += kStage) {
       int64_t tr[kStage];
 #pragma unroll
