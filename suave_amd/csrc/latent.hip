@@ -624,7 +624,10 @@ __global__ __launch_bounds__(256) void k_reparam(LatentFwdArgs a) {
 // issued before anything waits: the assignment-gradient partials (four items x four chunks in flight per thread
 // instead of one load at a time), y_soft, the KL logits gradient, and the dz / mu / logvar quads of the two
 // Gaussian passes, which run as one pass (same quad, one dz load) ahead of the barriers of the softmax part.
-__global__ __launch_bounds__(256) void k_latent_bwd(LatentBwdArgs a) {
+#ifndef SUAVE_LATBWD_MINBLOCKS  // tuning knob
+#define SUAVE_LATBWD_MINBLOCKS 4  // 128 registers (145 unconstrained, three blocks per CU: 1 024 blocks in 1.33 rounds); latent class 72.0 -> 68.9 us
+#endif
+__global__ __launch_bounds__(256, SUAVE_LATBWD_MINBLOCKS) void k_latent_bwd(LatentBwdArgs a) {
   constexpr int kDsStride = SUAVE_MAX_COMPONENTS + 1;  // odd stride: lane = row accesses hit distinct banks
   __shared__ float ds_s[64 * kDsStride];
   __shared__ float ys_s[64 * kDsStride];
