@@ -1147,7 +1147,12 @@ int launch_expand(const suave_plan* p, const suave_batch_t& b, float* x, int32_t
   ProfScope prof_scope(kProfExpand, s);
   const suave_model_t& m = p->model;
   const int row_bytes = (m.n_num | 1) * 4 + ((m.n_disc + 1) & ~1) * 2 + ((m.n_cols + 3) & ~3) + 4;  // k_expand's ldn, ldd, ldm
-  static const int rows_cap = [] { const char* e = getenv("SUAVE_EXPAND_ROWS"); return e ? std::max(4, atoi(e) & ~3) : 32; }();  // tuning knob (64 rows: +0.9 % on the S64 step)
+  // Rows per block: 64 from 256 rows per CU on, 32 from 64 rows per CU on, else 16 (measured on S64 with five blocks per CU resident:
+  // 65 536 rows 38.7 us at 32 rows, 33.2 at 64, 46 at 128; 16 384 rows 18.5 at 32, 25.2 at 64; 4 096 rows 16.7 at 32,
+  // 13.3 at 16; 256 rows 15.8 / 12.5 / 12.2 at 32 / 16 / 8; 32 768 rows: 32 ahead of 64 by 2 % of the step), capped by the staging buffer (wide schemas: 8 rows).
+  static const int rows_env = [] { const char* e = getenv("SUAVE_EXPAND_ROWS"); return e ? std::max(4, atoi(e) & ~3) : 0; }();  // tuning knob
+  int rows_cap = rows_env;
+  if (rows_cap == 0) rows_cap = b.n_rows >= (int64_t)256 * p->n_cu ? 64 : b.n_rows >= (int64_t)64 * p->n_cu ? 32 : 16;
   int rows_per_block = std::max(4, std::min(rows_cap, (48 * 1024) / std::max(row_bytes, 1)) & ~3);
   SUAVE_REQUIRE((size_t)rows_per_block * row_bytes <= 48 * 1024, "expand: schema too wide for the staging buffer");
   const int grid = std::min((b.n_rows + rows_per_block - 1) / rows_per_block, 4096);
